@@ -1,0 +1,133 @@
+/*
+ * C ABI of the MI355X path-solve library (libraytracing_amd.so).
+ *
+ * The reference (MaximeLeu/RayTracing) has no FFI layer: its path-solve path is plain Python
+ * (raytracing/geometry.py, raytracing/ray_tracing.py, electromagnetism_fun/electromagnetism.py).  Each entry point
+ * below names the reference function(s) it stands for; a Python binding only needs ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative code on failure; rt_last_error() gives the message of the
+ *     calling thread's last failure; functions returning a handle return NULL on failure;
+ *   - all arrays are dense, row-major, caller-owned; doubles are IEEE binary64, indices int32 unless stated;
+ *   - `on_device` = 0: the array pointers of that call are host memory (the library copies);
+ *     `on_device` = 1: they are device memory of the scene's GPU (nothing is copied, work is queued on the
+ *     scene's stream and the call returns after the stream has been synchronised);
+ *   - a handle may be used by one host thread at a time; handles of different GPUs are independent.
+ */
+#ifndef RT_PATHSOLVE_H
+#define RT_PATHSOLVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_scene rt_scene;
+typedef struct rt_candidates rt_candidates;
+
+#define RT_MAX_ORDER 4 /* interactions per path the solve kernels are instantiated for */
+
+const char *rt_last_error(void);
+int rt_device_count(void);
+
+/* ---- scene --------------------------------------------------------------------------------------------------
+ * The polygon list RayTracingProblem.__init__ takes from place.get_polygons_list() (ray_tracing.py:40), flattened:
+ * vert_off[N+1] CSR offsets, verts[Vtot*3], planes[N*4] = OrientedPolygon.get_parametric() of each polygon
+ * (geometry.py:1747-1765, with the sign fix-ups of geometry.py:2360-2363 already applied), material_id[N] index into
+ * the ITU material table (materials_properties.py:47-104), building_id[N] (geometry.py:2139).  Host pointers.
+ * Frames (geometry.py:1819-1853) and bounding boxes (geometry.py:1437-1465) are derived inside. */
+rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *vert_off, const double *verts,
+                          const double *planes, const int32_t *material_id, const int32_t *building_id);
+void rt_scene_destroy(rt_scene *scene);
+int32_t rt_scene_polygon_count(const rt_scene *scene);
+
+/* ---- obstruction: polygons_obstruct_line_path (geometry.py:836-898) ----------------------------------------------
+ * segs[n_seg*6] = (A, B) per segment; mask[N] or NULL restricts the test to polygons with mask != 0 (the LOS step
+ * passes the emitter visibility, ray_tracing.py:232-236); out[n_seg] = 1 when some polygon obstructs. */
+int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t n_seg, const uint8_t *mask, uint8_t *out,
+                         int on_device);
+/* return_polygons=True form (geometry.py:868-896): out[N] = 1 for every polygon that cuts the one segment. Host. */
+int rt_segment_hits(rt_scene *scene, const double *seg, uint8_t *out);
+
+/* ---- containment: OrientedPolygon.contains_point (geometry.py:1778-1803) -------------------------------------- */
+int rt_contains_points(rt_scene *scene, int32_t polygon, const double *points, int64_t n_points, int check_in_plane,
+                       double plane_tol, uint8_t *out, int on_device);
+
+/* ---- visibility: polygon_visibility_vector / polygons_visibility_matrix (geometry.py:924-1048) --------------------
+ * face_verts[n_face_verts*3], face_normal[3] = the face's get_normal(); self_index = its position in the scene or -1
+ * (an emitter screen, ray_tracing.py:216-219); out[N] receives 0/1 (zero-initialised, unlike geometry.py:953-954).
+ * rt_visibility_matrix writes the symmetrised N*N matrix (geometry.py:1046). */
+int rt_face_visibility(rt_scene *scene, const double *face_verts, int32_t n_face_verts, const double *face_normal,
+                       int32_t self_index, int strict, uint8_t *out);
+int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_device);
+
+/* ---- sharp edges: polygons_sharp_edges_iter (geometry.py:482-565) -----------------------------------------------
+ * Writes up to `capacity` edges in ascending (i, j) order: pairs[2*e] = (i, j), edges[6*e] = the shared edge with its
+ * lexicographically smaller endpoint first (array_utils.py:9-41).  *count = number found (may exceed capacity: call
+ * again with a larger buffer).  Host pointers. */
+int rt_sharp_edges(rt_scene *scene, double min_angle_deg, int32_t *pairs, double *edges, int64_t capacity,
+                   int64_t *count);
+
+/* ---- stand-alone solvers (geometry.py:660-687, 718-748, 800-833), batched over destinations ------------------------
+ * planes[k*4]; out_points[n_dest*k*3] (k reflections) or [n_dest*(k+1)*3] (k reflections then the diffraction point);
+ * out_ok[n_dest] = 1 when a specular solution exists (what sol.success means for a solver that cannot mis-converge).
+ * Host pointers; runs on `device`. */
+int rt_solve_reflections(int device, const double *origin, const double *dests, int64_t n_dest, const double *planes,
+                         int32_t k, double *out_points, uint8_t *out_ok);
+int rt_solve_reflections_diffraction(int device, const double *origin, const double *dests, int64_t n_dest,
+                                     const double *planes, int32_t k, const double *edge, double *out_points,
+                                     uint8_t *out_ok);
+
+/* ---- candidate enumeration: the depth-first loops of RayTracingProblem.solve (ray_tracing.py:299-388) -------------
+ * vis[N*N] (visibility matrix), ev[N] (emitter visibility), edge_pairs[n_edges*2] / edges[n_edges*6] (sharp edges in
+ * dictionary order) — host pointers.  Groups, in the order the reference visits them:
+ *   group g = 0 .. max_order-1            : g+1 reflections                 (ray_tracing.py:324-327)
+ *   group max_order                       : 1 diffraction                   (ray_tracing.py:334-350)
+ *   group max_order + m, m = 1..max_order-1 : m reflections + 1 diffraction (ray_tracing.py:355-388)
+ * Within a group candidates are in the reference's visiting order.  with_diffraction = 0 leaves the diffraction
+ * groups empty (reflection-only workloads). */
+rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, const uint8_t *ev, const int32_t *edge_pairs,
+                            const double *edges, int64_t n_edges, int32_t max_order, int with_diffraction);
+void rt_candidates_destroy(rt_candidates *cand);
+int32_t rt_candidates_group_count(const rt_candidates *cand);
+/* counts[group_count] = candidates per group */
+int rt_candidates_counts(const rt_candidates *cand, int64_t *counts);
+/* chains[count*n_refl] polygon indices and edge_ids[count] (-1 for reflection groups) of one group, host pointers;
+ * either may be NULL. */
+int rt_candidates_group(const rt_candidates *cand, int32_t group, int32_t *chains, int32_t *edge_ids);
+
+/* ---- the solve: LOS + every (receiver, candidate) (ray_tracing.py:232-237, 243-390) ---------------------------------
+ * tx[3], rx[n_rx*3].  Valid paths are appended, in no particular order, to
+ *   out_rx[cap] receiver index, out_group[cap] group (-1 = line of sight), out_cand[cap] index inside the group,
+ *   out_points[cap*RT_MAX_ORDER*3] interaction points (first n of each row used).
+ * *n_found = number of valid paths (if > capacity the surplus was dropped: call again with more room);
+ * *n_attempted = n_rx * (1 + total candidates), the path-solve count of the metric.
+ * on_device selects where rx and the out_* arrays live; the two counters are always host. */
+int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double *tx, const double *rx, int64_t n_rx,
+                   int32_t *out_rx, int32_t *out_group, int32_t *out_cand, double *out_points, int64_t capacity,
+                   int64_t *n_found, int64_t *n_attempted, int on_device);
+/* Device time, in milliseconds, and launch count of each kernel family during the last rt_solve_paths call on this
+ * scene (measured with HIP events on the scene's stream): [0] reflection candidates, [1] diffraction candidates,
+ * [2] segment obstruction, [3] finalisation.  ms[4], launches[4]. */
+int rt_solve_last_timing(rt_scene *scene, double *ms, int64_t *launches, int64_t *segments_tested);
+
+/* ---- field step: my_field_computation (electromagnetism.py:648-802) --------------------------------------------------
+ * Paths as produced by rt_solve_paths (host or device per on_device), n_rx receivers, n_freq carrier frequencies.
+ * Per path and frequency: field[3] complex (re, im interleaved), power; per receiver and frequency: power_db.
+ * status[n_paths] != 0 where the reference would raise an AssertionError (code = which assertion). */
+typedef struct rt_antenna_params {
+    double tx_gain, rx_gain, p_in;
+    int32_t isotropic;
+    int32_t alpha;
+} rt_antenna_params;
+int rt_fields(rt_scene *scene, rt_candidates *cand, const double *tx, const double *rx, int64_t n_rx,
+              const int32_t *path_rx, const int32_t *path_group, const int32_t *path_cand, const double *path_points,
+              int64_t n_paths, const double *freq_hz, int32_t n_freq, const rt_antenna_params *antenna,
+              double *out_field, double *out_power, double *out_angles, double *out_time, int32_t *out_status,
+              double *out_power_db, int on_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,302 @@
+"""ctypes binding of ``libraytracing_amd.so`` (C ABI in ``include/rt_pathsolve.h``).
+
+There is no CPU implementation behind these calls: a missing library or a missing GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+RT_MAX_ORDER = 4
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraytracing_amd.so")
+_lib = None
+
+c_void_p, c_int, c_int32, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class AntennaParams(ctypes.Structure):
+    _fields_ = [("tx_gain", c_double), ("rx_gain", c_double), ("p_in", c_double), ("isotropic", c_int32),
+                ("alpha", c_int32)]
+
+
+_SIGNATURES = {
+    "rt_last_error": (ctypes.c_char_p, []),
+    "rt_device_count": (c_int, []),
+    "rt_scene_create": (c_void_p, [c_int, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rt_scene_destroy": (None, [c_void_p]),
+    "rt_scene_polygon_count": (c_int32, [c_void_p]),
+    "rt_obstruct_segments": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int]),
+    "rt_segment_hits": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "rt_contains_points": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int, c_double, c_void_p, c_int]),
+    "rt_face_visibility": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_void_p]),
+    "rt_visibility_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    "rt_sharp_edges": (c_int, [c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rt_solve_reflections": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    "rt_solve_reflections_diffraction": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
+                                                 c_void_p, c_void_p]),
+    "rt_enumerate": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int]),
+    "rt_candidates_destroy": (None, [c_void_p]),
+    "rt_candidates_group_count": (c_int32, [c_void_p]),
+    "rt_candidates_counts": (c_int, [c_void_p, c_void_p]),
+    "rt_candidates_group": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "rt_solve_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int64, c_void_p, c_void_p, c_int]),
+    "rt_solve_last_timing": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rt_fields": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_int]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Loads the shared library (no GPU call is made)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError(f"{LIB_PATH} is missing: build it with `python -m raytracing_amd.build_ext` "
+                          "(there is no CPU implementation to fall back to)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RtError(f"{what}: {load().rt_last_error().decode()}")
+
+
+def require_gpu():
+    lib = load()
+    if lib.rt_device_count() < 1:
+        raise RtError("no HIP device is visible: the path-solve kernels need a GPU (there is no CPU implementation)")
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+def default_device():
+    return int(os.environ.get("LOCAL_RANK", "0")) % max(1, load().rt_device_count())
+
+
+class Candidates:
+    """Flat candidate lists of one emitter (``rt_enumerate``)."""
+
+    def __init__(self, scene, vis, ev, edge_pairs, edges, max_order, with_diffraction=True):
+        lib = require_gpu()
+        self.scene = scene
+        self.max_order = int(max_order)
+        vis8 = np.ascontiguousarray(vis, dtype=np.uint8)
+        ev8 = np.ascontiguousarray(ev, dtype=np.uint8)
+        n = scene.n
+        if vis8.shape != (n, n) or ev8.shape != (n,):
+            raise ValueError("visibility matrix / emitter visibility do not match the scene")
+        self.edge_pairs = np.ascontiguousarray(edge_pairs, dtype=np.int32).reshape(-1, 2)
+        self.edges = _f64(edges).reshape(-1, 2, 3)
+        self.handle = lib.rt_enumerate(scene.handle, _ptr(vis8), _ptr(ev8), _ptr(self.edge_pairs), _ptr(self.edges),
+                                       len(self.edge_pairs), self.max_order, 1 if with_diffraction else 0)
+        if not self.handle:
+            raise RtError(f"rt_enumerate: {lib.rt_last_error().decode()}")
+        self.n_groups = lib.rt_candidates_group_count(self.handle)
+        self.counts = np.zeros(self.n_groups, dtype=np.int64)
+        if self.n_groups:
+            _check(lib.rt_candidates_counts(self.handle, _ptr(self.counts)), "rt_candidates_counts")
+        self._groups = {}
+
+    def group_kind(self, g):
+        """(number of reflections, ends with a diffraction) of a group."""
+        if g < self.max_order:
+            return g + 1, False
+        return g - self.max_order, True
+
+    def group(self, g):
+        """(chains int32 [count, n_refl], edge_ids int32 [count]) of a group, fetched once."""
+        if g not in self._groups:
+            n_refl, _ = self.group_kind(g)
+            count = int(self.counts[g])
+            chains = np.zeros((count, n_refl), dtype=np.int32)
+            edge_ids = np.zeros(count, dtype=np.int32)
+            _check(load().rt_candidates_group(self.handle, g, _ptr(chains) if chains.size else None, _ptr(edge_ids)),
+                   "rt_candidates_group")
+            self._groups[g] = (chains, edge_ids)
+        return self._groups[g]
+
+    @property
+    def total(self):
+        return int(self.counts.sum())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().rt_candidates_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    """Device-resident polygon list (``rt_scene_create``)."""
+
+    def __init__(self, arrays, device=None):
+        lib = require_gpu()
+        self.device = default_device() if device is None else int(device)
+        self.arrays = arrays
+        self.n = arrays.n
+        self.handle = lib.rt_scene_create(self.device, arrays.n, _ptr(arrays.vert_off), _ptr(arrays.verts),
+                                          _ptr(arrays.planes), _ptr(arrays.material), _ptr(arrays.building))
+        if not self.handle:
+            raise RtError(f"rt_scene_create: {lib.rt_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().rt_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- obstruction ------------------------------------------------------------------------------
+    def obstructed(self, segments, mask=None):
+        segs = _f64(segments).reshape(-1, 6)
+        out = np.zeros(len(segs), dtype=np.uint8)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        _check(load().rt_obstruct_segments(self.handle, _ptr(segs), len(segs), _ptr(m), _ptr(out), 0),
+               "rt_obstruct_segments")
+        return out.astype(bool)
+
+    def segment_hits(self, segments):
+        segs = _f64(segments).reshape(-1, 6)
+        out = np.zeros((len(segs), self.n), dtype=np.uint8)
+        for i in range(len(segs)):
+            _check(load().rt_segment_hits(self.handle, _ptr(segs[i]), _ptr(out[i])), "rt_segment_hits")
+        return out.astype(bool)
+
+    def contains_points(self, polygon_index, points, check_in_plane=False, plane_tol=1e-8):
+        pts = _f64(points).reshape(-1, 3)
+        out = np.zeros(len(pts), dtype=np.uint8)
+        _check(load().rt_contains_points(self.handle, int(polygon_index), _ptr(pts), len(pts), int(bool(check_in_plane)),
+                                         float(plane_tol), _ptr(out), 0), "rt_contains_points")
+        return out.astype(bool)
+
+    # ---- visibility / sharp edges ----------------------------------------------------------------------
+    def face_visibility(self, face_points, face_parametric, self_index=-1, strict=False):
+        pts = _f64(face_points).reshape(-1, 3)
+        normal = _f64(np.asarray(face_parametric)[:3])
+        out = np.zeros(self.n, dtype=np.uint8)
+        _check(load().rt_face_visibility(self.handle, _ptr(pts), len(pts), _ptr(normal), int(self_index),
+                                         int(bool(strict)), _ptr(out)), "rt_face_visibility")
+        return out.astype(bool)
+
+    def visibility_matrix(self, strict=False):
+        out = np.zeros((self.n, self.n), dtype=np.uint8)
+        _check(load().rt_visibility_matrix(self.handle, int(bool(strict)), _ptr(out), 0), "rt_visibility_matrix")
+        return out.astype(bool)
+
+    def sharp_edges(self, min_angle=10.0):
+        cap = 2 * len(self.arrays.verts) + 16
+        pairs = np.zeros((cap, 2), dtype=np.int32)
+        edges = np.zeros((cap, 2, 3), dtype=np.float64)
+        count = np.zeros(1, dtype=np.int64)
+        _check(load().rt_sharp_edges(self.handle, float(min_angle), _ptr(pairs), _ptr(edges), cap, _ptr(count)),
+               "rt_sharp_edges")
+        k = int(count[0])
+        return pairs[:k].copy(), edges[:k].copy()
+
+    # ---- solve ----------------------------------------------------------------------------------------
+    def enumerate(self, vis, ev, edge_pairs, edges, max_order, with_diffraction=True):
+        return Candidates(self, vis, ev, edge_pairs, edges, max_order, with_diffraction)
+
+    def solve_paths(self, candidates, tx, rx, capacity=None):
+        """Host-array form of ``rt_solve_paths``: returns dict(rx, group, cand, points, n_attempted)."""
+        lib = load()
+        tx = _f64(tx).reshape(3)
+        rx = _f64(rx).reshape(-1, 3)
+        if capacity is None:
+            capacity = max(4096, 64 * len(rx))
+        while True:
+            o_rx = np.zeros(capacity, dtype=np.int32)
+            o_group = np.zeros(capacity, dtype=np.int32)
+            o_cand = np.zeros(capacity, dtype=np.int32)
+            o_pts = np.zeros((capacity, RT_MAX_ORDER, 3), dtype=np.float64)
+            found = np.zeros(1, dtype=np.int64)
+            attempted = np.zeros(1, dtype=np.int64)
+            _check(lib.rt_solve_paths(self.handle, candidates.handle, _ptr(tx), _ptr(rx), len(rx), _ptr(o_rx),
+                                      _ptr(o_group), _ptr(o_cand), _ptr(o_pts), capacity, _ptr(found), _ptr(attempted),
+                                      0), "rt_solve_paths")
+            k = int(found[0])
+            if k <= capacity:
+                break
+            capacity = k + k // 8 + 16
+        order = np.lexsort((o_cand[:k], o_group[:k], o_rx[:k]))
+        return dict(rx=o_rx[:k][order], group=o_group[:k][order], cand=o_cand[:k][order], points=o_pts[:k][order],
+                    n_attempted=int(attempted[0]))
+
+    def last_timing(self):
+        ms = np.zeros(4, dtype=np.float64)
+        launches = np.zeros(4, dtype=np.int64)
+        segs = np.zeros(1, dtype=np.int64)
+        _check(load().rt_solve_last_timing(self.handle, _ptr(ms), _ptr(launches), _ptr(segs)), "rt_solve_last_timing")
+        return dict(ms=dict(reflect=ms[0], diffract=ms[1], obstruct=ms[2], finalize=ms[3]),
+                    launches=dict(reflect=int(launches[0]), diffract=int(launches[1]), obstruct=int(launches[2]),
+                                  finalize=int(launches[3])), segments=int(segs[0]))
+
+
+# ---- entry points that need no scene ---------------------------------------------------------------------
+
+def polygon_contains_points(polygon, points, check_in_plane=False, plane_tol=1e-8):
+    from .geometry import scene_arrays_of
+
+    scene = scene_arrays_of([polygon]).device_scene()
+    return scene.contains_points(0, points, check_in_plane, plane_tol)
+
+
+def solve_reflections(origin, destinations, planes, device=None):
+    lib = require_gpu()
+    planes = _f64(planes).reshape(-1, 4)
+    dests = _f64(destinations).reshape(-1, 3)
+    origin = _f64(origin).reshape(3)
+    k = len(planes)
+    out = np.zeros((len(dests), k, 3), dtype=np.float64)
+    ok = np.zeros(len(dests), dtype=np.uint8)
+    _check(lib.rt_solve_reflections(default_device() if device is None else device, _ptr(origin), _ptr(dests),
+                                    len(dests), _ptr(planes), k, _ptr(out), _ptr(ok)), "rt_solve_reflections")
+    return out, ok.astype(bool)
+
+
+def solve_reflections_and_diffraction(origin, destinations, planes, edge, device=None):
+    lib = require_gpu()
+    planes = _f64(planes).reshape(-1, 4)
+    dests = _f64(destinations).reshape(-1, 3)
+    origin = _f64(origin).reshape(3)
+    edge = _f64(edge).reshape(2, 3)
+    k = len(planes)
+    out = np.zeros((len(dests), k + 1, 3), dtype=np.float64)
+    ok = np.zeros(len(dests), dtype=np.uint8)
+    _check(lib.rt_solve_reflections_diffraction(default_device() if device is None else device, _ptr(origin),
+                                                _ptr(dests), len(dests), _ptr(planes) if k else None, k, _ptr(edge),
+                                                _ptr(out), _ptr(ok)), "rt_solve_reflections_diffraction")
+    return out, ok.astype(bool)

@@ -1,0 +1,192 @@
+// Shared declarations of the path-solve library: scene layout in HBM, error handling, small fp64 vector helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rt_pathsolve.h"
+
+#define RT_WAVE 64
+
+// ---------------------------------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------------------------------
+void rt_set_error(const std::string &msg);
+
+#define RT_HIP(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            rt_set_error(std::string(#call) + ": " + hipGetErrorString(e_) + " at " + __FILE__ + ":" +    \
+                         std::to_string(__LINE__));                                                       \
+            return -1;                                                                                    \
+        }                                                                                                 \
+    } while (0)
+
+#define RT_HIP_NULL(call)                                                                                 \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            rt_set_error(std::string(#call) + ": " + hipGetErrorString(e_) + " at " + __FILE__ + ":" +    \
+                         std::to_string(__LINE__));                                                       \
+            return nullptr;                                                                               \
+        }                                                                                                 \
+    } while (0)
+
+#define RT_FAIL(msg)           \
+    do {                       \
+        rt_set_error(msg);     \
+        return -1;             \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// scene: structure-of-arrays in device memory (all read-only after creation)
+// ---------------------------------------------------------------------------------------------------------------
+struct SceneView {
+    int32_t n;               // polygons
+    int32_t vtot;            // vertices
+    int32_t vmax;            // most vertices in one polygon
+    const int32_t *vert_off; // [n+1]
+    const double *verts;     // [vtot*3] world coordinates
+    const double *planes;    // [n*4] nx ny nz d (as the polygon reports them)
+    const double *frames;    // [n*9] rows: x axis, y axis, z axis (= reported normal) of the polygon's own frame
+    const double *bbox;      // [n*6] min xyz, max xyz
+    const double *uv;        // [vtot*2] vertices in the polygon's own frame (first two coordinates)
+    const int32_t *material; // [n]
+    const int32_t *building; // [n]
+};
+
+struct TimingSlot {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+struct rt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    SceneView view{};
+    std::vector<void *> allocations;
+    // host copies used by host-side set-up code
+    std::vector<int32_t> h_vert_off;
+    std::vector<double> h_verts, h_planes, h_bbox;
+    // growable workspace owned by the solve
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    // timing of the last solve
+    double last_ms[4] = {0, 0, 0, 0};
+    int64_t last_launches[4] = {0, 0, 0, 0};
+    int64_t last_segments = 0;
+};
+
+int rt_scene_workspace(rt_scene *scene, size_t bytes, void **out);
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp64 3-vectors
+// ---------------------------------------------------------------------------------------------------------------
+struct d3 {
+    double x, y, z;
+};
+
+__host__ __device__ inline d3 mk3(double x, double y, double z) { return d3{x, y, z}; }
+__host__ __device__ inline d3 ld3(const double *p) { return d3{p[0], p[1], p[2]}; }
+__host__ __device__ inline void st3(double *p, d3 a) {
+    p[0] = a.x;
+    p[1] = a.y;
+    p[2] = a.z;
+}
+__host__ __device__ inline d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__host__ __device__ inline d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__host__ __device__ inline d3 operator*(double s, d3 a) { return d3{s * a.x, s * a.y, s * a.z}; }
+__host__ __device__ inline double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ inline d3 cross(d3 a, d3 b) {
+    return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__host__ __device__ inline double norm3(d3 a) { return sqrt(dot(a, a)); }
+__host__ __device__ inline d3 divs(d3 a, double s) { return d3{a.x / s, a.y / s, a.z / s}; }
+
+// Frame whose z axis is along v: y = ones - (ones·z) z, normalised; x = y × z (reference geometry.py:414-435).
+__host__ __device__ inline void frame_from_vector(d3 v, d3 &fx, d3 &fy, d3 &fz) {
+    fz = divs(v, norm3(v));
+    double s = fz.x + fz.y + fz.z;
+    fy = d3{1.0 - s * fz.x, 1.0 - s * fz.y, 1.0 - s * fz.z};
+    fy = divs(fy, norm3(fy));
+    fx = cross(fy, fz);
+}
+
+// Crossing-number point-in-polygon on a ring given by a coordinate functor; boundary points are inside
+// (the predicate Shapely's Polygon.intersects(Point) answers in reference geometry.py:877, 1803).
+template <typename GetXY>
+__host__ __device__ inline bool pip_inclusive(int nv, GetXY get, double px, double py) {
+    bool inside = false;
+    double ax, ay;
+    get(nv - 1, ax, ay);
+    for (int k = 0; k < nv; ++k) {
+        double bx, by;
+        get(k, bx, by);
+        double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+        if (cr == 0.0 && fmin(ax, bx) <= px && px <= fmax(ax, bx) && fmin(ay, by) <= py && py <= fmax(ay, by))
+            return true;
+        if ((ay > py) != (by > py)) {
+            if ((cr > 0.0) == (by > ay)) inside = !inside;
+        }
+        ax = bx;
+        ay = by;
+    }
+    return inside;
+}
+
+// Exact form of the reference's per-polygon obstruction test (geometry.py:857-884) for one polygon and one
+// segment A->B.
+__device__ inline bool polygon_cuts_segment(const SceneView &sc, int p, d3 A, d3 B) {
+    const double tol = 1e-8;
+    d3 V = B - A;
+    d3 fx, fy, fz;
+    frame_from_vector(V, fx, fy, fz);
+    const double z_min = dot(A, fz), z_max = dot(B, fz);
+    const int v0 = sc.vert_off[p], nv = sc.vert_off[p + 1] - v0;
+    double zlo = INFINITY, zhi = -INFINITY;
+    for (int v = 0; v < nv; ++v) {
+        double z = dot(ld3(sc.verts + 3 * (size_t)(v0 + v)), fz);
+        zlo = fmin(zlo, z);
+        zhi = fmax(zhi, z);
+    }
+    if (!(zhi > z_min && zlo < z_max)) return false;
+    const double px = dot(A, fx), py = dot(A, fy);
+    const double *vb = sc.verts + 3 * (size_t)v0;
+    bool in = pip_inclusive(
+        nv,
+        [&](int k, double &x, double &y) {
+            d3 P = ld3(vb + 3 * k);
+            x = dot(P, fx);
+            y = dot(P, fy);
+        },
+        px, py);
+    if (!in) return false;
+    d3 n = ld3(sc.planes + 4 * (size_t)p);
+    double d = sc.planes[4 * (size_t)p + 3];
+    double t = -(d + dot(A, n)) / dot(V, n);
+    return tol < t && t < 1 - tol;
+}
+
+// OrientedPolygon.contains_point with check_in_plane (reference geometry.py:1792-1803): |n·p + d| within
+// atol + 1e-5|d| (numpy.allclose), then point-in-polygon in the polygon's own frame.
+__device__ inline bool polygon_contains_point(const SceneView &sc, int p, d3 X, bool check_in_plane, double plane_tol) {
+    if (check_in_plane) {
+        d3 n = ld3(sc.planes + 4 * (size_t)p);
+        double d = sc.planes[4 * (size_t)p + 3];
+        if (!(fabs(dot(n, X) + d) <= plane_tol + 1e-5 * fabs(d))) return false;
+    }
+    const double *f = sc.frames + 9 * (size_t)p;
+    double px = dot(X, ld3(f)), py = dot(X, ld3(f + 3));
+    const int v0 = sc.vert_off[p], nv = sc.vert_off[p + 1] - v0;
+    const double *uv = sc.uv + 2 * (size_t)v0;
+    return pip_inclusive(
+        nv,
+        [&](int k, double &x, double &y) {
+            x = uv[2 * k];
+            y = uv[2 * k + 1];
+        },
+        px, py);
+}

@@ -1,0 +1,1141 @@
+// Candidate enumeration and the per-(receiver, candidate) solve of RayTracingProblem.solve
+// (reference ray_tracing.py:232-237 line of sight, :243-279 checks, :281-390 enumeration and solve;
+//  solvers geometry.py:592-833).
+//
+// Enumeration: the reference walks chains depth first, receivers innermost.  The set of chains does not depend on
+// the receiver, so it is built once per emitter as flat arrays by prefix-sum expansion over the CSR form of the
+// visibility matrix: level k = for every chain of level k-1, the polygons visible from its last polygon, ascending —
+// the same order the recursion visits them in.
+//
+// Solve: planar mirrors make the min-path-tracing system linear after unfolding, so the solution of
+// geometry.py:635-657 is the image construction: reflect the emitter through the chain's planes once per candidate,
+// then per receiver intersect backwards.  The Keller equation of geometry.py:690-715 has the closed form
+// z = zA + (zB - zA) rhoA / (rhoA + rhoB) in the edge's frame.  For reflection-then-diffraction candidates the
+// reference's system aims the reflections at the edge's first endpoint (geometry.py:821 keeps points[-1] there), which
+// makes the reflection points and their checks independent of the receiver: they are done once per candidate.
+//
+// Work mapping of the candidate kernels: one lane per candidate, all lanes of a wave walk the same receiver (scalar
+// loads).  A cheap padded pre-test rejects almost every pair; pairs that pass run the exact arithmetic and checks and
+// append a path record plus its segments; the obstruction kernel then tests all segments; a last kernel keeps the
+// paths none of whose segments is obstructed.
+#include <algorithm>
+#include <cstring>
+
+#include "rt_common.h"
+
+int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out);
+
+#define MIN_DISTANCE_TOL 0.005 /* ray_tracing.py:252 */
+
+struct CandGroup {
+    int n_refl = 0;
+    int has_edge = 0;
+    int64_t count = 0;
+    int32_t *chains = nullptr;    // device [count * n_refl]
+    int32_t *edge_ids = nullptr;  // device [count]
+};
+
+struct rt_candidates {
+    rt_scene *scene = nullptr;
+    int max_order = 0;
+    std::vector<CandGroup> groups;
+    int64_t n_edges = 0;
+    double *d_edges = nullptr;    // [n_edges * 6]
+    int32_t *d_edge_pairs = nullptr;
+    uint8_t *d_ev = nullptr;      // [n]
+    std::vector<void *> allocations;
+};
+
+struct PathRec {
+    int32_t rx, group, cand, nseg;
+    int64_t seg0;
+    double pts[RT_MAX_ORDER * 3];
+};
+
+struct Queues {
+    PathRec *paths;
+    double *segs;
+    int64_t path_cap, seg_cap;
+    unsigned long long *counters;  // [0] paths, [1] segments
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// enumeration kernels
+// ---------------------------------------------------------------------------------------------------------------
+
+// out[i] = sum_{j<i} in[j], out[n] = total; one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const int32_t *__restrict__ in, int64_t n,
+                                                          int64_t *__restrict__ out) {
+    __shared__ long long wsum[16];
+    __shared__ long long carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        const long long v = i < n ? in[i] : 0;
+        long long x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            long long y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        if (wave == 0) {
+            long long s = lane < 16 ? wsum[lane] : 0;
+            for (int off = 1; off < 16; off <<= 1) {
+                long long y = __shfl_up(s, off);
+                if (lane >= off) s += y;
+            }
+            if (lane < 16) wsum[lane] = s;
+        }
+        __syncthreads();
+        const long long prefix = carry + (wave > 0 ? wsum[wave - 1] : 0) + x - v;
+        if (i < n) out[i] = prefix;
+        __syncthreads();
+        if (tid == 1023) carry = prefix + v;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+// deg[i] = number of set bytes in row i of the visibility matrix; one wave per row
+__global__ void k_row_degree(const uint8_t *__restrict__ vis, int n, int32_t *__restrict__ deg) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    int c = 0;
+    for (int j = lane; j < n; j += 64) c += vis[(size_t)row * n + j] ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if (lane == 0) deg[row] = c;
+}
+
+// col[row_off[i] ...] = visible polygons of row i, ascending; one wave per row
+__global__ void k_fill_csr(const uint8_t *__restrict__ vis, int n, const int64_t *__restrict__ row_off,
+                           int32_t *__restrict__ col) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    int64_t w = row_off[row];
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool f = j < n && vis[(size_t)row * n + j];
+        const unsigned long long m = __ballot(f);
+        if (f) col[w + __popcll(m & ((1ull << lane) - 1))] = j;
+        w += __popcll(m);
+    }
+}
+
+// flags of the 1-diffraction candidates: an edge whose either polygon the emitter sees (ray_tracing.py:335)
+__global__ void k_edge_flags(const uint8_t *__restrict__ ev, const int32_t *__restrict__ pairs, int64_t n_edges,
+                             int32_t *__restrict__ flags) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_edges) flags[e] = (ev[pairs[2 * e]] || ev[pairs[2 * e + 1]]) ? 1 : 0;
+}
+
+__global__ void k_flags_from_bytes(const uint8_t *__restrict__ b, int64_t n, int32_t *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = b[i] ? 1 : 0;
+}
+
+// ordered compaction: out[off[i]] = i where flags[i]
+__global__ void k_scatter_indices(const int32_t *__restrict__ flags, const int64_t *__restrict__ off, int64_t n,
+                                  int32_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) out[off[i]] = (int32_t)i;
+}
+
+// tcnt[l] = number of sharp edges with a polygon visible from l (container_utils.py:41-46); one wave per polygon
+__global__ void k_edge_touch_count(const uint8_t *__restrict__ vis, int n, const int32_t *__restrict__ pairs,
+                                   int64_t n_edges, int32_t *__restrict__ tcnt) {
+    const int l = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (l >= n) return;
+    const uint8_t *row = vis + (size_t)l * n;
+    int c = 0;
+    for (int64_t e = lane; e < n_edges; e += 64) c += (row[pairs[2 * e]] || row[pairs[2 * e + 1]]) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if (lane == 0) tcnt[l] = c;
+}
+
+// per-parent child count of a level: degree (reflection level) or touching edges (diffraction level) of its last polygon
+__global__ void k_parent_counts(const int32_t *__restrict__ parents, int64_t n_parents, int klen,
+                                const int32_t *__restrict__ per_polygon, int32_t *__restrict__ cnt) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_parents) cnt[p] = per_polygon[parents[p * klen + klen - 1]];
+}
+
+__global__ void k_degree_from_offsets(const int64_t *__restrict__ row_off, int n, int32_t *__restrict__ deg) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) deg[i] = (int32_t)(row_off[i + 1] - row_off[i]);
+}
+
+// children of a reflection level; one thread per child, parent found by binary search in the offsets
+__global__ void k_expand_reflect(const int32_t *__restrict__ parents, int64_t n_parents, int klen,
+                                 const int64_t *__restrict__ off, const int64_t *__restrict__ row_off,
+                                 const int32_t *__restrict__ col, int64_t n_children, int32_t *__restrict__ out) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_children) return;
+    int64_t lo = 0, hi = n_parents;  // last p with off[p] <= c
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= c) lo = mid; else hi = mid;
+    }
+    const int32_t *par = parents + lo * klen;
+    int32_t *o = out + c * (klen + 1);
+    for (int k = 0; k < klen; ++k) o[k] = par[k];
+    o[klen] = col[row_off[par[klen - 1]] + (c - off[lo])];
+}
+
+// children of a diffraction level: (parent chain, edge) for every edge touching what the last polygon sees, in edge
+// order; one wave per parent
+__global__ void k_expand_edges(const int32_t *__restrict__ parents, int64_t n_parents, int klen,
+                               const int64_t *__restrict__ off, const uint8_t *__restrict__ vis, int n,
+                               const int32_t *__restrict__ pairs, int64_t n_edges, int32_t *__restrict__ out_chains,
+                               int32_t *__restrict__ out_edges) {
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= n_parents) return;
+    const int32_t *par = parents + p * klen;
+    const uint8_t *row = vis + (size_t)par[klen - 1] * n;
+    int64_t w = off[p];
+    for (int64_t e0 = 0; e0 < n_edges; e0 += 64) {
+        const int64_t e = e0 + lane;
+        const bool f = e < n_edges && (row[pairs[2 * e]] || row[pairs[2 * e + 1]]);
+        const unsigned long long m = __ballot(f);
+        if (f) {
+            const int64_t slot = w + __popcll(m & ((1ull << lane) - 1));
+            for (int k = 0; k < klen; ++k) out_chains[slot * klen + k] = par[k];
+            out_edges[slot] = (int32_t)e;
+        }
+        w += __popcll(m);
+    }
+}
+
+__global__ void k_iota(int32_t *out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// enumeration host side
+// ---------------------------------------------------------------------------------------------------------------
+
+template <typename T>
+static T *cand_alloc(rt_candidates *c, size_t count) {
+    void *d = nullptr;
+    if (hipMalloc(&d, sizeof(T) * (count ? count : 1)) != hipSuccess) return nullptr;
+    c->allocations.push_back(d);
+    return (T *)d;
+}
+
+static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+#define CAND_CHECK(ptr)                                             \
+    if (!(ptr)) {                                                   \
+        rt_set_error("rt_enumerate: out of device memory");        \
+        rt_candidates_destroy(c);                                   \
+        return nullptr;                                             \
+    }
+#define CAND_HIP(call)                                                                   \
+    if ((call) != hipSuccess) {                                                          \
+        rt_set_error(std::string("rt_enumerate: ") + #call + " failed: " +               \
+                     hipGetErrorString(hipGetLastError()));                              \
+        rt_candidates_destroy(c);                                                        \
+        return nullptr;                                                                  \
+    }
+
+static const int64_t MAX_GROUP_CANDIDATES = (1ll << 31) - 1;
+
+extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, const uint8_t *ev,
+                                       const int32_t *edge_pairs, const double *edges, int64_t n_edges,
+                                       int32_t max_order, int with_diffraction) {
+    if (!scene || !vis || !ev) {
+        rt_set_error("rt_enumerate: null argument");
+        return nullptr;
+    }
+    if (max_order < 0 || max_order > RT_MAX_ORDER) {
+        rt_set_error("rt_enumerate: max_order must be in 0.." + std::to_string(RT_MAX_ORDER));
+        return nullptr;
+    }
+    if (n_edges < 0 || (n_edges > 0 && (!edge_pairs || !edges))) {
+        rt_set_error("rt_enumerate: bad edge arrays");
+        return nullptr;
+    }
+    const int n = scene->view.n;
+    for (int64_t e = 0; e < n_edges; ++e) {
+        if (edge_pairs[2 * e] < 0 || edge_pairs[2 * e] >= n || edge_pairs[2 * e + 1] < 0 || edge_pairs[2 * e + 1] >= n) {
+            rt_set_error("rt_enumerate: edge polygon index out of range");
+            return nullptr;
+        }
+    }
+    if (hipSetDevice(scene->device) != hipSuccess) {
+        rt_set_error("rt_enumerate: hipSetDevice failed");
+        return nullptr;
+    }
+    hipStream_t st = scene->stream;
+    rt_candidates *c = new rt_candidates();
+    c->scene = scene;
+    c->max_order = max_order;
+    c->n_edges = with_diffraction ? n_edges : 0;
+    const int n_groups = max_order == 0 ? 0 : 2 * max_order;
+    c->groups.resize(n_groups);
+
+    uint8_t *d_vis = cand_alloc<uint8_t>(c, (size_t)n * n);
+    CAND_CHECK(d_vis);
+    c->d_ev = cand_alloc<uint8_t>(c, n);
+    CAND_CHECK(c->d_ev);
+    CAND_HIP(hipMemcpyAsync(d_vis, vis, (size_t)n * n, hipMemcpyHostToDevice, st));
+    CAND_HIP(hipMemcpyAsync(c->d_ev, ev, n, hipMemcpyHostToDevice, st));
+    c->d_edges = cand_alloc<double>(c, 6 * (size_t)n_edges);
+    c->d_edge_pairs = cand_alloc<int32_t>(c, 2 * (size_t)n_edges);
+    CAND_CHECK(c->d_edges);
+    CAND_CHECK(c->d_edge_pairs);
+    if (n_edges) {
+        CAND_HIP(hipMemcpyAsync(c->d_edges, edges, sizeof(double) * 6 * n_edges, hipMemcpyHostToDevice, st));
+        CAND_HIP(hipMemcpyAsync(c->d_edge_pairs, edge_pairs, sizeof(int32_t) * 2 * n_edges, hipMemcpyHostToDevice, st));
+    }
+    if (max_order == 0) {
+        CAND_HIP(hipStreamSynchronize(st));
+        return c;
+    }
+
+    // CSR adjacency of the visibility matrix
+    int32_t *deg = cand_alloc<int32_t>(c, n);
+    int64_t *row_off = cand_alloc<int64_t>(c, (size_t)n + 1);
+    CAND_CHECK(deg);
+    CAND_CHECK(row_off);
+    hipLaunchKernelGGL(k_row_degree, dim3(blocks_for(n, 4)), dim3(256), 0, st, d_vis, n, deg);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, deg, (int64_t)n, row_off);
+    int64_t nnz = 0;
+    CAND_HIP(hipMemcpyAsync(&nnz, row_off + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    CAND_HIP(hipStreamSynchronize(st));
+    int32_t *col = cand_alloc<int32_t>(c, (size_t)nnz);
+    CAND_CHECK(col);
+    hipLaunchKernelGGL(k_fill_csr, dim3(blocks_for(n, 4)), dim3(256), 0, st, d_vis, n, row_off, col);
+
+    // scratch for flags / counts / offsets, sized as the levels grow
+    auto scan_counts = [&](const int32_t *cnt, int64_t m, int64_t *off, int64_t *total) -> bool {
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, cnt, m, off);
+        if (hipMemcpyAsync(total, off + m, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        return hipStreamSynchronize(st) == hipSuccess;
+    };
+
+    // level 1: polygons the emitter sees, ascending (ray_tracing.py:284, 326-327)
+    {
+        int32_t *flags = cand_alloc<int32_t>(c, n);
+        int64_t *off = cand_alloc<int64_t>(c, (size_t)n + 1);
+        CAND_CHECK(flags);
+        CAND_CHECK(off);
+        hipLaunchKernelGGL(k_flags_from_bytes, dim3(blocks_for(n, 256)), dim3(256), 0, st, c->d_ev, (int64_t)n, flags);
+        int64_t total = 0;
+        if (!scan_counts(flags, n, off, &total)) CAND_HIP(hipErrorUnknown);
+        CandGroup &g = c->groups[0];
+        g.n_refl = 1;
+        g.count = total;
+        g.chains = cand_alloc<int32_t>(c, (size_t)total);
+        CAND_CHECK(g.chains);
+        hipLaunchKernelGGL(k_scatter_indices, dim3(blocks_for(n, 256)), dim3(256), 0, st, flags, off, (int64_t)n, g.chains);
+    }
+    // deeper reflection levels (ray_tracing.py:316-322)
+    for (int k = 2; k <= max_order; ++k) {
+        const CandGroup &par = c->groups[k - 2];
+        CandGroup &g = c->groups[k - 1];
+        g.n_refl = k;
+        if (par.count == 0) continue;
+        int32_t *cnt = cand_alloc<int32_t>(c, (size_t)par.count);
+        int64_t *off = cand_alloc<int64_t>(c, (size_t)par.count + 1);
+        CAND_CHECK(cnt);
+        CAND_CHECK(off);
+        hipLaunchKernelGGL(k_parent_counts, dim3(blocks_for(par.count, 256)), dim3(256), 0, st, par.chains, par.count,
+                           k - 1, deg, cnt);
+        int64_t total = 0;
+        if (!scan_counts(cnt, par.count, off, &total)) CAND_HIP(hipErrorUnknown);
+        if (total > MAX_GROUP_CANDIDATES) {
+            rt_set_error("rt_enumerate: more than 2^31-1 candidates at reflection order " + std::to_string(k));
+            rt_candidates_destroy(c);
+            return nullptr;
+        }
+        g.count = total;
+        g.chains = cand_alloc<int32_t>(c, (size_t)total * k);
+        CAND_CHECK(g.chains);
+        if (total)
+            hipLaunchKernelGGL(k_expand_reflect, dim3(blocks_for(total, 256)), dim3(256), 0, st, par.chains, par.count,
+                               k - 1, off, row_off, col, total, g.chains);
+    }
+    // diffraction groups
+    for (int m = 0; m < max_order; ++m) {
+        CandGroup &g = c->groups[max_order + m];
+        g.n_refl = m;
+        g.has_edge = 1;
+    }
+    if (with_diffraction && n_edges > 0) {
+        // 1 diffraction (ray_tracing.py:334-350)
+        {
+            int32_t *flags = cand_alloc<int32_t>(c, (size_t)n_edges);
+            int64_t *off = cand_alloc<int64_t>(c, (size_t)n_edges + 1);
+            CAND_CHECK(flags);
+            CAND_CHECK(off);
+            hipLaunchKernelGGL(k_edge_flags, dim3(blocks_for(n_edges, 256)), dim3(256), 0, st, c->d_ev, c->d_edge_pairs,
+                               n_edges, flags);
+            int64_t total = 0;
+            if (!scan_counts(flags, n_edges, off, &total)) CAND_HIP(hipErrorUnknown);
+            CandGroup &g = c->groups[max_order];
+            g.count = total;
+            g.edge_ids = cand_alloc<int32_t>(c, (size_t)total);
+            CAND_CHECK(g.edge_ids);
+            hipLaunchKernelGGL(k_scatter_indices, dim3(blocks_for(n_edges, 256)), dim3(256), 0, st, flags, off, n_edges,
+                               g.edge_ids);
+        }
+        // m reflections + 1 diffraction, m >= 1 (ray_tracing.py:355-388)
+        if (max_order >= 2) {
+            int32_t *tcnt = cand_alloc<int32_t>(c, n);
+            CAND_CHECK(tcnt);
+            hipLaunchKernelGGL(k_edge_touch_count, dim3(blocks_for(n, 4)), dim3(256), 0, st, d_vis, n, c->d_edge_pairs,
+                               n_edges, tcnt);
+            for (int m = 1; m < max_order; ++m) {
+                const CandGroup &par = c->groups[m - 1];
+                CandGroup &g = c->groups[max_order + m];
+                if (par.count == 0) continue;
+                int32_t *cnt = cand_alloc<int32_t>(c, (size_t)par.count);
+                int64_t *off = cand_alloc<int64_t>(c, (size_t)par.count + 1);
+                CAND_CHECK(cnt);
+                CAND_CHECK(off);
+                hipLaunchKernelGGL(k_parent_counts, dim3(blocks_for(par.count, 256)), dim3(256), 0, st, par.chains,
+                                   par.count, m, tcnt, cnt);
+                int64_t total = 0;
+                if (!scan_counts(cnt, par.count, off, &total)) CAND_HIP(hipErrorUnknown);
+                if (total > MAX_GROUP_CANDIDATES) {
+                    rt_set_error("rt_enumerate: more than 2^31-1 candidates with " + std::to_string(m) +
+                                 " reflections and a diffraction");
+                    rt_candidates_destroy(c);
+                    return nullptr;
+                }
+                g.count = total;
+                g.chains = cand_alloc<int32_t>(c, (size_t)total * m);
+                g.edge_ids = cand_alloc<int32_t>(c, (size_t)total);
+                CAND_CHECK(g.chains);
+                CAND_CHECK(g.edge_ids);
+                if (total)
+                    hipLaunchKernelGGL(k_expand_edges, dim3(blocks_for(par.count, 4)), dim3(256), 0, st, par.chains,
+                                       par.count, m, off, d_vis, n, c->d_edge_pairs, n_edges, g.chains, g.edge_ids);
+            }
+        }
+    }
+    CAND_HIP(hipGetLastError());
+    CAND_HIP(hipStreamSynchronize(st));
+    return c;
+}
+
+extern "C" void rt_candidates_destroy(rt_candidates *c) {
+    if (!c) return;
+    if (c->scene) (void)hipSetDevice(c->scene->device);
+    for (void *p : c->allocations) (void)hipFree(p);
+    delete c;
+}
+
+extern "C" int32_t rt_candidates_group_count(const rt_candidates *c) { return c ? (int32_t)c->groups.size() : -1; }
+
+extern "C" int rt_candidates_counts(const rt_candidates *c, int64_t *counts) {
+    if (!c || !counts) RT_FAIL("rt_candidates_counts: null argument");
+    for (size_t g = 0; g < c->groups.size(); ++g) counts[g] = c->groups[g].count;
+    return 0;
+}
+
+extern "C" int rt_candidates_group(const rt_candidates *c, int32_t group, int32_t *chains, int32_t *edge_ids) {
+    if (!c) RT_FAIL("rt_candidates_group: null handle");
+    if (group < 0 || group >= (int)c->groups.size()) RT_FAIL("rt_candidates_group: group out of range");
+    const CandGroup &g = c->groups[group];
+    RT_HIP(hipSetDevice(c->scene->device));
+    if (chains && g.n_refl > 0 && g.count > 0)
+        RT_HIP(hipMemcpy(chains, g.chains, sizeof(int32_t) * g.count * g.n_refl, hipMemcpyDeviceToHost));
+    if (edge_ids) {
+        if (g.has_edge && g.count > 0)
+            RT_HIP(hipMemcpy(edge_ids, g.edge_ids, sizeof(int32_t) * g.count, hipMemcpyDeviceToHost));
+        else
+            for (int64_t i = 0; i < g.count; ++i) edge_ids[i] = -1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// solve kernels
+// ---------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double fast_rcp_s(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    return r * (2.0 - x * r);
+}
+
+__device__ inline bool reserve(const Queues &q, int nseg, int64_t &path_slot, int64_t &seg_slot) {
+    path_slot = (int64_t)atomicAdd(&q.counters[0], 1ull);
+    seg_slot = (int64_t)atomicAdd(&q.counters[1], (unsigned long long)nseg);
+    return path_slot < q.path_cap && seg_slot + nseg <= q.seg_cap;
+}
+
+// Exact image construction for K planes: X[i] on plane i for the path origin -> X[0] .. X[K-1] -> dest.
+// img[i] = origin mirrored through planes 0..i; g[i] = d_i + img[i]·n_i.  False when an image segment does not
+// cross its plane strictly inside (no specular path over the infinite planes).
+template <int K>
+__device__ inline bool unfold_exact(const d3 *nrm, const double *g, const d3 *img, d3 dest, d3 *X) {
+    d3 T = dest;
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {
+        const d3 dir = T - img[i];
+        const double t = -g[i] / dot(dir, nrm[i]);
+        if (!(t > 0.0 && t < 1.0)) return false;
+        X[i] = img[i] + t * dir;
+        T = X[i];
+    }
+    return true;
+}
+
+// Reflection candidates: lane = candidate of a K-reflection group, loop = receivers of the block's tile.
+template <int K>
+__global__ __launch_bounds__(256) void k_reflect(SceneView sc, const int32_t *__restrict__ chains, int64_t count,
+                                                  int group, d3 tx, const double *__restrict__ rx, int64_t rx0,
+                                                  int64_t rx1, int rx_tile, Queues q) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = c < count;
+    int32_t poly[K];
+    d3 nrm[K], img[K];
+    double g[K];
+    d3 prev = tx;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        poly[i] = active ? chains[c * K + i] : 0;
+        const double *pl = sc.planes + 4 * (size_t)poly[i];
+        nrm[i] = ld3(pl);
+        const double s = pl[3] + dot(prev, nrm[i]);
+        img[i] = prev - (2.0 * s) * nrm[i];
+        g[i] = -s;  // d + img·n = -(d + prev·n)
+        prev = img[i];
+    }
+    const double *bb = sc.bbox + 6 * (size_t)poly[K - 1];
+    const double b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
+    const d3 im = img[K - 1], nk = nrm[K - 1];
+    const double gk = g[K - 1];
+
+    const int64_t r_begin = rx0 + (int64_t)blockIdx.y * rx_tile;
+    const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        const d3 R = ld3(rx + 3 * r);  // wave-uniform
+        const d3 dir = R - im;
+        const double t = -gk * fast_rcp_s(dot(dir, nk));
+        const double pad = 1e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 1e-6;
+        const double hx = im.x + t * dir.x, hy = im.y + t * dir.y, hz = im.z + t * dir.z;
+        const bool cand = active && t > -1e-6 && t < 1.0 + 1e-6 && hx >= b0 - pad && hx <= b3 + pad && hy >= b1 - pad &&
+                          hy <= b4 + pad && hz >= b2 - pad && hz <= b5 + pad;
+        if (!cand) continue;
+        d3 X[K];
+        if (!unfold_exact<K>(nrm, g, img, R, X)) continue;
+        bool ok = true;
+        for (int i = 0; i < K && ok; ++i) ok = polygon_contains_point(sc, poly[i], X[i], true, 1e-8);  // ray_tracing.py:253-255
+        if (!ok) continue;
+        // ray_tracing.py:268-272
+        d3 a = tx;
+        for (int i = 0; i < K && ok; ++i) {
+            ok = norm3(a - X[i]) >= MIN_DISTANCE_TOL;
+            a = X[i];
+        }
+        ok = ok && norm3(a - R) >= MIN_DISTANCE_TOL;
+        if (!ok) continue;
+        int64_t ps, ss;
+        if (!reserve(q, K + 1, ps, ss)) continue;
+        PathRec &rec = q.paths[ps];
+        rec.rx = (int32_t)r;
+        rec.group = group;
+        rec.cand = (int32_t)c;
+        rec.nseg = K + 1;
+        rec.seg0 = ss;
+        a = tx;
+        for (int i = 0; i < K; ++i) {
+            st3(rec.pts + 3 * i, X[i]);
+            st3(q.segs + 6 * (ss + i), a);
+            st3(q.segs + 6 * (ss + i) + 3, X[i]);
+            a = X[i];
+        }
+        st3(q.segs + 6 * (ss + K), a);
+        st3(q.segs + 6 * (ss + K) + 3, R);
+    }
+}
+
+// Receiver-independent half of an (M reflections + diffraction) candidate: reflection points aimed at the edge's first
+// endpoint, their containment and spacing checks.  Candidates that pass go to `alive` with their points and their M
+// receiver-independent segments.
+struct AliveRec {
+    int32_t cand;
+    int32_t pad;
+    double pts[(RT_MAX_ORDER - 1) * 3];
+};
+
+template <int M>
+__global__ __launch_bounds__(256) void k_rd_prepare(SceneView sc, const int32_t *__restrict__ chains,
+                                                     const int32_t *__restrict__ edge_ids, int64_t count,
+                                                     const double *__restrict__ edges, d3 tx, AliveRec *alive,
+                                                     double *segs, int64_t cap, unsigned long long *counter) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    d3 nrm[M], img[M];
+    double g[M];
+    int32_t poly[M];
+    d3 prev = tx;
+    for (int i = 0; i < M; ++i) {
+        poly[i] = chains[c * M + i];
+        const double *pl = sc.planes + 4 * (size_t)poly[i];
+        nrm[i] = ld3(pl);
+        const double s = pl[3] + dot(prev, nrm[i]);
+        img[i] = prev - (2.0 * s) * nrm[i];
+        g[i] = -s;
+        prev = img[i];
+    }
+    const d3 P0 = ld3(edges + 6 * (size_t)edge_ids[c]);
+    d3 X[M];
+    if (!unfold_exact<M>(nrm, g, img, P0, X)) return;
+    for (int i = 0; i < M; ++i)
+        if (!polygon_contains_point(sc, poly[i], X[i], true, 1e-8)) return;
+    d3 a = tx;
+    for (int i = 0; i < M; ++i) {
+        if (!(norm3(a - X[i]) >= MIN_DISTANCE_TOL)) return;
+        a = X[i];
+    }
+    const int64_t slot = (int64_t)atomicAdd(counter, 1ull);
+    if (slot >= cap) return;
+    alive[slot].cand = (int32_t)c;
+    a = tx;
+    for (int i = 0; i < M; ++i) {
+        st3(alive[slot].pts + 3 * i, X[i]);
+        st3(segs + 6 * (slot * M + i), a);
+        st3(segs + 6 * (slot * M + i) + 3, X[i]);
+        a = X[i];
+    }
+}
+
+// keeps the alive records none of whose M receiver-independent segments is obstructed
+template <int M>
+__global__ void k_rd_filter(const AliveRec *__restrict__ in, const uint8_t *__restrict__ hit, int64_t n, AliveRec *out,
+                            unsigned long long *counter) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < M; ++k)
+        if (hit[i * M + k]) return;
+    const int64_t slot = (int64_t)atomicAdd(counter, 1ull);
+    out[slot] = in[i];
+}
+
+// Diffraction candidates: lane = alive (M reflections + edge) record, or for M = 0 an edge of the 1-diffraction
+// group; loop = receivers of the block's tile.
+template <int M>
+__global__ __launch_bounds__(256) void k_diffract(SceneView sc, const AliveRec *__restrict__ alive,
+                                                   const int32_t *__restrict__ edge_ids, int64_t count, int group,
+                                                   const double *__restrict__ edges, d3 tx,
+                                                   const double *__restrict__ rx, int64_t rx0, int64_t rx1, int rx_tile,
+                                                   Queues q) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = idx < count;
+    int32_t cand = 0;
+    d3 A = tx;
+    if (active) {
+        if (M == 0) {
+            cand = (int32_t)idx;
+        } else {
+            cand = alive[idx].cand;
+            A = ld3(alive[idx].pts + 3 * (M - 1));
+        }
+    }
+    const double *e = edges + 6 * (size_t)(active ? edge_ids[cand] : 0);
+    const d3 P0 = ld3(e), P1 = ld3(e + 3);
+    // edge-aligned frame (geometry.py:736-742)
+    d3 fx, fy, fz;
+    frame_from_vector(P1 - P0, fx, fy, fz);
+    const double xe = dot(P0, fx), ye = dot(P0, fy), ze = dot(P0, fz), z1 = dot(P1, fz);
+    const double ax = dot(A, fx), ay = dot(A, fy), az = dot(A, fz);
+    const double rhoA = sqrt((xe - ax) * (xe - ax) + (ye - ay) * (ye - ay));
+
+    const int64_t r_begin = rx0 + (int64_t)blockIdx.y * rx_tile;
+    const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        const d3 R = ld3(rx + 3 * r);
+        const double bx = dot(R, fx), by = dot(R, fy), bz = dot(R, fz);
+        const double rhoB = sqrt((xe - bx) * (xe - bx) + (ye - by) * (ye - by));
+        const double sum = rhoA + rhoB;
+        // Keller cone: (z - zA)/|X - A| = (zB - z)/|B - X|  <=>  z = zA + (zB - zA) rhoA/(rhoA + rhoB)
+        const double z = az + (bz - az) * (rhoA / sum);
+        if (!(active && sum > 0.0 && z >= ze - 1e-6 && z <= z1 + 1e-6)) continue;
+        // back to world coordinates (geometry.py:746-748, 831)
+        const d3 D = (xe * fx + ye * fy) + z * fz;
+        // point_on_edge_ (geometry.py:470-479)
+        const double tol = 1e-8;
+        const double dx = dot(D, fx), dy = dot(D, fy), dz = dot(D, fz);
+        if (!(xe - tol <= dx && dx <= xe + tol && ye - tol <= dy && dy <= ye + tol && ze - tol <= dz && dz <= z1 + tol))
+            continue;
+        if (!(norm3(A - D) >= MIN_DISTANCE_TOL)) continue;  // ray_tracing.py:268-272 on lines[:-1]
+        int64_t ps, ss;
+        if (!reserve(q, 2, ps, ss)) continue;
+        PathRec &rec = q.paths[ps];
+        rec.rx = (int32_t)r;
+        rec.group = group;
+        rec.cand = cand;
+        rec.nseg = 2;
+        rec.seg0 = ss;
+        for (int i = 0; i < M; ++i) st3(rec.pts + 3 * i, ld3(alive[idx].pts + 3 * i));
+        st3(rec.pts + 3 * M, D);
+        st3(q.segs + 6 * ss, A);
+        st3(q.segs + 6 * ss + 3, D);
+        st3(q.segs + 6 * (ss + 1), D);
+        st3(q.segs + 6 * (ss + 1) + 3, R);
+    }
+}
+
+__global__ void k_los_segments(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t n, double *segs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st3(segs + 6 * i, tx);
+    st3(segs + 6 * i + 3, ld3(rx + 3 * (rx0 + i)));
+}
+
+struct OutArrays {
+    int32_t *rx, *group, *cand;
+    double *pts;
+    int64_t cap;
+    unsigned long long *count;
+};
+
+__global__ void k_los_finalize(const uint8_t *__restrict__ hit, int64_t rx0, int64_t n, OutArrays out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || hit[i]) return;
+    const int64_t slot = (int64_t)atomicAdd(out.count, 1ull);
+    if (slot >= out.cap) return;
+    out.rx[slot] = (int32_t)(rx0 + i);
+    out.group[slot] = -1;
+    out.cand[slot] = 0;
+    for (int k = 0; k < RT_MAX_ORDER * 3; ++k) out.pts[slot * RT_MAX_ORDER * 3 + k] = 0.0;
+}
+
+__global__ void k_finalize(const PathRec *__restrict__ paths, const uint8_t *__restrict__ hit, int64_t n, OutArrays out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PathRec &p = paths[i];
+    for (int k = 0; k < p.nseg; ++k)
+        if (hit[p.seg0 + k]) return;
+    const int64_t slot = (int64_t)atomicAdd(out.count, 1ull);
+    if (slot >= out.cap) return;
+    out.rx[slot] = p.rx;
+    out.group[slot] = p.group;
+    out.cand[slot] = p.cand;
+    for (int k = 0; k < RT_MAX_ORDER * 3; ++k) out.pts[slot * RT_MAX_ORDER * 3 + k] = p.pts[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// solve host side
+// ---------------------------------------------------------------------------------------------------------------
+
+struct EventTimer {
+    hipStream_t st;
+    std::vector<hipEvent_t> ev[4];
+    explicit EventTimer(hipStream_t s) : st(s) {}
+    void begin(int fam) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, st);
+        ev[fam].push_back(a);
+        ev[fam].push_back(b);
+    }
+    void end(int fam) { (void)hipEventRecord(ev[fam].back(), st); }
+    void collect(double *ms, int64_t *launches) {
+        for (int f = 0; f < 4; ++f) {
+            ms[f] = 0;
+            launches[f] = (int64_t)ev[f].size() / 2;
+            for (size_t i = 0; i + 1 < ev[f].size(); i += 2) {
+                float t = 0;
+                if (hipEventElapsedTime(&t, ev[f][i], ev[f][i + 1]) == hipSuccess) ms[f] += t;
+            }
+            for (hipEvent_t e : ev[f]) (void)hipEventDestroy(e);
+            ev[f].clear();
+        }
+    }
+};
+
+template <int K>
+static void launch_reflect(rt_scene *s, const CandGroup &g, int group, d3 tx, const double *rx, int64_t rx0, int64_t rx1,
+                           int rx_tile, const Queues &q) {
+    dim3 grid(blocks_for(g.count, 256), blocks_for(rx1 - rx0, rx_tile));
+    hipLaunchKernelGGL(k_reflect<K>, grid, dim3(256), 0, s->stream, s->view, g.chains, g.count, group, tx, rx, rx0, rx1,
+                       rx_tile, q);
+}
+
+template <int M>
+static void launch_diffract(rt_scene *s, const AliveRec *alive, const int32_t *edge_ids, int64_t count, int group,
+                            const double *edges, d3 tx, const double *rx, int64_t rx0, int64_t rx1, int rx_tile,
+                            const Queues &q) {
+    dim3 grid(blocks_for(count, 256), blocks_for(rx1 - rx0, rx_tile));
+    hipLaunchKernelGGL(k_diffract<M>, grid, dim3(256), 0, s->stream, s->view, alive, edge_ids, count, group, edges, tx,
+                       rx, rx0, rx1, rx_tile, q);
+}
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double *tx, const double *rx, int64_t n_rx,
+                              int32_t *out_rx, int32_t *out_group, int32_t *out_cand, double *out_points,
+                              int64_t capacity, int64_t *n_found, int64_t *n_attempted, int on_device) {
+    if (!scene || !cand || !tx || !n_found || !n_attempted) RT_FAIL("rt_solve_paths: null argument");
+    if (cand->scene != scene) RT_FAIL("rt_solve_paths: candidates belong to another scene");
+    if (n_rx < 0 || capacity < 0) RT_FAIL("rt_solve_paths: negative size");
+    if (n_rx > 0 && !rx) RT_FAIL("rt_solve_paths: null receivers");
+    if (capacity > 0 && (!out_rx || !out_group || !out_cand || !out_points)) RT_FAIL("rt_solve_paths: null output");
+    if (n_rx > 0x7fffffffLL) RT_FAIL("rt_solve_paths: too many receivers");
+    RT_HIP(hipSetDevice(scene->device));
+    hipStream_t st = scene->stream;
+    const d3 TX = ld3(tx);
+    const int n = scene->view.n;
+    (void)n;
+
+    int64_t total_cand = 0;
+    for (const CandGroup &g : cand->groups) total_cand += g.count;
+    *n_attempted = n_rx * (1 + total_cand);
+    *n_found = 0;
+    for (int f = 0; f < 4; ++f) {
+        scene->last_ms[f] = 0;
+        scene->last_launches[f] = 0;
+    }
+    scene->last_segments = 0;
+    if (n_rx == 0) return 0;
+
+    // device views of the caller's arrays
+    const double *d_rx = rx;
+    OutArrays out{};
+    std::vector<void *> temps;
+    auto temp_alloc = [&](size_t bytes) -> void * {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
+        temps.push_back(d);
+        return d;
+    };
+    auto free_temps = [&]() {
+        for (void *p : temps) (void)hipFree(p);
+        temps.clear();
+    };
+#define SOLVE_HIP(call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            rt_set_error(std::string("rt_solve_paths: ") + #call + ": " + hipGetErrorString(e_));         \
+            free_temps();                                                                                 \
+            return -1;                                                                                    \
+        }                                                                                                 \
+    } while (0)
+#define SOLVE_PTR(p)                                                   \
+    if (!(p)) {                                                        \
+        rt_set_error("rt_solve_paths: out of device memory");          \
+        free_temps();                                                  \
+        return -1;                                                     \
+    }
+
+    unsigned long long *d_counters = (unsigned long long *)temp_alloc(sizeof(unsigned long long) * 8);
+    SOLVE_PTR(d_counters);
+    SOLVE_HIP(hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 8, st));
+    if (on_device) {
+        out.rx = out_rx;
+        out.group = out_group;
+        out.cand = out_cand;
+        out.pts = out_points;
+    } else {
+        double *t = (double *)temp_alloc(sizeof(double) * 3 * n_rx);
+        SOLVE_PTR(t);
+        SOLVE_HIP(hipMemcpyAsync(t, rx, sizeof(double) * 3 * n_rx, hipMemcpyHostToDevice, st));
+        d_rx = t;
+        out.rx = (int32_t *)temp_alloc(sizeof(int32_t) * capacity);
+        out.group = (int32_t *)temp_alloc(sizeof(int32_t) * capacity);
+        out.cand = (int32_t *)temp_alloc(sizeof(int32_t) * capacity);
+        out.pts = (double *)temp_alloc(sizeof(double) * RT_MAX_ORDER * 3 * capacity);
+        SOLVE_PTR(out.rx);
+        SOLVE_PTR(out.group);
+        SOLVE_PTR(out.cand);
+        SOLVE_PTR(out.pts);
+    }
+    out.cap = capacity;
+    out.count = d_counters + 2;
+
+    EventTimer timer(st);
+
+    // ---- receiver-independent half of the reflection+diffraction groups -------------------------------------
+    const int mo = cand->max_order;
+    std::vector<AliveRec *> alive(mo, nullptr);
+    std::vector<int64_t> alive_count(mo, 0);
+    for (int m = 1; m < mo; ++m) {
+        const CandGroup &g = cand->groups[mo + m];
+        if (g.count == 0) continue;
+        AliveRec *a0 = (AliveRec *)temp_alloc(sizeof(AliveRec) * g.count);
+        AliveRec *a1 = (AliveRec *)temp_alloc(sizeof(AliveRec) * g.count);
+        double *segs = (double *)temp_alloc(sizeof(double) * 6 * g.count * m);
+        uint8_t *hit = (uint8_t *)temp_alloc((size_t)g.count * m);
+        SOLVE_PTR(a0);
+        SOLVE_PTR(a1);
+        SOLVE_PTR(segs);
+        SOLVE_PTR(hit);
+        unsigned long long *cnt = d_counters + 4;
+        SOLVE_HIP(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), st));
+        timer.begin(1);
+        dim3 grid(blocks_for(g.count, 256));
+        switch (m) {
+            case 1: hipLaunchKernelGGL(k_rd_prepare<1>, grid, dim3(256), 0, st, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
+            case 2: hipLaunchKernelGGL(k_rd_prepare<2>, grid, dim3(256), 0, st, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
+            default: hipLaunchKernelGGL(k_rd_prepare<3>, grid, dim3(256), 0, st, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
+        }
+        timer.end(1);
+        unsigned long long n0 = 0;
+        SOLVE_HIP(hipMemcpyAsync(&n0, cnt, sizeof(n0), hipMemcpyDeviceToHost, st));
+        SOLVE_HIP(hipStreamSynchronize(st));
+        if (n0 == 0) continue;
+        timer.begin(2);
+        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, hit)) {
+            free_temps();
+            return -1;
+        }
+        timer.end(2);
+        scene->last_segments += (int64_t)n0 * m;
+        timer.begin(3);
+        switch (m) {
+            case 1: hipLaunchKernelGGL(k_rd_filter<1>, dim3(blocks_for(n0, 256)), dim3(256), 0, st, a0, hit, (int64_t)n0, a1, cnt + 1); break;
+            case 2: hipLaunchKernelGGL(k_rd_filter<2>, dim3(blocks_for(n0, 256)), dim3(256), 0, st, a0, hit, (int64_t)n0, a1, cnt + 1); break;
+            default: hipLaunchKernelGGL(k_rd_filter<3>, dim3(blocks_for(n0, 256)), dim3(256), 0, st, a0, hit, (int64_t)n0, a1, cnt + 1); break;
+        }
+        timer.end(3);
+        unsigned long long n1 = 0;
+        SOLVE_HIP(hipMemcpyAsync(&n1, cnt + 1, sizeof(n1), hipMemcpyDeviceToHost, st));
+        SOLVE_HIP(hipStreamSynchronize(st));
+        alive[m] = a1;
+        alive_count[m] = (int64_t)n1;
+    }
+
+    // ---- receivers, in chunks whose survivors fit the workspace ---------------------------------------------
+    int64_t chunk = n_rx;
+    const int64_t max_pairs_per_launch = 1ll << 36;
+    if (total_cand > 0 && chunk * total_cand > max_pairs_per_launch) chunk = std::max<int64_t>(1, max_pairs_per_launch / total_cand);
+    int64_t path_cap = std::max<int64_t>(1 << 16, std::min<int64_t>(chunk * std::max<int64_t>(total_cand, 1) / 64 + 4096, 1ll << 26));
+    const int rx_tile = 128;
+
+    for (int64_t r0 = 0; r0 < n_rx;) {
+        const int64_t r1 = std::min(n_rx, r0 + chunk);
+        const int64_t nr = r1 - r0;
+        const int64_t seg_cap = path_cap * 3;
+        // workspace layout: paths | segs | hits | los segs | los hits
+        size_t off_paths = 0;
+        size_t off_segs = align_up(off_paths + sizeof(PathRec) * path_cap);
+        size_t off_hits = align_up(off_segs + sizeof(double) * 6 * seg_cap);
+        size_t off_lsegs = align_up(off_hits + (size_t)seg_cap);
+        size_t off_lhits = align_up(off_lsegs + sizeof(double) * 6 * nr);
+        size_t total = align_up(off_lhits + (size_t)nr);
+        void *ws = nullptr;
+        if (rt_scene_workspace(scene, total, &ws)) {
+            free_temps();
+            return -1;
+        }
+        char *w = (char *)ws;
+        Queues q{(PathRec *)(w + off_paths), (double *)(w + off_segs), path_cap, seg_cap, d_counters};
+        uint8_t *d_hits = (uint8_t *)(w + off_hits);
+        double *d_lsegs = (double *)(w + off_lsegs);
+        uint8_t *d_lhits = (uint8_t *)(w + off_lhits);
+        SOLVE_HIP(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
+
+        // line of sight against the polygons the emitter sees (ray_tracing.py:232-237)
+        timer.begin(3);
+        hipLaunchKernelGGL(k_los_segments, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, d_lsegs);
+        timer.end(3);
+        timer.begin(2);
+        if (rt_launch_obstruct(scene, d_lsegs, nr, cand->d_ev, d_lhits)) {
+            free_temps();
+            return -1;
+        }
+        timer.end(2);
+        scene->last_segments += nr;
+        timer.begin(3);
+        hipLaunchKernelGGL(k_los_finalize, dim3(blocks_for(nr, 256)), dim3(256), 0, st, d_lhits, r0, nr, out);
+        timer.end(3);
+
+        // reflections
+        timer.begin(0);
+        for (int k = 1; k <= mo; ++k) {
+            const CandGroup &g = cand->groups[k - 1];
+            if (g.count == 0) continue;
+            switch (k) {
+                case 1: launch_reflect<1>(scene, g, k - 1, TX, d_rx, r0, r1, rx_tile, q); break;
+                case 2: launch_reflect<2>(scene, g, k - 1, TX, d_rx, r0, r1, rx_tile, q); break;
+                case 3: launch_reflect<3>(scene, g, k - 1, TX, d_rx, r0, r1, rx_tile, q); break;
+                default: launch_reflect<4>(scene, g, k - 1, TX, d_rx, r0, r1, rx_tile, q); break;
+            }
+        }
+        timer.end(0);
+        // diffractions
+        timer.begin(1);
+        for (int m = 0; m < mo; ++m) {
+            const CandGroup &g = cand->groups[mo + m];
+            const int64_t cnt = m == 0 ? g.count : alive_count[m];
+            if (cnt == 0) continue;
+            switch (m) {
+                case 0: launch_diffract<0>(scene, nullptr, g.edge_ids, cnt, mo + m, cand->d_edges, TX, d_rx, r0, r1, rx_tile, q); break;
+                case 1: launch_diffract<1>(scene, alive[m], g.edge_ids, cnt, mo + m, cand->d_edges, TX, d_rx, r0, r1, rx_tile, q); break;
+                case 2: launch_diffract<2>(scene, alive[m], g.edge_ids, cnt, mo + m, cand->d_edges, TX, d_rx, r0, r1, rx_tile, q); break;
+                default: launch_diffract<3>(scene, alive[m], g.edge_ids, cnt, mo + m, cand->d_edges, TX, d_rx, r0, r1, rx_tile, q); break;
+            }
+        }
+        timer.end(1);
+        unsigned long long counts[2] = {0, 0};
+        SOLVE_HIP(hipMemcpyAsync(counts, d_counters, sizeof(counts), hipMemcpyDeviceToHost, st));
+        SOLVE_HIP(hipStreamSynchronize(st));
+        SOLVE_HIP(hipGetLastError());
+        if ((int64_t)counts[0] > path_cap || (int64_t)counts[1] > seg_cap) {
+            // survivors did not fit: grow the queues and redo this chunk (nothing of it has reached the outputs
+            // except its line-of-sight paths, which are taken back)
+            const int64_t need = std::max<int64_t>((int64_t)counts[0], ((int64_t)counts[1] + 2) / 3);
+            path_cap = need + need / 8 + 1024;
+            unsigned long long found = 0;
+            SOLVE_HIP(hipMemcpy(&found, out.count, sizeof(found), hipMemcpyDeviceToHost));
+            // count LOS paths of this chunk to roll the cursor back
+            std::vector<uint8_t> lh(nr);
+            SOLVE_HIP(hipMemcpy(lh.data(), d_lhits, nr, hipMemcpyDeviceToHost));
+            unsigned long long los_n = 0;
+            for (uint8_t h : lh) los_n += h ? 0 : 1;
+            found -= los_n;
+            SOLVE_HIP(hipMemcpy(out.count, &found, sizeof(found), hipMemcpyHostToDevice));
+            continue;
+        }
+        const int64_t n_paths = (int64_t)counts[0], n_segs = (int64_t)counts[1];
+        if (n_segs > 0) {
+            timer.begin(2);
+            if (rt_launch_obstruct(scene, q.segs, n_segs, nullptr, d_hits)) {
+                free_temps();
+                return -1;
+            }
+            timer.end(2);
+            scene->last_segments += n_segs;
+            timer.begin(3);
+            hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n_paths, 256)), dim3(256), 0, st, q.paths, d_hits, n_paths, out);
+            timer.end(3);
+        }
+        r0 = r1;
+    }
+    unsigned long long found = 0;
+    SOLVE_HIP(hipMemcpyAsync(&found, out.count, sizeof(found), hipMemcpyDeviceToHost, st));
+    SOLVE_HIP(hipStreamSynchronize(st));
+    SOLVE_HIP(hipGetLastError());
+    *n_found = (int64_t)found;
+    if (!on_device) {
+        const int64_t m = std::min<int64_t>((int64_t)found, capacity);
+        if (m > 0) {
+            SOLVE_HIP(hipMemcpy(out_rx, out.rx, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+            SOLVE_HIP(hipMemcpy(out_group, out.group, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+            SOLVE_HIP(hipMemcpy(out_cand, out.cand, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+            SOLVE_HIP(hipMemcpy(out_points, out.pts, sizeof(double) * RT_MAX_ORDER * 3 * m, hipMemcpyDeviceToHost));
+        }
+    }
+    timer.collect(scene->last_ms, scene->last_launches);
+    free_temps();
+    return 0;
+}
+
+extern "C" int rt_solve_last_timing(rt_scene *scene, double *ms, int64_t *launches, int64_t *segments_tested) {
+    if (!scene) RT_FAIL("rt_solve_last_timing: null scene");
+    for (int f = 0; f < 4; ++f) {
+        if (ms) ms[f] = scene->last_ms[f];
+        if (launches) launches[f] = scene->last_launches[f];
+    }
+    if (segments_tested) *segments_tested = scene->last_segments;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stand-alone solver entry points (geometry.py:660-687, 718-748, 800-833)
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ void k_solve_standalone(d3 origin, const double *__restrict__ dests, int64_t n, const double *__restrict__ planes,
+                                   int k, const double *__restrict__ edge, double *__restrict__ out, uint8_t *__restrict__ ok) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const d3 dest = ld3(dests + 3 * i);
+    d3 nrm[RT_MAX_ORDER], img[RT_MAX_ORDER], X[RT_MAX_ORDER];
+    double g[RT_MAX_ORDER];
+    d3 prev = origin;
+    for (int j = 0; j < k; ++j) {
+        nrm[j] = ld3(planes + 4 * j);
+        const double s = planes[4 * j + 3] + dot(prev, nrm[j]);
+        img[j] = prev - (2.0 * s) * nrm[j];
+        g[j] = -s;
+        prev = img[j];
+    }
+    const int npts = k + (edge ? 1 : 0);
+    double *o = out + (size_t)i * npts * 3;
+    bool good = true;
+    d3 T = edge ? ld3(edge) : dest;  // reflections aim at the edge's first endpoint (geometry.py:821)
+    for (int j = k - 1; j >= 0; --j) {
+        const d3 dir = T - img[j];
+        const double t = -g[j] / dot(dir, nrm[j]);
+        if (!(t > 0.0 && t < 1.0)) good = false;
+        X[j] = img[j] + t * dir;
+        T = X[j];
+    }
+    for (int j = 0; j < k; ++j) st3(o + 3 * j, X[j]);
+    if (edge) {
+        const d3 A = k > 0 ? X[k - 1] : origin;
+        const d3 P0 = ld3(edge), P1 = ld3(edge + 3);
+        d3 fx, fy, fz;
+        frame_from_vector(P1 - P0, fx, fy, fz);
+        const double xe = dot(P0, fx), ye = dot(P0, fy);
+        const double ax = dot(A, fx), ay = dot(A, fy), az = dot(A, fz);
+        const double bx = dot(dest, fx), by = dot(dest, fy), bz = dot(dest, fz);
+        const double rhoA = sqrt((xe - ax) * (xe - ax) + (ye - ay) * (ye - ay));
+        const double rhoB = sqrt((xe - bx) * (xe - bx) + (ye - by) * (ye - by));
+        const double sum = rhoA + rhoB;
+        if (!(sum > 0.0)) good = false;
+        const double z = az + (bz - az) * (rhoA / sum);
+        st3(o + 3 * k, (xe * fx + ye * fy) + z * fz);
+    }
+    ok[i] = good ? 1 : 0;
+}
+
+static int solve_standalone(int device, const double *origin, const double *dests, int64_t n_dest, const double *planes,
+                            int32_t k, const double *edge, double *out_points, uint8_t *out_ok) {
+    if (!origin || (n_dest > 0 && (!dests || !out_points || !out_ok))) RT_FAIL("rt_solve_*: null argument");
+    if (k < 0 || k > RT_MAX_ORDER || (k > 0 && !planes)) RT_FAIL("rt_solve_*: bad plane count");
+    if (n_dest <= 0) return 0;
+    RT_HIP(hipSetDevice(device));
+    const int npts = k + (edge ? 1 : 0);
+    if (npts == 0) RT_FAIL("rt_solve_*: nothing to solve");
+    double *d_dest = nullptr, *d_planes = nullptr, *d_edge = nullptr, *d_out = nullptr;
+    uint8_t *d_ok = nullptr;
+    hipError_t e = hipMalloc(&d_dest, sizeof(double) * 3 * n_dest);
+    if (e == hipSuccess) e = hipMalloc(&d_planes, sizeof(double) * 4 * (k ? k : 1));
+    if (e == hipSuccess) e = hipMalloc(&d_edge, sizeof(double) * 6);
+    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(double) * 3 * npts * n_dest);
+    if (e == hipSuccess) e = hipMalloc(&d_ok, n_dest);
+    if (e == hipSuccess) e = hipMemcpy(d_dest, dests, sizeof(double) * 3 * n_dest, hipMemcpyHostToDevice);
+    if (e == hipSuccess && k) e = hipMemcpy(d_planes, planes, sizeof(double) * 4 * k, hipMemcpyHostToDevice);
+    if (e == hipSuccess && edge) e = hipMemcpy(d_edge, edge, sizeof(double) * 6, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_solve_standalone, dim3(blocks_for(n_dest, 256)), dim3(256), 0, 0, ld3(origin), d_dest, n_dest,
+                           d_planes, k, edge ? d_edge : nullptr, d_out, d_ok);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_points, d_out, sizeof(double) * 3 * npts * n_dest, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_ok, d_ok, n_dest, hipMemcpyDeviceToHost);
+    (void)hipFree(d_dest);
+    (void)hipFree(d_planes);
+    (void)hipFree(d_edge);
+    (void)hipFree(d_out);
+    (void)hipFree(d_ok);
+    if (e != hipSuccess) RT_FAIL(std::string("rt_solve_*: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int rt_solve_reflections(int device, const double *origin, const double *dests, int64_t n_dest,
+                                    const double *planes, int32_t k, double *out_points, uint8_t *out_ok) {
+    return solve_standalone(device, origin, dests, n_dest, planes, k, nullptr, out_points, out_ok);
+}
+
+extern "C" int rt_solve_reflections_diffraction(int device, const double *origin, const double *dests, int64_t n_dest,
+                                                const double *planes, int32_t k, const double *edge,
+                                                double *out_points, uint8_t *out_ok) {
+    if (!edge) RT_FAIL("rt_solve_reflections_diffraction: null edge");
+    return solve_standalone(device, origin, dests, n_dest, planes, k, edge, out_points, out_ok);
+}

@@ -1,0 +1,771 @@
+"""Scene model and geometry entry points of the path-solve path.
+
+Host side of the reference's ``raytracing/geometry.py``: the polygon / building / place containers with the
+same names, construction rules and polygon ORDER (everything downstream — visibility matrix rows, candidate
+chains, path records — is indexed by that order), plus the geometry entry points, which hand the work to the
+HIP library through ``raytracing_amd._lib`` (no CPU implementation of those lives here).
+
+Reference lines followed:
+  plane / frame / bounding box of a polygon ........ geometry.py:1437-1465, 1747-1853
+  building extrusion, emitter cube ................. geometry.py:2313-2415, 2508-2531
+  place and its polygon order ...................... geometry.py:2534-2663
+  GeoJSON -> place ................................. geometry.py:2806-2920
+The reference builds scenes with GeoPandas/PROJ/GDAL and unseeded random heights; ``load_place`` does the same
+steps with a small tolerant GeoJSON reader, an own ETRS89-LAEA (EPSG:3035) forward projection and a seeded
+generator, so a scene is a pure function of (file, seed).
+"""
+import itertools
+import json
+import math
+import re
+import uuid
+
+import numpy as np
+
+from . import array_utils
+from . import container_utils
+from .materials_properties import MATERIAL_ID, material_of_building_type, set_properties
+
+
+# --------------------------------------------------------------------------------------------------
+# small numeric helpers (reference geometry.py:33, 72-87, 135-146, 150-181)
+# --------------------------------------------------------------------------------------------------
+
+def midpoint(p1, p2):
+    return (p1 + p2) / 2
+
+
+def normalize_path(points):
+    """Unit vectors and lengths of the two legs of a 3-point path (reference geometry.py:72-87)."""
+    assert len(points) == 3
+    vectors = np.diff(points, axis=0)
+    norms = np.linalg.norm(vectors, axis=1)
+    return vectors[0] / norms[0], norms[0], vectors[1] / norms[1], norms[1]
+
+
+def path_length(points):
+    return np.sum(np.linalg.norm(np.diff(points, axis=0), axis=1))
+
+
+def enclosed_area(points):
+    """Signed shoelace sum of the xy projection; NEGATIVE for counter-clockwise (reference :150-167)."""
+    x = points[:, 0]
+    y = points[:, 1]
+    s = np.sum((x[1:] - x[:-1]) * (y[1:] + y[:-1]))
+    s += (x[0] - x[-1]) * (y[0] + y[-1])
+    return s / 2
+
+
+def is_ccw(points):
+    return enclosed_area(points) < 0
+
+
+def projection_matrix_from_vector(vector):
+    """Orthonormal frame whose last axis is along ``vector`` (reference geometry.py:414-435)."""
+    z = vector / np.linalg.norm(vector)
+    y = np.ones_like(z)
+    y = y - y.dot(z) * z
+    y = y / np.linalg.norm(y)
+    x = np.cross(y, z)
+    matrix = np.empty((3, 3))
+    matrix[:, 0] = x
+    matrix[:, 1] = y
+    matrix[:, 2] = z
+    return matrix
+
+
+# --------------------------------------------------------------------------------------------------
+# containers
+# --------------------------------------------------------------------------------------------------
+
+class OrientedGeometry:
+    """Base container (reference geometry.py:1093-1507): id, attributes and cached bounding box."""
+
+    def __init__(self, **attributes):
+        self.attributes = attributes
+        self.id = attributes.pop("id", None)
+        if self.id is None:
+            self.id = str(uuid.uuid4())
+        self.domain = None
+        self.centroid = None
+        self.visibility_matrix = None
+        self.sharp_edges = None
+
+    def get_polygons_iter(self):
+        raise NotImplementedError
+
+    def get_polygons_list(self):
+        return list(self.get_polygons_iter())
+
+    def get_polygons_count(self):
+        return sum(1 for _ in self.get_polygons_iter())
+
+    def get_points(self):
+        return np.concatenate([polygon.points for polygon in self.get_polygons_iter()])
+
+    def get_domain(self, force=False):
+        if force or self.domain is None:
+            points = self.get_points()
+            self.domain = np.array([points.min(axis=0), points.max(axis=0)])
+        return self.domain
+
+    def get_centroid(self, force=False):
+        """Centre of the bounding box, not the centre of mass (reference :1452-1465)."""
+        if force or self.centroid is None:
+            self.centroid = self.get_domain().mean(axis=0)
+        return self.centroid
+
+    def get_visibility_matrix(self, strict=False, force=False):
+        if force or self.visibility_matrix is None:
+            self.visibility_matrix = polygons_visibility_matrix(self.get_polygons_list(), strict=strict)
+        return self.visibility_matrix
+
+    def get_sharp_edges(self, min_angle=10.0, force=False):
+        if force or self.sharp_edges is None:
+            self.sharp_edges = sharp_edges_visibility_dict(
+                polygons_sharp_edges_iter(self.get_polygons_list(), min_angle=min_angle))
+        return self.sharp_edges
+
+    def apply_on_points(self, func, *args, **kwargs):
+        raise NotImplementedError
+
+    def translate(self, vector):
+        vector = np.asarray(vector, dtype=float)
+        return self.apply_on_points(lambda p: p.reshape(-1, 3) + vector.reshape(1, 3))
+
+    def project(self, matrix, around_point=None):
+        matrix = np.asarray(matrix, dtype=float)
+        if around_point is None:
+            return self.apply_on_points(lambda p: p @ matrix.T)
+        a = np.asarray(around_point, dtype=float).reshape(1, 3)
+        return self.apply_on_points(lambda p: (p - a) @ matrix.T + a)
+
+
+class OrientedPolygon(OrientedGeometry):
+    """Planar polygon given by its vertices in order (reference geometry.py:1572-1853)."""
+
+    def __init__(self, points, **attributes):
+        super().__init__(**attributes)
+        self.points = np.asarray(points).astype(float)
+        self.parametric = None
+        self.matrix = None
+        self.properties = None
+        self.building_id = None
+        self.part = "side"
+
+    def __len__(self):
+        return self.points.shape[0]
+
+    def __str__(self):
+        return (f"Polygon({len(self)} points) part {self.part}, building id: {self.building_id}, "
+                f"properties set?:{self.properties is not None}")
+
+    def __eq__(self, other):
+        if not isinstance(other, OrientedPolygon):
+            return False
+        return (self.id == other.id and np.array_equal(self.points, other.points)
+                and self.building_id == other.building_id and self.part == other.part
+                and self.properties == other.properties)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def get_polygons_iter(self):
+        yield self
+
+    def apply_on_points(self, func, *args, **kwargs):
+        return OrientedPolygon(func(self.points, *args, **kwargs))
+
+    def get_parametric(self, force=False):
+        """[a, b, c, d] with unit normal from the first three vertices, d = -n·p2 (reference :1747-1765)."""
+        if force or self.parametric is None:
+            p = self.points
+            normal = np.cross(p[1] - p[0], p[2] - p[1])
+            normal = normal / np.linalg.norm(normal)
+            d = -np.dot(normal, p[2])
+            self.parametric = np.array([normal[0], normal[1], normal[2], d])
+        return self.parametric
+
+    def get_normal(self):
+        return self.get_parametric()[:3]
+
+    def get_matrix(self, force=False):
+        """Columns [x, y, z]: x along the first side, z the normal, y = z × x (reference :1819-1853)."""
+        if not force and self.matrix is not None:
+            return self.matrix
+        normal = self.get_normal()
+        matrix = np.empty((3, 3))
+        matrix[0] = self.points[1] - self.points[0]
+        matrix[1] = np.cross(normal, matrix[0])
+        matrix[2] = normal
+        for i in range(2):
+            matrix[i] /= np.linalg.norm(matrix[i])
+        self.matrix = matrix.T
+        return self.matrix
+
+    def distance_to_point(self, point):
+        return np.dot(self.get_normal(), (np.asarray(point, dtype=float).reshape(3) - self.points[0]))
+
+    def contains_point(self, point, check_in_plane=False, plane_tol=1e-8):
+        """Point-in-polygon in the polygon's own frame, boundary included (reference :1778-1803).
+        Runs on the GPU through the library's containment entry point."""
+        from . import _lib
+
+        return bool(_lib.polygon_contains_points(self, np.asarray(point, dtype=float).reshape(1, 3),
+                                                 check_in_plane, plane_tol)[0])
+
+    def to_json(self):
+        return dict(id=self.id, **self.attributes, geotype="polygon", properties=self.properties,
+                    building_id=self.building_id, part=self.part, points=self.points.tolist())
+
+    @classmethod
+    def from_json(cls, data):
+        data = dict(data)
+        if data.pop("geotype") != "polygon":
+            raise ValueError("Cannot cast geotype to polygon.")
+        part = data.pop("part")
+        properties = data.pop("properties")
+        building_id = data.pop("building_id")
+        polygon = cls(np.array(data.pop("points")), **data)
+        polygon.part, polygon.properties, polygon.building_id = part, properties, building_id
+        return polygon
+
+
+class OrientedSurface(OrientedGeometry):
+    """A set of polygons, e.g. the ground (reference geometry.py:2006-2099)."""
+
+    def __init__(self, polygons, **attributes):
+        super().__init__(**attributes)
+        self.building_type = attributes.pop("building_type", None)
+        if self.building_type is None:
+            self.building_type = "road"
+        if type(polygons) != list:
+            polygons = [polygons]
+        if isinstance(polygons[0], np.ndarray):
+            self.polygons = [OrientedPolygon(points=p) for p in polygons]
+            for polygon in self.polygons:
+                polygon.properties = set_properties(self.building_type)
+                polygon.part = "ground"
+                polygon.building_id = self.id
+        elif isinstance(polygons[0], OrientedPolygon):
+            self.polygons = polygons
+        else:
+            raise ValueError("OrientedSurface needs a nump.ndarray or OrientedPolygon as input")
+
+    def __len__(self):
+        return len(self.polygons)
+
+    def get_polygons_iter(self):
+        return iter(self.polygons)
+
+    def apply_on_points(self, func, *args, **kwargs):
+        return OrientedSurface([p.apply_on_points(func, *args, **kwargs) for p in self.polygons])
+
+    def to_json(self):
+        return dict(id=self.id, **self.attributes, geotype="surface",
+                    polygons=[p.to_json() for p in self.polygons])
+
+    @classmethod
+    def from_json(cls, data):
+        data = dict(data)
+        if data.pop("geotype") != "surface":
+            raise ValueError("Cannot cast geotype to surface.")
+        polygons = [OrientedPolygon.from_json(p) for p in data.pop("polygons")]
+        return cls(polygons, **data)
+
+
+class OrientedPolyhedron(OrientedGeometry):
+    """Closed set of outward-oriented polygons (reference geometry.py:2122-2268)."""
+
+    def __init__(self, polygons, **attributes):
+        super().__init__(**attributes)
+        self.aux_surface = OrientedSurface(polygons)
+        self.polygons = self.aux_surface.polygons
+        self.building_type = attributes.pop("building_type", None)
+        for polygon in self.polygons:
+            polygon.building_id = self.id
+
+    def __len__(self):
+        return len(self.polygons)
+
+    def get_polygons_iter(self):
+        return iter(self.polygons)
+
+    def get_top_face(self):
+        for polygon in self.polygons:
+            if polygon.part == "top":
+                return polygon
+        assert False, f"could not get top face of {self}"
+
+    def get_bottom_face(self):
+        for polygon in self.polygons:
+            if polygon.part == "bottom":
+                return polygon
+        assert False, f"could not get bottom face of {self}"
+
+    def apply_on_points(self, func, *args, **kwargs):
+        return OrientedPolyhedron(self.aux_surface.apply_on_points(func, *args, **kwargs).polygons)
+
+    def apply_properties_to_polygons(self):
+        assert self.building_type is not None, f"building type for polyhedron {self} is not set"
+        for polygon in self.polygons:
+            polygon.properties = set_properties(self.building_type)
+
+    def to_json(self):
+        return dict(id=self.id, **self.attributes, geotype="polyhedron", building_type=self.building_type,
+                    polygons=[p.to_json() for p in self.polygons])
+
+    @classmethod
+    def from_json(cls, data):
+        data = dict(data)
+        if data.pop("geotype") != "polyhedron":
+            raise ValueError("Cannot cast geotype to polyhedron.")
+        polygons = [OrientedPolygon.from_json(p) for p in data.pop("polygons")]
+        building_type = data.pop("building_type", None)
+        out = cls(polygons, **data)
+        out.building_type = building_type
+        return out
+
+
+class Building(OrientedPolyhedron):
+    """Footprint extruded along z (reference geometry.py:2305-2415)."""
+
+    @staticmethod
+    def by_polygon_and_height(polygon, height, id=None, make_ccw=True, keep_ground=True, flat_roof=True):
+        if isinstance(polygon, OrientedPolygon):
+            bottom_points = polygon.points
+        elif isinstance(polygon, np.ndarray):
+            bottom_points = polygon
+        else:
+            raise ValueError(f"Type {type(polygon)} is not supported for polygon !")
+        bottom_points = np.asarray(bottom_points, dtype=float)
+        top_points = np.array(bottom_points)
+        if flat_roof:
+            top_points[:, -1] = float(np.max(bottom_points[:, 2]))
+        top_points[:, -1] += float(height)
+
+        if make_ccw:
+            if not is_ccw(top_points):
+                top_points = top_points[::-1, :]
+            else:
+                bottom_points = bottom_points[::-1, :]
+
+        top = OrientedPolygon(top_points)
+        top.part = "top"
+        bottom = OrientedPolygon(bottom_points)
+        bottom.part = "bottom"
+        if top.get_normal()[2] < 0:
+            top.parametric = -top.parametric
+        if bottom.get_normal()[2] > 0:
+            bottom.parametric = -bottom.parametric
+
+        polygons = [top, bottom] if keep_ground else [top]
+        walls_bottom = bottom_points[::-1, :]  # same xy order as the top ring
+        n = top_points.shape[0]
+        for i in range(n):
+            a, b = top_points[i - 1], top_points[i]
+            c, d = walls_bottom[i - 1], walls_bottom[i]
+            polygons.append(OrientedPolygon(np.vstack([a, c, d, b])))
+        return OrientedPolyhedron(polygons, id=id)
+
+    @staticmethod
+    def by_polygon2d_and_height(polygon, height, id=None, make_ccw=True, keep_ground=False, flat_roof=True):
+        points_2d = np.asarray(polygon, dtype=float)
+        if points_2d.ndim != 2 or points_2d.shape[1] != 2:
+            raise ValueError(f"Type {type(polygon)} is not supported for polygon !")
+        if np.array_equal(points_2d[0], points_2d[-1]):
+            points_2d = points_2d[:-1]  # GeoJSON rings repeat the first vertex
+        points_3d = np.hstack((points_2d, np.zeros((len(points_2d), 1))))
+        return Building.by_polygon_and_height(OrientedPolygon(points_3d), height, id, make_ccw=make_ccw,
+                                              keep_ground=keep_ground, flat_roof=flat_roof)
+
+
+class Cube(OrientedPolyhedron):
+    """Axis-aligned cube around a point; its 6 faces are the emitter's screens (reference :2502-2531)."""
+
+    @staticmethod
+    def by_point_and_side_length(point, side_length):
+        r = side_length / 2
+        polygon = np.array([[r, r, -r], [-r, r, -r], [-r, -r, -r], [r, -r, -r]], dtype=float)
+        polygon += np.asarray(point, dtype=float).reshape(1, 3)
+        building = Building.by_polygon_and_height(polygon, side_length)
+        return Cube(building.polygons)
+
+
+class OrientedPlace(OrientedGeometry):
+    """Ground surface + polyhedra + receiver points (reference geometry.py:2534-2663)."""
+
+    def __init__(self, surface, polyhedra=None, set_of_points=None, **attributes):
+        super().__init__(**attributes)
+        if isinstance(surface, OrientedSurface):
+            self.surface = surface
+        elif type(surface) == list or type(surface) == np.ndarray:
+            self.surface = OrientedSurface(surface)
+        else:
+            raise ValueError("OrientedPlace needs an OrientedSurface or a numpy.ndarray as surface input")
+        if polyhedra is not None:
+            if type(polyhedra) != list:
+                polyhedra = [polyhedra]
+            if len(polyhedra) == 0 or isinstance(polyhedra[0], OrientedPolyhedron):
+                self.polyhedra = polyhedra
+            else:
+                self.polyhedra = [OrientedPolyhedron(p) for p in polyhedra]
+        else:
+            self.polyhedra = []
+        if set_of_points is None:
+            set_of_points = np.empty((0, 3))
+        if type(set_of_points) == np.ndarray and set_of_points.ndim == 2 and set_of_points.shape[1] == 3:
+            self.set_of_points = set_of_points
+        else:
+            raise ValueError(f"OrientedPlace has an invalid set_of_points as input: {set_of_points}, "
+                             f"type {type(set_of_points)}")
+        self._scene_arrays = None
+
+    def __str__(self):
+        return f"Place({len(self.polyhedra)} polyhedra, {self.set_of_points.shape[0]} points)"
+
+    def add_set_of_points(self, points):
+        self.set_of_points = np.concatenate([self.set_of_points, np.asarray(points, dtype=float).reshape(-1, 3)])
+
+    def get_polygons_iter(self):
+        """Ground polygons first, then each polyhedron's polygons in its own order (reference :2650-2656)."""
+        return itertools.chain(self.surface.get_polygons_iter(),
+                               itertools.chain.from_iterable(p.get_polygons_iter() for p in self.polyhedra))
+
+    def apply_on_points(self, func, *args, **kwargs):
+        surface = self.surface.apply_on_points(func, *args, **kwargs)
+        polyhedra = [p.apply_on_points(func, *args, **kwargs) for p in self.polyhedra]
+        return OrientedPlace(surface, polyhedra=polyhedra, set_of_points=func(self.set_of_points, *args, **kwargs))
+
+    def obstructs_line_path(self, points):
+        return polygons_obstruct_line_path(self.get_polygons_list(), points)
+
+    def add_tree_crowns(self):
+        """Adds a crown on every tree trunk (reference :2789-2802); scenes built here have no trunks."""
+        crowns = []
+        for polyhedron in self.polyhedra:
+            if polyhedron.building_type == "tree_trunk":
+                raise NotImplementedError("tree trunks are not part of the scenes this package builds")
+        self.polyhedra.extend(crowns)
+
+    def to_json(self, filename=None):
+        data = dict(id=self.id, **self.attributes, geotype="place", surface=self.surface.to_json(),
+                    polyhedra=[p.to_json() for p in self.polyhedra], set_of_points=self.set_of_points.tolist())
+        if filename is not None:
+            with open(filename, "w") as f:
+                json.dump(data, f)
+        return data
+
+    @classmethod
+    def from_json(cls, data=None, filename=None):
+        if data is None:
+            with open(filename) as f:
+                data = json.load(f)
+        data = dict(data)
+        if data.pop("geotype") != "place":
+            raise ValueError("Cannot cast geotype to place.")
+        surface = OrientedSurface.from_json(data.pop("surface"))
+        polyhedra = [OrientedPolyhedron.from_json(p) for p in data.pop("polyhedra")]
+        points = np.array(data.pop("set_of_points"), dtype=float).reshape(-1, 3)
+        return cls(surface, polyhedra, points, **data)
+
+
+# --------------------------------------------------------------------------------------------------
+# flat (structure-of-arrays) view of a polygon list: what the HIP library consumes
+# --------------------------------------------------------------------------------------------------
+
+class SceneArrays:
+    """Contiguous arrays describing N polygons.
+
+    vert_off  int32  [N+1]     CSR offsets into ``verts``
+    verts     float64[Vtot,3]  vertices, polygon after polygon, in each polygon's own order
+    planes    float64[N,4]     [nx, ny, nz, d] exactly as ``get_parametric`` returns them (tops/bottoms may carry
+                               a flipped sign, see ``Building.by_polygon_and_height``)
+    material  int32  [N]       index into ``materials_properties.MATERIAL_NAMES``
+    building  int32  [N]       dense id of the polyhedron / surface the polygon belongs to
+    """
+
+    def __init__(self, polygons):
+        polygons = list(polygons)
+        self.n = len(polygons)
+        counts = np.array([len(p) for p in polygons], dtype=np.int64)
+        self.vert_off = np.zeros(self.n + 1, dtype=np.int32)
+        np.cumsum(counts, out=self.vert_off[1:])
+        self.verts = np.ascontiguousarray(np.concatenate([p.points for p in polygons]), dtype=np.float64)
+        self.planes = np.ascontiguousarray(np.array([p.get_parametric() for p in polygons]), dtype=np.float64)
+        self.material = np.zeros(self.n, dtype=np.int32)
+        self.building = np.zeros(self.n, dtype=np.int32)
+        building_index = {}
+        for i, p in enumerate(polygons):
+            material = "concrete"
+            if p.properties is not None:
+                material = p.properties.get("material", "concrete")
+            self.material[i] = MATERIAL_ID[material]
+            self.building[i] = building_index.setdefault(p.building_id, len(building_index))
+        self._device_scene = None
+
+    def device_scene(self):
+        """The library-side scene handle for these polygons (created on first use, then reused)."""
+        from . import _lib
+
+        if self._device_scene is None:
+            self._device_scene = _lib.Scene(self)
+        return self._device_scene
+
+
+def scene_arrays_of(polygons):
+    """SceneArrays for a polygon list, cached on the list's first polygon so repeated calls reuse the upload."""
+    polygons = list(polygons)
+    key = tuple(id(p) for p in polygons)
+    cache = getattr(polygons[0], "_scene_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    arrays = SceneArrays(polygons)
+    polygons[0]._scene_cache = (key, arrays)
+    return arrays
+
+
+# --------------------------------------------------------------------------------------------------
+# geometry entry points (GPU)
+# --------------------------------------------------------------------------------------------------
+
+def polygons_obstruct_line_path(polygons, points, return_polygons=False):
+    """True when any polygon cuts the open segment ``points[0] -> points[1]`` (reference geometry.py:836-898)."""
+    from . import _lib
+
+    points = np.asarray(points, dtype=float)
+    assert len(points) == 2, "wrong argument"
+    polygons = list(polygons)
+    if len(polygons) == 0:
+        return [] if return_polygons else False
+    scene = scene_arrays_of(polygons).device_scene()
+    if return_polygons:
+        hits = np.flatnonzero(scene.segment_hits(points.reshape(1, 2, 3))[0])
+        groups, current = [], []
+        for i in hits:  # grouping rule of the reference (:886-895)
+            if not current or current[0].building_id == polygons[i].building_id:
+                current.append(polygons[i])
+            else:
+                groups.append(current)
+                current = []
+        if current:
+            groups.append(current)
+        return groups
+    return bool(scene.obstructed(points.reshape(1, 2, 3))[0])
+
+
+def polygon_visibility_vector(polygon_A, polygons, out=None, strict=False):
+    """Which polygons a ray leaving the front of ``polygon_A`` may hit (reference geometry.py:924-1019).
+    ``out`` is OR-ed into when given; a fresh vector starts at all-False (the reference leaves it uninitialised)."""
+    polygons = list(polygons)
+    scene = scene_arrays_of(polygons).device_scene()
+    self_index = -1
+    for i, p in enumerate(polygons):
+        if p is polygon_A:
+            self_index = i
+            break
+    vis = scene.face_visibility(polygon_A.points, polygon_A.get_parametric(), self_index, strict)
+    if out is None:
+        return vis
+    out |= vis
+    return out
+
+
+def polygons_visibility_matrix(polygons, strict=False):
+    """Symmetric N×N visibility matrix (reference geometry.py:1022-1048)."""
+    polygons = list(polygons)
+    return scene_arrays_of(polygons).device_scene().visibility_matrix(strict)
+
+
+def polygons_sharp_edges_iter(polygons, min_angle=10.0):
+    """Yields ``(edge (2,3), i, j)`` for every convex shared edge, pairs in ascending (i, j) order
+    (reference geometry.py:482-565)."""
+    polygons = list(polygons)
+    pairs, edges = scene_arrays_of(polygons).device_scene().sharp_edges(min_angle)
+    for (i, j), edge in zip(pairs, edges):
+        yield edge, int(i), int(j)
+
+
+def sharp_edges_visibility_dict(sharp_edges):
+    d = container_utils.ManyToOneDict()
+    for edge, i, j in sharp_edges:
+        d[i, j] = edge
+    return d
+
+
+class SolveResult:
+    """What the three solver entry points return beside the points: the fields of SciPy's result object that the
+    reference's callers read (``success``, ``x``)."""
+
+    def __init__(self, x, success):
+        self.x = x
+        self.success = bool(success)
+        self.status = 1 if success else 0
+        self.message = "The solution converged." if success else "No specular solution exists."
+
+
+def reflexion_points_from_origin_destination_and_planes(origin, destination, planes_parametric, **kwargs):
+    """Reflection point on each plane (reference geometry.py:660-687).  ``success`` is False when no specular path
+    exists over the infinite planes (an image segment misses its plane)."""
+    from . import _lib
+
+    planes = np.asarray(planes_parametric, dtype=float).reshape(-1, 4)
+    x, ok = _lib.solve_reflections(np.asarray(origin, dtype=float).reshape(3),
+                                   np.asarray(destination, dtype=float).reshape(1, 3), planes)
+    return x[0], SolveResult(x[0].reshape(-1), ok[0])
+
+
+def diffraction_point_from_origin_destination_and_edge(origin, destination, edge, **kwargs):
+    """Keller-cone point on the edge's line (reference geometry.py:718-748)."""
+    from . import _lib
+
+    x, ok = _lib.solve_reflections_and_diffraction(np.asarray(origin, dtype=float).reshape(3),
+                                                   np.asarray(destination, dtype=float).reshape(1, 3),
+                                                   np.empty((0, 4)), np.asarray(edge, dtype=float).reshape(2, 3))
+    return x[0], SolveResult(x[0].reshape(-1), ok[0])
+
+
+def reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge(origin, destination,
+                                                                                   planes_parametric, edge, **kwargs):
+    """Reflections then one diffraction (reference geometry.py:800-833), including its rule that the reflection
+    points are aimed at the edge's first endpoint."""
+    from . import _lib
+
+    if len(planes_parametric) == 0:
+        return diffraction_point_from_origin_destination_and_edge(origin, destination, edge, **kwargs)
+    if edge is None:
+        return reflexion_points_from_origin_destination_and_planes(origin, destination, planes_parametric, **kwargs)
+    planes = np.asarray(planes_parametric, dtype=float).reshape(-1, 4)
+    x, ok = _lib.solve_reflections_and_diffraction(np.asarray(origin, dtype=float).reshape(3),
+                                                   np.asarray(destination, dtype=float).reshape(1, 3),
+                                                   planes, np.asarray(edge, dtype=float).reshape(2, 3))
+    return x[0], SolveResult(x[0].reshape(-1), ok[0])
+
+
+def point_on_edge_(point, edge, tol=1e-8):
+    """Point within a ±tol box of the edge in the edge-aligned frame (reference geometry.py:456-479)."""
+    edge = np.asarray(edge, dtype=float)
+    matrix = projection_matrix_from_vector(edge[1] - edge[0]).T
+    pe = edge @ matrix.T
+    pp = np.asarray(point, dtype=float).reshape(3) @ matrix.T
+    a, b = pe[0], pe[1]
+    return bool(a[0] - tol <= pp[0] <= a[0] + tol and a[1] - tol <= pp[1] <= a[1] + tol
+                and a[2] - tol <= pp[2] <= b[2] + tol)
+
+
+# --------------------------------------------------------------------------------------------------
+# GeoJSON -> place
+# --------------------------------------------------------------------------------------------------
+
+_GRS80_A = 6378137.0
+_GRS80_F = 1.0 / 298.257222101
+
+
+def lonlat_to_epsg3035(lon_deg, lat_deg):
+    """Forward ETRS89-LAEA Europe (EPSG:3035): Lambert azimuthal equal-area on GRS80, origin 52°N 10°E,
+    false easting 4 321 000 m, false northing 3 210 000 m (EPSG guidance note 7-2, method 9820).
+    The reference gets this from PROJ through ``GeoDataFrame.to_crs(epsg=3035)`` (geometry.py:2916)."""
+    lon = np.radians(np.asarray(lon_deg, dtype=float))
+    lat = np.radians(np.asarray(lat_deg, dtype=float))
+    e2 = 2 * _GRS80_F - _GRS80_F ** 2
+    e = math.sqrt(e2)
+    lat0, lon0 = math.radians(52.0), math.radians(10.0)
+
+    def q(phi):
+        s = np.sin(phi)
+        return (1 - e2) * (s / (1 - e2 * s * s) - (1 / (2 * e)) * np.log((1 - e * s) / (1 + e * s)))
+
+    qp = q(math.pi / 2)
+    q0 = q(lat0)
+    beta = np.arcsin(q(lat) / qp)
+    beta0 = math.asin(q0 / qp)
+    rq = _GRS80_A * math.sqrt(qp / 2)
+    d = _GRS80_A * (math.cos(lat0) / math.sqrt(1 - e2 * math.sin(lat0) ** 2)) / (rq * math.cos(beta0))
+    b = rq * np.sqrt(2 / (1 + math.sin(beta0) * np.sin(beta) + math.cos(beta0) * np.cos(beta) * np.cos(lon - lon0)))
+    east = 4321000.0 + b * d * np.cos(beta) * np.sin(lon - lon0)
+    north = 3210000.0 + (b / d) * (math.cos(beta0) * np.sin(beta) - math.sin(beta0) * np.cos(beta) * np.cos(lon - lon0))
+    return east, north
+
+
+def read_geojson_tolerant(path):
+    """Parse a GeoJSON file, accepting the trailing commas GDAL accepts (``place_levant*.geojson`` have them)."""
+    with open(path, encoding="utf-8") as f:
+        text = f.read()
+    try:
+        return json.loads(text)
+    except json.JSONDecodeError:
+        return json.loads(re.sub(r",(\s*[}\]])", r"\1", text))
+
+
+def preprocess_geojson(filename, drop_missing_heights=False, seed=0, project=True):
+    """Footprints of a rooftop file as a list of dicts ``{ring (n,2) metres, height, building_type, id}``.
+
+    Steps of the reference's ``preprocess_geojson`` (geometry.py:2867-2920): keep Polygon features only, fill
+    missing heights with uniform(8, 15) rounded to 0.1 m, default building type "appartments", one id per
+    building, project lon/lat to EPSG:3035.  Differences, all for determinism: the random heights come from
+    ``numpy.random.default_rng(seed)`` (one draw per feature, used where the file has none), ids are derived from
+    the seed, and the result stays in memory instead of being written next to the input.
+    """
+    data = read_geojson_tolerant(filename)
+    features = [f for f in data["features"] if f.get("geometry") and f["geometry"].get("type") == "Polygon"]
+    rng = np.random.default_rng(seed)
+    random_heights = np.round(rng.uniform(8, 15, size=len(features)), 1)
+    id_rng = np.random.default_rng([seed, 1])
+    out = []
+    for k, feature in enumerate(features):
+        props = feature.get("properties") or {}
+        height = props.get("height", None)
+        try:
+            height = float(height) if height is not None else float("nan")
+        except (TypeError, ValueError):
+            height = float("nan")
+        if math.isnan(height):
+            if drop_missing_heights:
+                continue
+            height = float(random_heights[k])
+        ring = np.asarray(feature["geometry"]["coordinates"][0], dtype=float)[:, :2]  # exterior only (:2404)
+        if project:
+            x, y = lonlat_to_epsg3035(ring[:, 0], ring[:, 1])
+            ring = np.column_stack([x, y])
+        building_id = str(uuid.UUID(int=int(id_rng.integers(0, 2 ** 63)) << 64 | int(id_rng.integers(0, 2 ** 63))))
+        out.append(dict(ring=ring, height=height, building_type=props.get("building_type", "appartments"),
+                        id=building_id))
+    return out
+
+
+def generate_place_from_rooftops_file(roof_top_file, center=True, drop_missing_heights=True, default_height=10,
+                                      seed=0):
+    """Place made of one flat ground quad over the footprints' bounding box and one extruded building per
+    footprint (reference geometry.py:2824-2863).  Accepts either a path or the list ``preprocess_geojson``
+    returns."""
+    footprints = roof_top_file
+    if isinstance(roof_top_file, (str, bytes)) or hasattr(roof_top_file, "__fspath__"):
+        footprints = preprocess_geojson(roof_top_file, seed=seed)
+    all_xy = np.concatenate([f["ring"] for f in footprints])
+    lo, hi = all_xy.min(axis=0), all_xy.max(axis=0)
+    shift = (lo + hi) / 2 if center else np.zeros(2)
+    lo, hi = lo - shift, hi - shift
+
+    polyhedra = []
+    for f in footprints:
+        building = Building.by_polygon2d_and_height(f["ring"] - shift, f["height"], id=f["id"], keep_ground=False,
+                                                    flat_roof=True)
+        building.building_type = f["building_type"]
+        building.apply_properties_to_polygons()
+        polyhedra.append(building)
+
+    ground = np.zeros((4, 3))  # corner order of the reference's get_bounds (:2815-2822)
+    ground[0::3, 0] = lo[0]
+    ground[1:3, 0] = hi[0]
+    ground[:2, 1] = lo[1]
+    ground[2:, 1] = hi[1]
+    place = OrientedPlace(OrientedSurface(ground, building_type="ground"))
+    place.polyhedra = polyhedra
+    return place
+
+
+def load_place(filename, seed=0):
+    """``preprocess_geojson`` + ``generate_place_from_rooftops_file`` in one deterministic call."""
+    return generate_place_from_rooftops_file(preprocess_geojson(filename, seed=seed))

@@ -1,0 +1,219 @@
+"""``RayTracingProblem`` with the reference's construction and solve interface, computed on the GPU.
+
+Mirrors ``raytracing/ray_tracing.py`` of the reference: constructor and attributes (:32-63), ``precompute`` (:201-237),
+``solve`` (:281-390), ``to_json`` / ``from_json`` (:66-132).  The result containers have the reference's shapes:
+    los[r]                   list of (2,3) arrays
+    reflections[r][order]    list of (lines (order+2,3), [polygon indices])
+    diffractions[r][order]   list of (lines (order+2,3), [polygon indices], (i, j), edge (2,3))
+in the order the reference's depth-first loops produce them.
+"""
+import json
+from collections import defaultdict
+
+import numpy as np
+
+from . import _lib
+from . import geometry as geom
+
+
+class RayTracingProblem:
+    def __init__(self, emitter, place, receivers=None, n_screens=6):
+        assert 0 < n_screens <= 6
+        self.emitter = emitter
+        self.n_screens = n_screens
+        self.place = place
+        self.polygons = None
+        self.receivers = np.array([])
+        if self.place is not None:
+            polygon_list = place.get_polygons_list()
+            self.polygons = np.empty(len(polygon_list), dtype=object)
+            for i, p in enumerate(polygon_list):
+                self.polygons[i] = p
+            self.receivers = self.place.set_of_points
+        if receivers is not None:
+            # as in the reference (:42-43) the extra receivers reach the place, not this problem's receiver list
+            self.place.add_set_of_points(receivers)
+        self.solved_receivers = None
+        self.visibility_matrix = None
+        self.distance_to_screen = None
+        self.emitter_visibility = None
+        self.sharp_edges = None
+        self.path_solves_attempted = 0
+        self._scene = None
+        self._edge_pairs = None
+        self._edge_array = None
+        n = self.receivers.shape[0]
+        self.los = {r: list() for r in range(n)}
+        self.reflections = {r: defaultdict(list) for r in range(n)}
+        self.diffractions = {r: defaultdict(list) for r in range(n)}
+        if self.place is not None:
+            self.precompute()
+
+    # ------------------------------------------------------------------------------------------------
+    def _device_scene(self):
+        if self._scene is None:
+            self._scene = geom.scene_arrays_of(list(self.polygons)).device_scene()
+        return self._scene
+
+    def precompute(self):
+        """Visibility matrix, emitter visibility through the screens of a 0.2 m cube, sharp edges, lines of sight."""
+        scene = self._device_scene()
+        self.visibility_matrix = self.place.get_visibility_matrix(strict=False)
+        emitter = np.asarray(self.emitter, dtype=float)
+        cube = geom.Cube.by_point_and_side_length(emitter, 2 * 0.1)
+        self.distance_to_screen = cube.polygons[0].distance_to_point(emitter)
+
+        visibilities = []
+        for i in range(self.n_screens):
+            screen = cube.polygons[i]
+            vis = scene.face_visibility(screen.points, screen.get_parametric(), -1, False)
+            visibilities.append((int(np.sum(vis)), vis))
+        visibilities.sort(key=lambda x: x[0], reverse=True)
+        self.emitter_visibility = visibilities[0][1].copy()
+        for _, vis in visibilities[1:self.n_screens]:
+            self.emitter_visibility |= vis
+
+        self.sharp_edges = self.place.get_sharp_edges()
+        keys = list(self.sharp_edges.keys())
+        self._edge_pairs = np.array(keys, dtype=np.int32).reshape(-1, 2)
+        self._edge_array = np.array([dict.__getitem__(self.sharp_edges, k) for k in keys], dtype=float).reshape(-1, 2, 3)
+
+        if len(self.receivers) > 0:
+            tx = emitter.reshape(3)
+            segs = np.concatenate([np.broadcast_to(tx, (len(self.receivers), 3)), self.receivers], axis=1)
+            blocked = scene.obstructed(segs, mask=self.emitter_visibility)
+            for r, receiver in enumerate(self.receivers):
+                if not blocked[r]:
+                    self.los[r].append(np.vstack([emitter.reshape(1, 3), receiver.reshape(1, 3)]))
+
+    def get_visible_polygons_indices(self, index):
+        return np.where(self.visibility_matrix[index, :])[0]
+
+    # ------------------------------------------------------------------------------------------------
+    def check_reflections(self, lines, polygons_indices):
+        """Validity of one reflection path (reference :243-274)."""
+        scene = self._device_scene()
+        lines = np.asarray(lines, dtype=float)
+        for i, index in enumerate(polygons_indices):
+            if not scene.contains_points(index, lines[i + 1], True, 1e-8)[0]:
+                return False
+        segs = np.concatenate([lines[:-1], lines[1:]], axis=1)[:len(polygons_indices) + 1]
+        if scene.obstructed(segs).any():
+            return False
+        return bool((np.linalg.norm(np.diff(lines, axis=0), axis=1) >= 0.005).all())
+
+    def check_reflections_and_diffraction(self, lines, polygons_indices, edge):
+        return self.check_reflections(lines[:-1, :], polygons_indices) and geom.point_on_edge_(lines[-2, :], edge) \
+            and not self._device_scene().obstructed(np.concatenate([lines[-2], lines[-1]]).reshape(1, 6))[0]
+
+    # ------------------------------------------------------------------------------------------------
+    def solve(self, max_order=2, receivers_indexs=None):
+        """Finds every reflection / diffraction path up to ``max_order`` for all (or the listed) receivers.
+        Results are appended to ``reflections`` / ``diffractions`` (calling twice appends twice, as the reference)."""
+        emitter = np.asarray(self.emitter, dtype=float)
+        if receivers_indexs is not None:
+            assert all(i < len(self.receivers) for i in receivers_indexs), \
+                f"provided RX indexs {receivers_indexs} but only {len(self.receivers)} RX exist"
+            rx_ids = [int(i) for i in receivers_indexs]
+            receivers = [self.receivers[i] for i in rx_ids]
+        else:
+            rx_ids = list(range(len(self.receivers)))
+            receivers = self.receivers
+        if max_order < 1 or len(rx_ids) == 0:
+            if max_order >= 2:
+                self.solved_receivers = receivers
+            return
+
+        scene = self._device_scene()
+        cand = scene.enumerate(self.visibility_matrix, self.emitter_visibility, self._edge_pairs, self._edge_array,
+                               max_order, with_diffraction=True)
+        rx = np.asarray([self.receivers[i] for i in rx_ids], dtype=float).reshape(-1, 3)
+        res = scene.solve_paths(cand, emitter.reshape(3), rx)
+        self.path_solves_attempted += res["n_attempted"]
+        tx_row = emitter.reshape(1, 3)
+        edge_keys = [tuple(int(v) for v in k) for k in self._edge_pairs]
+        for local_rx, g, c, pts in zip(res["rx"], res["group"], res["cand"], res["points"]):
+            if g < 0:
+                continue  # lines of sight were stored by precompute()
+            r = rx_ids[int(local_rx)]
+            n_refl, has_edge = cand.group_kind(int(g))
+            chains, edge_ids = cand.group(int(g))
+            chain = [int(v) for v in chains[int(c)]] if n_refl else []
+            n_pts = n_refl + (1 if has_edge else 0)
+            lines = np.vstack([tx_row, pts[:n_pts], self.receivers[r].reshape(1, 3)])
+            if has_edge:
+                e = int(edge_ids[int(c)])
+                self.diffractions[r][n_refl + 1].append((lines, chain, edge_keys[e], self._edge_array[e].copy()))
+            else:
+                self.reflections[r][n_refl].append((lines, chain))
+        cand.close()
+        if max_order >= 2:
+            self.solved_receivers = receivers  # the reference only gets here for max_order >= 2 (:352-353, 390)
+
+    # ------------------------------------------------------------------------------------------------
+    def path_set(self):
+        """Set of (rx, kind, order, polygon chain, edge key): the surviving path set."""
+        out = set()
+        for r, lst in self.los.items():
+            for _ in lst:
+                out.add((r, "LOS", 0, (), ()))
+        for r, by_order in self.reflections.items():
+            for order, lst in by_order.items():
+                for _, chain in lst:
+                    out.add((r, "R", order, tuple(chain), ()))
+        for r, by_order in self.diffractions.items():
+            for order, lst in by_order.items():
+                for item in lst:
+                    out.add((r, "D", order, tuple(item[1]), tuple(item[2])))
+        return out
+
+    def __str__(self):
+        return (f"RayTracingProblem object containing: {self.place}, emitter: {self.emitter}, "
+                f"number of solved_receivers: {len(self.solved_receivers) if self.solved_receivers is not None else 0}, "
+                f"los: {len(self.los)}, reflections: {len(self.reflections)}, diffractions : {len(self.diffractions)}")
+
+    # ---- on-disk format of the reference (:66-132) -------------------------------------------------------
+    def to_json(self, filename):
+        def enc(obj):
+            if isinstance(obj, np.ndarray):
+                return obj.tolist()
+            if isinstance(obj, (np.integer,)):
+                return int(obj)
+            if isinstance(obj, (np.floating,)):
+                return float(obj)
+            raise TypeError(type(obj))
+
+        data = {
+            "place": self.place.to_json(),
+            "receivers": self.receivers,
+            "solved_receivers": self.solved_receivers,
+            "emitter": self.emitter,
+            "n_screens": self.n_screens,
+            "los": self.los,
+            "reflections": self.reflections,
+            "diffractions": self.diffractions,
+        }
+        filename = filename if ".json" in filename else f"{filename}.json"
+        with open(filename, "w") as f:
+            json.dump(data, f, default=enc)
+
+    @staticmethod
+    def from_json(filename):
+        with open(filename) as f:
+            data = json.load(f)
+        place = geom.OrientedPlace.from_json(data=data["place"])
+        problem = RayTracingProblem(np.array(data["emitter"]), place, n_screens=data["n_screens"])
+        solved = data.get("solved_receivers")
+        problem.solved_receivers = [np.array(s) for s in solved] if solved is not None else None
+        problem.reflections = {int(r): defaultdict(list) for r in data["reflections"]}
+        for r, by_order in data["reflections"].items():
+            for k, items in by_order.items():
+                for points, indices in items:
+                    problem.reflections[int(r)][int(k)].append((np.array(points), indices))
+        problem.diffractions = {int(r): defaultdict(list) for r in data["diffractions"]}
+        for r, by_order in data["diffractions"].items():
+            for k, items in by_order.items():
+                for points, chain, indices, edge_points in items:
+                    problem.diffractions[int(r)][int(k)].append((np.array(points), chain, tuple(indices),
+                                                                 np.array(edge_points)))
+        return problem

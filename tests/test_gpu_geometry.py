@@ -1,0 +1,184 @@
+"""GPU parity of the geometry entry points against the CPU oracle, through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+
+from conftest import oracle_polys, small_tx_rx
+
+pytestmark = pytest.mark.gpu
+
+
+def random_segments(place, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = place.get_domain()
+    lo = lo - [5, 5, 0]
+    hi = hi + [5, 5, 10]
+    a = rng.uniform(lo, hi, size=(n, 3))
+    b = rng.uniform(lo, hi, size=(n, 3))
+    return np.concatenate([a, b], axis=1)
+
+
+@pytest.mark.parametrize("name,n", [("small", 400), ("place_levant", 300)])
+def test_obstruction_matches_oracle(places, name, n):
+    from oracle import geometry_oracle as go
+    from raytracing_amd import geometry as geom
+
+    place = places(name)
+    polys = oracle_polys(place)
+    scene = geom.scene_arrays_of(place.get_polygons_list()).device_scene()
+    segs = random_segments(place, n, 1)
+    got = scene.obstructed(segs)
+    want = np.array([go.polygons_obstruct_line_path(polys, s.reshape(2, 3)) for s in segs])
+    assert got.sum() > 10 and (~got).sum() > 10
+    np.testing.assert_array_equal(got, want)
+    # masked form (what the line-of-sight step uses)
+    mask = np.zeros(len(polys), dtype=bool)
+    mask[::3] = True
+    got = scene.obstructed(segs, mask=mask)
+    sub = [p for p, m in zip(polys, mask) if m]
+    want = np.array([go.polygons_obstruct_line_path(sub, s.reshape(2, 3)) for s in segs])
+    np.testing.assert_array_equal(got, want)
+    # every-polygon form
+    hits = scene.segment_hits(segs[:40])
+    for s, h in zip(segs[:40], hits):
+        assert list(np.flatnonzero(h)) == go.polygons_obstruct_line_path(polys, s.reshape(2, 3), return_indices=True)
+
+
+def test_obstruction_api_and_edge_cases(places):
+    from raytracing_amd import geometry as geom
+
+    place = places("small")
+    polygons = place.get_polygons_list()
+    scene = geom.scene_arrays_of(polygons).device_scene()
+    assert scene.obstructed(np.zeros((0, 6))).shape == (0,)
+    # a vertical segment through the first roof, and one that stops short of it
+    top = polygons[1]
+    c = top.points.mean(axis=0)
+    assert geom.polygons_obstruct_line_path(polygons, np.array([c + [0, 0, 5], c - [0, 0, 5]]))
+    assert not geom.polygons_obstruct_line_path(polygons, np.array([c + [0, 0, 5], c + [0, 0, 1]]))
+    # a segment that ends exactly on the roof plane is not obstructed by it (1e-8 < t < 1 - 1e-8)
+    assert not geom.polygons_obstruct_line_path([top], np.array([c + [0, 0, 5], c]))
+    groups = geom.polygons_obstruct_line_path(polygons, np.array([c + [0, 0, 5], c - [0, 0, 5]]), return_polygons=True)
+    assert len(groups) >= 1 and all(isinstance(g, list) for g in groups)
+
+
+def test_contains_point_matches_oracle(places):
+    from oracle import geometry_oracle as go
+    from raytracing_amd import geometry as geom
+
+    place = places("place_levant")
+    polys = oracle_polys(place)
+    scene = geom.scene_arrays_of(place.get_polygons_list()).device_scene()
+    rng = np.random.default_rng(3)
+    for idx in [0, 1, 2, 5, 40, 77, 150]:
+        p = polys[idx]
+        m = p.matrix()
+        lo, hi = p.points.min(axis=0), p.points.max(axis=0)
+        pts = rng.uniform(lo - 1, hi + 1, size=(200, 3))
+        # put the points in the polygon's plane, a few slightly off it
+        dist = pts @ p.normal + p.parametric[3]
+        pts = pts - np.outer(dist, p.normal)
+        pts[::10] += 1e-3 * p.normal
+        pts = np.vstack([pts, p.points, (p.points + np.roll(p.points, 1, axis=0)) / 2])
+        for check in (False, True):
+            got = scene.contains_points(idx, pts, check, 1e-8)
+            want = np.array([go.contains_point(p, q, check) for q in pts])
+            # vertices and edge midpoints sit exactly on the boundary up to rounding: both answers are noise there
+            interior = np.ones(len(pts), dtype=bool)
+            interior[-2 * len(p.points):] = False
+            np.testing.assert_array_equal(got[interior], want[interior])
+            assert got[interior].sum() > 5
+
+
+@pytest.mark.parametrize("name", ["small", "ny", "place_levant"])
+def test_visibility_matrix_matches_oracle(places, name):
+    from oracle import visibility_oracle as vo
+    from raytracing_amd import geometry as geom
+
+    place = places(name)
+    polys = oracle_polys(place)
+    got = geom.polygons_visibility_matrix(place.get_polygons_list())
+    want = vo.polygons_visibility_matrix(polys)
+    assert got.dtype == bool and got.shape == want.shape
+    assert not got.diagonal().any()
+    np.testing.assert_array_equal(got, got.T)
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, f"{len(bad)} entries differ, first {bad[:10].tolist()}"
+
+
+def test_emitter_visibility_matches_oracle(places):
+    from oracle import geometry_oracle as go
+    from oracle import visibility_oracle as vo
+    from raytracing_amd import geometry as geom
+
+    for name, tx in [("small", np.array([3.0, 38.0, 18.0])), ("place_levant", np.array([0.0, 0.0, 18.7]))]:
+        place = places(name)
+        polys = oracle_polys(place)
+        polygons = place.get_polygons_list()
+        cube_o = go.cube_by_point_and_side_length(tx, 0.2)
+        cube_p = geom.Cube.by_point_and_side_length(tx, 0.2)
+        for face_o, face_p in zip(cube_o, cube_p.polygons):
+            np.testing.assert_array_equal(face_o.points, face_p.points)
+            got = geom.polygon_visibility_vector(face_p, polygons)
+            want = vo.polygon_visibility_vector(face_o, polys)
+            np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["small", "ny", "place_levant"])
+def test_sharp_edges_match_oracle(places, name):
+    from oracle import geometry_oracle as go
+    from raytracing_amd import geometry as geom
+
+    place = places(name)
+    polys = oracle_polys(place)
+    got = list(geom.polygons_sharp_edges_iter(place.get_polygons_list()))
+    want = go.polygons_sharp_edges(polys)
+    assert [(i, j) for _, i, j in got] == [(i, j) for _, i, j in want]
+    for (eg, _, _), (ew, _, _) in zip(got, want):
+        np.testing.assert_array_equal(eg, ew)
+    assert len(got) > 10
+
+
+def test_standalone_solvers_match_oracle():
+    from oracle import geometry_oracle as go
+    from raytracing_amd import geometry as geom
+
+    cube = go.cube_by_point_and_side_length(np.zeros(3), 20.0)
+    A = np.array([0.0, 0.0, 0.0])
+    B = np.array([6.0, 6.0, 6.0])
+    rng = np.random.default_rng(5)
+    n_checked = 0
+    for k in (1, 2, 3):
+        for _ in range(40):
+            faces = rng.choice(6, size=k, replace=True)
+            if any(faces[i] == faces[i + 1] for i in range(k - 1)):
+                continue
+            planes = [cube[f].parametric for f in faces]
+            a = A + rng.uniform(-8, 8, 3)
+            b = B + rng.uniform(-3, 3, 3)
+            x_gpu, sol_gpu = geom.reflexion_points_from_origin_destination_and_planes(a, b, planes)
+            x_ref, sol_ref = go.reflexion_points_from_origin_destination_and_planes(a, b, planes)
+            assert sol_gpu.success  # inside a closed box a specular path over the planes always exists
+            if sol_ref.success and np.abs(sol_ref.fun).max() < 1e-9:
+                np.testing.assert_allclose(x_gpu, x_ref, atol=1e-6, rtol=0)  # metres
+                n_checked += 1
+    assert n_checked > 60
+    # diffraction and reflection + diffraction (the reflections aim at the edge's first endpoint)
+    edge = np.array([[10.0, 10.0, -10.0], [10.0, 10.0, 10.0]])
+    for _ in range(30):
+        a = rng.uniform(-8, 8, 3)
+        b = np.array([30.0, 12.0, 5.0]) + rng.uniform(-5, 5, 3)
+        x_gpu, sol_gpu = geom.diffraction_point_from_origin_destination_and_edge(a, b, edge)
+        x_ref, sol_ref = go.diffraction_point_from_origin_destination_and_edge(a, b, edge)
+        assert sol_gpu.success and sol_ref.success
+        np.testing.assert_allclose(x_gpu.reshape(-1), np.asarray(x_ref).reshape(-1), atol=1e-6, rtol=0)
+        planes = [cube[0].parametric]
+        x_gpu, sol_gpu = geom.reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge(a, b, planes, edge)
+        x_ref, sol_ref = go.reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge(a, b, planes, edge)
+        if sol_ref.success:
+            np.testing.assert_allclose(x_gpu, x_ref, atol=1e-6, rtol=0)
+    # no specular path: both points on the same side is fine, opposite sides is not
+    plane = [np.array([0.0, 0.0, 1.0, 0.0])]
+    _, sol = geom.reflexion_points_from_origin_destination_and_planes(np.array([0, 0, 1.0]), np.array([1.0, 0, -1.0]), plane)
+    assert not sol.success
+    _, sol = geom.reflexion_points_from_origin_destination_and_planes(np.array([0, 0, 1.0]), np.array([1.0, 0, 2.0]), plane)
+    assert sol.success
