@@ -484,3 +484,71 @@ def polygons_sharp_edges(polys, min_angle=10.0):
                 if found:
                     break
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# exact roots of the same systems (no iteration)
+# ---------------------------------------------------------------------------------------------
+# SciPy's hybr, as the reference calls it, does not always report the root of these systems even when one exists:
+# on chains whose planes meet near the path it can stall on the planes' common line and still return success, and
+# with the hand-written "jac" of geometry.py:710-713 it often reaches the Keller root to 1e-16 and returns
+# success=False.  The functions below give the roots themselves; tests use them to decide whether a candidate that
+# hybr rejected has a root of the reference's own zero function.
+
+class ExactSolution:
+    def __init__(self, x, success):
+        self.x = x
+        self.success = bool(success)
+
+
+def exact_reflexion_points(origin, destination, planes_parametric):
+    """Root of reflexion_zero_func: mirror the origin through the planes, then intersect backwards.  success=False
+    when an image segment does not cross its plane strictly inside (then the system has no root)."""
+    origin = np.asarray(origin, dtype=float).reshape(3)
+    target = np.asarray(destination, dtype=float).reshape(3)
+    planes = [np.asarray(p, dtype=float) for p in planes_parametric]
+    images = []
+    prev = origin
+    for p in planes:
+        prev = prev - 2 * (p[3] + prev @ p[:3]) * p[:3]
+        images.append(prev)
+    ok = True
+    points = [None] * len(planes)
+    for i in reversed(range(len(planes))):
+        p = planes[i]
+        direction = target - images[i]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = -(p[3] + images[i] @ p[:3]) / (direction @ p[:3])
+        if not (0.0 < t < 1.0):
+            ok = False
+        points[i] = images[i] + t * direction
+        target = points[i]
+    x = np.array(points).reshape(-1, 3)
+    return x, ExactSolution(x.reshape(-1), ok)
+
+
+def exact_diffraction_point(origin, destination, edge):
+    """Root of diffraction_zero_func in the edge frame: z = zA + (zB - zA) rhoA / (rhoA + rhoB)."""
+    A = np.asarray(origin, dtype=float).reshape(3)
+    B = np.asarray(destination, dtype=float).reshape(3)
+    matrix = projection_matrix_from_line_path(edge).T
+    pA, pB, Xe = matrix @ A, matrix @ B, matrix @ edge[0]
+    rho_a = np.hypot(Xe[0] - pA[0], Xe[1] - pA[1])
+    rho_b = np.hypot(Xe[0] - pB[0], Xe[1] - pB[1])
+    ok = rho_a + rho_b > 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = pA[2] + (pB[2] - pA[2]) * (rho_a / (rho_a + rho_b))
+    x = (np.array([Xe[0], Xe[1], z]) @ matrix).reshape(1, 3)
+    return x, ExactSolution(np.array([z]), ok)
+
+
+def exact_reflexion_points_and_diffraction_point(origin, destination, planes_parametric, edge):
+    """Root of reflexion_and_diffraction_zero_func: its reflection block sees the edge's first endpoint as its
+    destination (geometry.py:821), its last equation the last reflection point and the receiver."""
+    if len(planes_parametric) == 0:
+        return exact_diffraction_point(origin, destination, edge)
+    if edge is None:
+        return exact_reflexion_points(origin, destination, planes_parametric)
+    x, sol = exact_reflexion_points(origin, edge[0], planes_parametric)
+    d, sol_d = exact_diffraction_point(x[-1], destination, edge)
+    return np.vstack([x, d]), ExactSolution(np.concatenate([x.reshape(-1), sol_d.x]), sol.success and sol_d.success)

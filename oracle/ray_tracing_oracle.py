@@ -17,8 +17,17 @@ from . import visibility_oracle as vo
 
 class RayTracingOracle:
     def __init__(self, emitter, polys, receivers, n_screens=6, visibility_matrix=None, sharp_edges=None,
-                 precompute=True):
+                 precompute=True, solver="hybr"):
         assert 0 < n_screens <= 6
+        assert solver in ("hybr", "exact")
+        # "hybr": SciPy's root exactly as the reference calls it.  "exact": the roots of the same systems in closed
+        # form (geometry_oracle.exact_*), i.e. what a solver that always finds the root when one exists returns.
+        if solver == "hybr":
+            self.solve_reflections = go.reflexion_points_from_origin_destination_and_planes
+            self.solve_mixed = go.reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge
+        else:
+            self.solve_reflections = go.exact_reflexion_points
+            self.solve_mixed = go.exact_reflexion_points_and_diffraction_point
         self.emitter = np.asarray(emitter, dtype=float)
         self.polys = list(polys)
         self.receivers = np.asarray(receivers, dtype=float).reshape(-1, 3)
@@ -99,7 +108,7 @@ class RayTracingOracle:
             planes = [self.polys[i].parametric for i in polygons_indices]
             for r, receiver in zip(rx_ids, receivers):
                 self.counts["R" * order] += 1
-                points, sol = go.reflexion_points_from_origin_destination_and_planes(emitter, receiver, planes)
+                points, sol = self.solve_reflections(emitter, receiver, planes)
                 if not sol.success:
                     continue
                 lines = np.vstack([emitter.reshape(1, 3), points, receiver.reshape(1, 3)])
@@ -120,8 +129,7 @@ class RayTracingOracle:
             if self.emitter_visibility[i] or self.emitter_visibility[j]:
                 for r, receiver in zip(rx_ids, receivers):
                     self.counts["D"] += 1
-                    points, sol = go.reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge(
-                        emitter, receiver, [], edge)
+                    points, sol = self.solve_mixed(emitter, receiver, [], edge)
                     if not sol.success:
                         continue
                     lines = np.vstack([emitter.reshape(1, 3), points, receiver.reshape(1, 3)])
@@ -142,8 +150,7 @@ class RayTracingOracle:
             for edge_polygons, edge in edges_touching(visible):
                 for r, receiver in zip(rx_ids, receivers):
                     self.counts["R" * (order - 1) + "D"] += 1
-                    points, sol = go.reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge(
-                        emitter, receiver, planes, edge)
+                    points, sol = self.solve_mixed(emitter, receiver, planes, edge)
                     if not sol.success:
                         continue
                     lines = np.vstack([emitter.reshape(1, 3), points, receiver.reshape(1, 3)])
