@@ -255,6 +255,18 @@ class Scene:
         return dict(rx=o_rx[:k][order], group=o_group[:k][order], cand=o_cand[:k][order], points=o_pts[:k][order],
                     n_attempted=int(attempted[0]))
 
+    def solve_paths_device(self, candidates, tx, rx_ptr, n_rx, out_rx_ptr, out_group_ptr, out_cand_ptr, out_points_ptr,
+                           capacity):
+        """Device-pointer form of ``rt_solve_paths`` (receivers and outputs already in this GPU's memory).
+        Returns (n_found, n_attempted)."""
+        tx = _f64(tx).reshape(3)
+        found = np.zeros(1, dtype=np.int64)
+        attempted = np.zeros(1, dtype=np.int64)
+        _check(load().rt_solve_paths(self.handle, candidates.handle, _ptr(tx), rx_ptr, int(n_rx), out_rx_ptr,
+                                     out_group_ptr, out_cand_ptr, out_points_ptr, int(capacity), _ptr(found),
+                                     _ptr(attempted), 1), "rt_solve_paths")
+        return int(found[0]), int(attempted[0])
+
     def last_timing(self):
         ms = np.zeros(4, dtype=np.float64)
         launches = np.zeros(4, dtype=np.int64)

@@ -1,0 +1,97 @@
+"""Deterministic benchmark / test scenarios of the path-solve path (scene file, emitter, receiver lattice).
+
+The reference builds its study scenes by hand in ``electromagnetism_fun/place_utils.py`` (e.g. ``create_small_place``
+:53-73: TX (3, 38, 18), receivers (5, 15 - 4 i, 1.5)); the lattices below are synthetic inputs of the same shape for
+the larger scenes, all derived from the scene file and seed 0.
+"""
+import os
+
+import numpy as np
+
+from . import geometry as geom
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+def _footprints(place):
+    return [p.get_top_face().points[:, :2] for p in place.polyhedra]
+
+
+def _inside_any(footprints, boxes, x, y):
+    for ring, (lo, hi) in zip(footprints, boxes):
+        if lo[0] <= x <= hi[0] and lo[1] <= y <= hi[1]:
+            inside = False
+            n = len(ring)
+            for k in range(n):
+                ax, ay = ring[k - 1]
+                bx, by = ring[k]
+                cr = (bx - ax) * (y - ay) - (by - ay) * (x - ax)
+                if cr == 0 and min(ax, bx) <= x <= max(ax, bx) and min(ay, by) <= y <= max(ay, by):
+                    return True
+                if (ay > y) != (by > y) and ((cr > 0) == (by > ay)):
+                    inside = not inside
+            if inside:
+                return True
+    return False
+
+
+def lattice_receivers(place, n_side, z, inset=0.05, count=None):
+    """n_side × n_side lattice over the ground box shrunk by ``inset``, at height z; lattice points inside a
+    footprint (boundary included) are dropped and replaced by points of the same lattice shifted by half a pitch,
+    taken in row order, until ``count`` (default n_side²) receivers exist."""
+    count = n_side * n_side if count is None else count
+    lo, hi = place.get_domain()
+    cx, cy = (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2
+    hx, hy = (hi[0] - lo[0]) / 2 * (1 - inset), (hi[1] - lo[1]) / 2 * (1 - inset)
+    xs = np.linspace(cx - hx, cx + hx, n_side)
+    ys = np.linspace(cy - hy, cy + hy, n_side)
+    fps = _footprints(place)
+    boxes = [(f.min(axis=0), f.max(axis=0)) for f in fps]
+    out = []
+    px, py = (xs[1] - xs[0]) / 2 if n_side > 1 else 0.0, (ys[1] - ys[0]) / 2 if n_side > 1 else 0.0
+    for shift in range(0, 64):
+        # pass 0 is the lattice itself; pass s >= 1 is the lattice moved by (half pitch) / s
+        ox, oy = (px / shift, py / shift) if shift else (0.0, 0.0)
+        for y in ys:
+            for x in xs:
+                xx, yy = x + ox, y + oy
+                if abs(xx - cx) > hx or abs(yy - cy) > hy:
+                    continue
+                if not _inside_any(fps, boxes, xx, yy):
+                    out.append((xx, yy, z))
+                    if len(out) == count:
+                        return np.array(out, dtype=float)
+    raise RuntimeError("could not place the requested number of receivers outside the footprints")
+
+
+def emitter_outside(place, x, y, z):
+    """(x, y, z) moved in +x by 1 m steps until it is outside every footprint."""
+    fps = _footprints(place)
+    boxes = [(f.min(axis=0), f.max(axis=0)) for f in fps]
+    while _inside_any(fps, boxes, x, y):
+        x += 1.0
+    return np.array([x, y, z], dtype=float)
+
+
+def small_place(n_rx=16):
+    """Config 1: data/small.geojson, TX (3, 38, 18), receivers (5, 15 - 4 i, 1.5)."""
+    place = geom.load_place(os.path.join(DATA_DIR, "small.geojson"))
+    tx = np.array([3.0, 38.0, 18.0])
+    rx = np.array([[5.0, 15.0 - 4.0 * i, 1.5] for i in range(n_rx)])
+    return place, tx, rx
+
+
+def levant_grid(n_side=32):
+    """Config 2: data/place_levant.geojson, TX above the scene centre at 18.7 m, n_side² receivers at 1.2 m."""
+    place = geom.load_place(os.path.join(DATA_DIR, "place_levant.geojson"))
+    lo, hi = place.get_domain()
+    tx = emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 18.7)
+    return place, tx, lattice_receivers(place, n_side, 1.2)
+
+
+def lln_grid(n_side=100):
+    """Config 3: data/lln.geojson, TX above the scene centre at 30 m, n_side² receivers at 1.5 m."""
+    place = geom.load_place(os.path.join(DATA_DIR, "lln.geojson"))
+    lo, hi = place.get_domain()
+    tx = emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
+    return place, tx, lattice_receivers(place, n_side, 1.5)
