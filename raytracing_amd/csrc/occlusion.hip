@@ -15,7 +15,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__restrict__ segs, int64_t n_seg,
-                                                   const uint8_t *__restrict__ mask, uint8_t *__restrict__ out) {
+                                                   const uint8_t *__restrict__ mask, int poly_chunk,
+                                                   uint8_t *__restrict__ out) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = s < n_seg;
     d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
@@ -26,8 +27,9 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
     const d3 V = B - A;
     const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
     bool hit = false;
-    const int n = sc.n;
-    for (int p = 0; p < n; ++p) {
+    const int p_begin = blockIdx.y * poly_chunk;
+    const int p_end = p_begin + poly_chunk < sc.n ? p_begin + poly_chunk : sc.n;
+    for (int p = p_begin; p < p_end; ++p) {
         if (MASKED) {
             if (!mask[p]) continue;  // wave-uniform
         }
@@ -36,8 +38,13 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
         const double nx = pl[0], ny = pl[1], nz = pl[2], d = pl[3];
         const double den = V.x * nx + V.y * ny + V.z * nz;
         const double num = d + (A.x * nx + A.y * ny + A.z * nz);
-        const double t = -num * fast_rcp(den);
-        bool cand = active && !hit && (t > -1e-6) && (t < 1.0 + 1e-6);
+        // t = -num/den must lie in (1e-8, 1 - 1e-8); compared without dividing, with room for rounding (1e-11 is
+        // far above the error of num for coordinates of a few km and far below 1e-8 |den| unless the segment grazes
+        // the plane): a segment that merely starts or ends on the polygon is rejected here
+        const double ad = fabs(den);
+        const double sn = den < 0.0 ? num : -num;
+        bool cand = active && !hit && sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
+        const double t = sn * fast_rcp(ad);
         const double hx = A.x + t * V.x, hy = A.y + t * V.y, hz = A.z + t * V.z;
         cand = cand && hx >= bb[0] - pad && hx <= bb[3] + pad && hy >= bb[1] - pad && hy <= bb[4] + pad &&
                hz >= bb[2] - pad && hz <= bb[5] + pad;
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
             if (__all(hit || !active)) break;
         }
     }
-    if (active) out[s] = hit ? 1 : 0;
+    if (active && hit) out[s] = 1;  // out starts at zero; several polygon chunks may set the same byte
 }
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out) {
@@ -56,12 +63,22 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, con
     const int block = 256;
     const int64_t grid = (n_seg + block - 1) / block;
     if (grid > 0x7fffffffLL) RT_FAIL("rt_obstruct_segments: too many segments for one launch");
+    // few segments: split the polygon list over grid.y so the launch still fills the chip (target >= ~2048 waves)
+    const int64_t waves = grid * (block / RT_WAVE);
+    int64_t ny = waves >= 2048 ? 1 : (2048 + waves - 1) / waves;
+    const int64_t max_ny = (scene->view.n + 31) / 32;
+    ny = ny > max_ny ? max_ny : ny;
+    ny = ny < 1 ? 1 : ny;
+    int poly_chunk = (int)((scene->view.n + ny - 1) / ny);
+    poly_chunk = (poly_chunk + 31) & ~31;  // keeps the early-exit test aligned
+    ny = (scene->view.n + poly_chunk - 1) / poly_chunk;
+    RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_seg, scene->stream));
     if (d_mask)
-        hipLaunchKernelGGL(k_obstruct<true>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view, d_segs,
-                           n_seg, d_mask, d_out);
+        hipLaunchKernelGGL(k_obstruct<true>, dim3((unsigned)grid, (unsigned)ny), dim3(block), 0, scene->stream,
+                           scene->view, d_segs, n_seg, d_mask, poly_chunk, d_out);
     else
-        hipLaunchKernelGGL(k_obstruct<false>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view, d_segs,
-                           n_seg, d_mask, d_out);
+        hipLaunchKernelGGL(k_obstruct<false>, dim3((unsigned)grid, (unsigned)ny), dim3(block), 0, scene->stream,
+                           scene->view, d_segs, n_seg, d_mask, poly_chunk, d_out);
     RT_HIP(hipGetLastError());
     return 0;
 }

@@ -490,34 +490,89 @@ __device__ inline bool unfold_exact(const d3 *nrm, const double *g, const d3 *im
     return true;
 }
 
-// Reflection candidates: lane = candidate of a K-reflection group, loop = receivers of the block's tile.
+// Exact solve and checks of one (candidate, receiver) pair of a K-reflection group; appends the path if it survives.
 template <int K>
-__global__ __launch_bounds__(256) void k_reflect(SceneView sc, const int32_t *__restrict__ chains, int64_t count,
-                                                  int group, d3 tx, const double *__restrict__ rx, int64_t rx0,
-                                                  int64_t rx1, int rx_tile, Queues q) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = c < count;
+__device__ inline void reflect_exact(const SceneView &sc, const int32_t *__restrict__ chains, int64_t c, int group,
+                                     d3 tx, d3 R, int64_t r, const Queues &q) {
     int32_t poly[K];
-    d3 nrm[K], img[K];
+    d3 nrm[K], img[K], X[K];
     double g[K];
     d3 prev = tx;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        poly[i] = active ? chains[c * K + i] : 0;
+        poly[i] = chains[c * K + i];
         const double *pl = sc.planes + 4 * (size_t)poly[i];
         nrm[i] = ld3(pl);
         const double s = pl[3] + dot(prev, nrm[i]);
         img[i] = prev - (2.0 * s) * nrm[i];
-        g[i] = -s;  // d + img·n = -(d + prev·n)
+        g[i] = -s;
         prev = img[i];
     }
-    const double *bb = sc.bbox + 6 * (size_t)poly[K - 1];
+    if (!unfold_exact<K>(nrm, g, img, R, X)) return;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        if (!polygon_contains_point(sc, poly[i], X[i], true, 1e-8)) return;  // ray_tracing.py:253-255
+    // ray_tracing.py:268-272
+    d3 a = tx;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        if (!(norm3(a - X[i]) >= MIN_DISTANCE_TOL)) return;
+        a = X[i];
+    }
+    if (!(norm3(a - R) >= MIN_DISTANCE_TOL)) return;
+    int64_t ps, ss;
+    if (!reserve(q, K + 1, ps, ss)) return;
+    PathRec &rec = q.paths[ps];
+    rec.rx = (int32_t)r;
+    rec.group = group;
+    rec.cand = (int32_t)c;
+    rec.nseg = K + 1;
+    rec.seg0 = ss;
+    a = tx;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        st3(rec.pts + 3 * i, X[i]);
+        st3(q.segs + 6 * (ss + i), a);
+        st3(q.segs + 6 * (ss + i) + 3, X[i]);
+        a = X[i];
+    }
+    st3(q.segs + 6 * (ss + K), a);
+    st3(q.segs + 6 * (ss + K) + 3, R);
+}
+
+// Reflection candidates: lane = candidate of a K-reflection group, loop = receivers of the block's tile.
+// The loop only runs the padded pre-test (is the last reflection point near its polygon's box?); pairs that pass are
+// parked in a per-wave LDS queue and solved exactly 64 at a time, so the expensive part runs with all lanes busy
+// instead of once per receiver with one or two lanes.
+template <int K>
+__global__ __launch_bounds__(256) void k_reflect(SceneView sc, const int32_t *__restrict__ chains, int64_t count,
+                                                  int group, d3 tx, const double *__restrict__ rx, int64_t rx0,
+                                                  int64_t rx1, int rx_tile, Queues q) {
+    __shared__ uint32_t wave_queue[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c_base = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+    const int64_t c = c_base + lane;
+    const bool active = c < count;
+    d3 prev = tx, nk = mk3(0, 0, 1);
+    double gk = 0;
+    int32_t last = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        last = active ? chains[c * K + i] : 0;
+        const double *pl = sc.planes + 4 * (size_t)last;
+        nk = ld3(pl);
+        const double s = pl[3] + dot(prev, nk);
+        prev = prev - (2.0 * s) * nk;
+        gk = -s;  // d + img·n = -(d + prev·n)
+    }
+    const d3 im = prev;
+    const double *bb = sc.bbox + 6 * (size_t)last;
     const double b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
-    const d3 im = img[K - 1], nk = nrm[K - 1];
-    const double gk = g[K - 1];
 
     const int64_t r_begin = rx0 + (int64_t)blockIdx.y * rx_tile;
     const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
+    int qn = 0;  // wave-uniform
+    uint32_t *wq = wave_queue[wave];
     for (int64_t r = r_begin; r < r_end; ++r) {
         const d3 R = ld3(rx + 3 * r);  // wave-uniform
         const d3 dir = R - im;
@@ -526,37 +581,23 @@ __global__ __launch_bounds__(256) void k_reflect(SceneView sc, const int32_t *__
         const double hx = im.x + t * dir.x, hy = im.y + t * dir.y, hz = im.z + t * dir.z;
         const bool cand = active && t > -1e-6 && t < 1.0 + 1e-6 && hx >= b0 - pad && hx <= b3 + pad && hy >= b1 - pad &&
                           hy <= b4 + pad && hz >= b2 - pad && hz <= b5 + pad;
-        if (!cand) continue;
-        d3 X[K];
-        if (!unfold_exact<K>(nrm, g, img, R, X)) continue;
-        bool ok = true;
-        for (int i = 0; i < K && ok; ++i) ok = polygon_contains_point(sc, poly[i], X[i], true, 1e-8);  // ray_tracing.py:253-255
-        if (!ok) continue;
-        // ray_tracing.py:268-272
-        d3 a = tx;
-        for (int i = 0; i < K && ok; ++i) {
-            ok = norm3(a - X[i]) >= MIN_DISTANCE_TOL;
-            a = X[i];
+        const unsigned long long m = __ballot(cand);
+        if (m == 0) continue;
+        if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)lane << 16) | (uint32_t)(r - r_begin);
+        qn += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+            const uint32_t e = wq[qn - 64 + lane];
+            qn -= 64;
+            const int64_t rr = r_begin + (e & 0xffffu);
+            reflect_exact<K>(sc, chains, c_base + (e >> 16), group, tx, ld3(rx + 3 * rr), rr, q);
+            __builtin_amdgcn_wave_barrier();
         }
-        ok = ok && norm3(a - R) >= MIN_DISTANCE_TOL;
-        if (!ok) continue;
-        int64_t ps, ss;
-        if (!reserve(q, K + 1, ps, ss)) continue;
-        PathRec &rec = q.paths[ps];
-        rec.rx = (int32_t)r;
-        rec.group = group;
-        rec.cand = (int32_t)c;
-        rec.nseg = K + 1;
-        rec.seg0 = ss;
-        a = tx;
-        for (int i = 0; i < K; ++i) {
-            st3(rec.pts + 3 * i, X[i]);
-            st3(q.segs + 6 * (ss + i), a);
-            st3(q.segs + 6 * (ss + i) + 3, X[i]);
-            a = X[i];
-        }
-        st3(q.segs + 6 * (ss + K), a);
-        st3(q.segs + 6 * (ss + K) + 3, R);
+    }
+    if (lane < qn) {
+        const uint32_t e = wq[lane];
+        const int64_t rr = r_begin + (e & 0xffffu);
+        reflect_exact<K>(sc, chains, c_base + (e >> 16), group, tx, ld3(rx + 3 * rr), rr, q);
     }
 }
 
@@ -914,7 +955,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     const int64_t max_pairs_per_launch = 1ll << 36;
     if (total_cand > 0 && chunk * total_cand > max_pairs_per_launch) chunk = std::max<int64_t>(1, max_pairs_per_launch / total_cand);
     int64_t path_cap = std::max<int64_t>(1 << 16, std::min<int64_t>(chunk * std::max<int64_t>(total_cand, 1) / 64 + 4096, 1ll << 26));
-    const int rx_tile = 128;
+    const int rx_tile = 32;
 
     for (int64_t r0 = 0; r0 < n_rx;) {
         const int64_t r1 = std::min(n_rx, r0 + chunk);

@@ -6,12 +6,8 @@ The reference fixes the carrier by editing the module; here ``material_table(fre
 any carrier so that a frequency sweep does not reload anything, and the module-level names hold the
 12.5 GHz defaults.
 """
-from math import pi
-
 import numpy as np
-
-C_LIGHT = 299792458.0
-EPSILON_0 = 8.8541878128e-12  # scipy.constants.epsilon_0 (CODATA 2018)
+from scipy.constants import c as C_LIGHT, epsilon_0 as EPSILON_0, pi  # the reference takes them from SciPy too (:13)
 
 N_TREES = 10
 MIN_TREE_HEIGHT = 10

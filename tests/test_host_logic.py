@@ -1,0 +1,186 @@
+"""Host-side logic of the product and the C-ABI surface.  No GPU: nothing here launches a kernel."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from raytracing_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "rt_pathsolve.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", header))
+    declared -= {"rt_scene", "rt_candidates"}
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in the header but not exported"
+    assert declared == set(_lib.exported_symbols())
+    assert lib.rt_last_error() is not None
+
+
+def test_missing_gpu_fails_loudly():
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+
+    if _lib.load().rt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    place = geom.load_place(os.path.join(DATA, "small.geojson"))
+    with pytest.raises(_lib.RtError):
+        geom.polygons_visibility_matrix(place.get_polygons_list())
+    with pytest.raises(_lib.RtError):
+        geom.polygons_obstruct_line_path(place.get_polygons_list(), np.array([[0, 0, 1.0], [5, 5, 1.0]]))
+
+
+def test_product_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "raytracing_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_scene_polygon_counts_and_order():
+    from raytracing_amd import geometry as geom
+
+    expected = {"small": 31, "place_levant": 237, "place_levant_edited": 214, "ny": 92,
+                "place_saint_jean/place_saint_jean": 679}
+    for name, n in expected.items():
+        place = geom.load_place(os.path.join(DATA, name + ".geojson"))
+        polys = place.get_polygons_list()
+        assert len(polys) == n
+        assert polys[0].part == "ground" and polys[0].properties["material"] == "medium_dry_ground"
+        assert polys[1].part == "top" and polys[2].part == "side"
+        np.testing.assert_allclose(polys[0].get_normal(), [0, 0, 1])
+        # every building: top counter-clockwise with +z normal, walls [A, C, D, B] with outward horizontal normals
+        for b in place.polyhedra:
+            top = b.polygons[0]
+            assert geom.is_ccw(top.points) and top.get_normal()[2] > 0
+            c = top.points[:, :2].mean(axis=0)
+            for w in b.polygons[1:]:
+                assert abs(w.get_normal()[2]) < 1e-12 and len(w) == 4
+                assert w.points[0, 2] == w.points[3, 2] > w.points[1, 2] == w.points[2, 2] == 0
+    # deterministic: same file, same seed -> identical arrays
+    a = geom.SceneArrays(geom.load_place(os.path.join(DATA, "ny.geojson")).get_polygons_list())
+    b = geom.SceneArrays(geom.load_place(os.path.join(DATA, "ny.geojson")).get_polygons_list())
+    np.testing.assert_array_equal(a.verts, b.verts)
+    np.testing.assert_array_equal(a.planes, b.planes)
+    assert a.vert_off[-1] == len(a.verts) and a.verts.shape[1] == 3
+
+
+def test_product_polygons_match_reference_vectors():
+    from raytracing_amd import geometry as geom
+
+    g = np.load(os.path.join(GOLDEN, "polygons.npz"))
+    for i in range(int(g["n_polys"])):
+        p = geom.OrientedPolygon(g[f"poly{i}_points"])
+        np.testing.assert_array_equal(p.get_parametric(), g[f"poly{i}_parametric"])
+        np.testing.assert_array_equal(p.get_matrix(), g[f"poly{i}_matrix"])
+        np.testing.assert_array_equal(p.get_domain(), g[f"poly{i}_domain"])
+        np.testing.assert_array_equal(p.get_centroid(), g[f"poly{i}_centroid"])
+    fp = g["bld_footprint"]
+    for name, f in (("ccw", fp), ("cw", fp[::-1].copy())):
+        for keep in (True, False):
+            tag = f"bld_{name}_{int(keep)}"
+            b = geom.Building.by_polygon_and_height(f.copy(), 7.5, keep_ground=keep)
+            assert [p.part for p in b.polygons] == list(g[tag + "_parts"])
+            for j, p in enumerate(b.polygons):
+                np.testing.assert_array_equal(p.points, g[f"{tag}_{j}_points"])
+                np.testing.assert_array_equal(p.get_parametric(), g[f"{tag}_{j}_parametric"])
+    cube = geom.Cube.by_point_and_side_length(np.array([3.0, 38.0, 18.0]), 0.2)
+    np.testing.assert_array_equal(np.array([p.points for p in cube.polygons]), g["cube_points"])
+    np.testing.assert_array_equal(np.array([p.get_parametric() for p in cube.polygons]), g["cube_parametric"])
+    assert cube.polygons[0].distance_to_point(np.array([3.0, 38.0, 18.0])) == float(g["cube_distance"])
+    h = np.load(os.path.join(GOLDEN, "helpers.npz"))
+    for v, m in zip(h["frame_in"], h["frame_out"]):
+        np.testing.assert_array_equal(geom.projection_matrix_from_vector(v), m)
+    got = [geom.point_on_edge_(p, h["edge"]) for p in h["edge_points"]]
+    assert got == list(h["edge_on"])
+    for p, si, Si, sr, Sr, L in zip(h["path_in"], h["path_si"], h["path_Si"], h["path_sr"], h["path_Sr"], h["path_len"]):
+        a, b, c, d = geom.normalize_path(p)
+        np.testing.assert_array_equal(a, si)
+        np.testing.assert_array_equal(c, sr)
+        assert b == Si and d == Sr and geom.path_length(p) == L
+    from raytracing_amd import array_utils
+
+    np.testing.assert_array_equal(array_utils.sort_by_columns(h["sort_in"]), h["sort_out"])
+
+
+def test_epsg3035_projection():
+    from raytracing_amd.geometry import lonlat_to_epsg3035
+
+    # EPSG guidance note 7-2, Lambert Azimuthal Equal Area example: 50°N 5°E -> E 3962799.45, N 2999718.85
+    e, n = lonlat_to_epsg3035(5.0, 50.0)
+    assert abs(e - 3962799.45) < 0.01 and abs(n - 2999718.85) < 0.01
+    e, n = lonlat_to_epsg3035(10.0, 52.0)  # the projection origin
+    assert abs(e - 4321000.0) < 1e-6 and abs(n - 3210000.0) < 1e-6
+
+
+def test_tolerant_geojson_reader():
+    from raytracing_amd.geometry import read_geojson_tolerant
+
+    with pytest.raises(json.JSONDecodeError):
+        json.loads(open(os.path.join(DATA, "place_levant.geojson")).read())
+    data = read_geojson_tolerant(os.path.join(DATA, "place_levant.geojson"))
+    assert len(data["features"]) == 24
+
+
+def test_many_to_one_dict():
+    """Behaviour of the reference's container (container_utils.py:24-48; its tests: tests/test_container_utils.py)."""
+    from raytracing_amd.container_utils import ManyToOneDict
+
+    with open(os.path.join(GOLDEN, "misc.json")) as f:
+        want = json.load(f)["many_to_one"]
+    d = ManyToOneDict()
+    d[0, 1] = "a"
+    d[1, 2] = "b"
+    d[3, 4] = "c"
+    d[2, 3] = "d"
+    assert [list(k) for k, _ in d[1]] == want["1"]
+    assert [list(k) for k, _ in d[1, 4, ...]] == want["1,4,..."]
+    assert [list(k) for k, _ in d[9, ...]] == want["9,..."]
+    assert d[3, 4] == ((3, 4), "c")
+    e = ManyToOneDict()
+    e[1, 2] = np.array([1.0, 2.0])
+    f2 = ManyToOneDict.from_json(data=json.loads(e.to_json()))
+    assert e == f2 and not (e != f2)
+    import pickle
+
+    assert pickle.loads(pickle.dumps(dict(e))).keys() == dict(e).keys()
+
+
+def test_materials_match_reference_strings():
+    from raytracing_amd import materials_properties as mat
+
+    with open(os.path.join(GOLDEN, "misc.json")) as f:
+        want = json.load(f)
+    for building_type, props in want["set_properties"].items():
+        got = mat.set_properties(building_type)
+        assert got["material"] == props["material"]
+        for key in ("mu", "epsilon", "sigma", "roughness"):
+            assert float(got[key]) == float(props[key]), (building_type, key)
+        assert abs(complex(got["epsilon_eff"]) - complex(props["epsilon_eff"])) <= 1e-12 * abs(complex(props["epsilon_eff"]))
+    c = want["constants"]
+    assert mat.FREQUENCY == c["FREQUENCY"] and mat.LAMBDA == c["LAMBDA"] and mat.K == c["K"] and mat.Z_0 == c["Z_0"]
+    eps, rough = mat.material_table()
+    for name, (re_, im_) in want["epsilon_eff"].items():
+        assert abs(eps[mat.MATERIAL_ID[name]] - complex(re_, im_)) <= 1e-12 * abs(complex(re_, im_))
+
+
+def test_scenarios_are_deterministic_and_outside_buildings():
+    from raytracing_amd import scenarios
+
+    place, tx, rx = scenarios.levant_grid(8)
+    place2, tx2, rx2 = scenarios.levant_grid(8)
+    np.testing.assert_array_equal(rx, rx2)
+    np.testing.assert_array_equal(tx, tx2)
+    assert rx.shape == (64, 3) and (rx[:, 2] == 1.2).all()
+    fps = scenarios._footprints(place)
+    boxes = [(f.min(axis=0), f.max(axis=0)) for f in fps]
+    assert not any(scenarios._inside_any(fps, boxes, x, y) for x, y, _ in rx)
+    assert not scenarios._inside_any(fps, boxes, tx[0], tx[1])
+    place, tx, rx = scenarios.small_place(16)
+    np.testing.assert_array_equal(rx[3], [5.0, 3.0, 1.5])
