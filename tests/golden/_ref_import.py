@@ -128,3 +128,31 @@ def import_reference_geometry():
     import raytracing.geometry as geom
 
     return geom
+
+
+def import_reference_electromagnetism():
+    """The reference's field module, for the generator only.  Beyond the stand-ins above it needs names from
+    shapely.geometry / shapely.ops / geopandas at import time (never called here), `np.complex`, and its own directory
+    on sys.path (it imports `electromagnetism_utils` both ways).  Importing it changes the working directory
+    (place_utils.py:30); the caller's directory is restored."""
+    import os
+
+    geom = import_reference_geometry()
+    if not hasattr(np, "complex"):
+        np.complex = complex
+    shgeom = sys.modules["shapely.geometry"]
+    for name in ("LineString", "MultiPolygon"):
+        setattr(shgeom, name, shgeom.Polygon)
+    ops = types.ModuleType("shapely.ops")
+    ops.split = None
+    sys.modules["shapely.ops"] = ops
+    sys.modules["shapely"].ops = ops
+    em_dir = os.path.join(REFERENCE_ROOT, "electromagnetism_fun")
+    if em_dir not in sys.path:
+        sys.path.insert(0, em_dir)
+    cwd = os.getcwd()
+    try:
+        import electromagnetism_fun.electromagnetism as em
+    finally:
+        os.chdir(cwd)
+    return geom, em
