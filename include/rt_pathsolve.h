@@ -113,19 +113,49 @@ int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double *tx, const
 int rt_solve_last_timing(rt_scene *scene, double *ms, int64_t *launches, int64_t *segments_tested);
 
 /* ---- field step: my_field_computation (electromagnetism.py:648-802) --------------------------------------------------
- * Paths as produced by rt_solve_paths (host or device per on_device), n_rx receivers, n_freq carrier frequencies.
- * Per path and frequency: field[3] complex (re, im interleaved), power; per receiver and frequency: power_db.
- * status[n_paths] != 0 where the reference would raise an AssertionError (code = which assertion). */
+ * A path is described by
+ *   path_rx[i]            receiver index
+ *   path_kind[i]          number of reflections + 256 if it ends with a diffraction (0 = line of sight)
+ *   path_chain[i*RT_MAX_ORDER + k]   polygon of reflection k
+ *   path_edge_polys[i*2]  the two polygons of the diffracting edge (sharp-edge key order), path_edge_points[i*6] its
+ *                         endpoints
+ *   path_points[i*RT_MAX_ORDER*3]    interaction points
+ * i.e. what the reference's reflections / diffractions containers hold (ray_tracing.py:314, 350, 376).
+ * rt_describe_paths fills kind / chain / edge arrays from the (group, candidate) pairs rt_solve_paths returned.
+ * rt_fields: per path and frequency field[3] complex (re, im interleaved, world frame) and power (em:779-787); per
+ * path tx/rx angles in degrees [tx_el, tx_az, rx_el, rx_az] (em:566-575) and time of flight; per receiver and
+ * frequency 10 log10(sum of powers / p_in) (electromagnetism_utils.py:104-115, 180-188), -inf without paths;
+ * status[i] != 0 where the reference would raise an AssertionError: 1 incidence angle (em:294), 2 Fresnel
+ * coefficient > 1 (em:268), 3 reflected stronger than incident (em:342), 4 wedge angle (em:408), 5 beta_0 (em:413),
+ * 6 ray inside the wedge (em:425-426), 7 edge orientation (em:470), 8 diffracted stronger than incident (em:502),
+ * 9 concave geometry in the tree loss (geometry.py:916), 10 point at the antenna (electromagnetism_utils.py:151).
+ * Antennas are aligned per receiver on its shortest path, a line of sight first (em:610-644, 768-771).
+ * Up to 16 frequencies per call; the material table is ITU-R P.2040-2 as in materials_properties.py:47-109. */
 typedef struct rt_antenna_params {
-    double tx_gain, rx_gain, p_in;
-    int32_t isotropic;
-    int32_t alpha;
+    double tx_gain, rx_gain, p_in; /* materials_properties.py:32, 41 */
+    int32_t isotropic;             /* materials_properties.py:36 */
+    int32_t alpha;                 /* materials_properties.py:37 */
 } rt_antenna_params;
-int rt_fields(rt_scene *scene, rt_candidates *cand, const double *tx, const double *rx, int64_t n_rx,
-              const int32_t *path_rx, const int32_t *path_group, const int32_t *path_cand, const double *path_points,
-              int64_t n_paths, const double *freq_hz, int32_t n_freq, const rt_antenna_params *antenna,
-              double *out_field, double *out_power, double *out_angles, double *out_time, int32_t *out_status,
-              double *out_power_db, int on_device);
+/* Optional inputs of rt_fields (NULL pointer or NULL members = the defaults of my_field_computation).  They exist so that
+ * the reference's per-step entry points can be served by the same kernel: ElectromagneticField.from_path (em:156-176:
+ * antenna aimed by the caller), Reflection.my_reflect (em:314-349: incident field given, first point of the path given)
+ * and Diffraction.my_diff (em:453-507).
+ *   aim_tx / aim_rx [n_rx*3]  points the two antennas are aimed at, per receiver (both or neither)
+ *   path_origin [n_paths*3]   first point of each path instead of tx
+ *   path_e_in   [n_paths*6]   complex field (re, im interleaved) arriving at the first interaction instead of the source
+ *                             field of the emitter's antenna */
+typedef struct rt_field_options {
+    const double *aim_tx, *aim_rx, *path_origin, *path_e_in;
+} rt_field_options;
+int rt_describe_paths(rt_candidates *cand, const int32_t *path_group, const int32_t *path_cand, int64_t n_paths,
+                      int32_t *out_kind, int32_t *out_chain, int32_t *out_edge_polys, double *out_edge_points,
+                      int on_device);
+int rt_fields(rt_scene *scene, const double *tx, const double *rx, int64_t n_rx, const int32_t *path_rx,
+              const int32_t *path_kind, const int32_t *path_chain, const int32_t *path_edge_polys,
+              const double *path_edge_points, const double *path_points, int64_t n_paths, const double *freq_hz,
+              int32_t n_freq, const rt_antenna_params *antenna, const rt_field_options *options, double *out_field,
+              double *out_power, double *out_angles, double *out_time, int32_t *out_status, double *out_power_db,
+              int on_device);
 
 #ifdef __cplusplus
 }

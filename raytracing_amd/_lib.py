@@ -19,6 +19,10 @@ class RtError(RuntimeError):
     pass
 
 
+class FieldOptions(ctypes.Structure):
+    _fields_ = [("aim_tx", c_void_p), ("aim_rx", c_void_p), ("path_origin", c_void_p), ("path_e_in", c_void_p)]
+
+
 class AntennaParams(ctypes.Structure):
     _fields_ = [("tx_gain", c_double), ("rx_gain", c_double), ("p_in", c_double), ("isotropic", c_int32),
                 ("alpha", c_int32)]
@@ -47,9 +51,10 @@ _SIGNATURES = {
     "rt_solve_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_void_p, c_void_p, c_int]),
     "rt_solve_last_timing": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
-    "rt_fields": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_int]),
+    "rt_describe_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "rt_fields": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_int]),
 }
 
 
@@ -138,6 +143,19 @@ class Candidates:
                    "rt_candidates_group")
             self._groups[g] = (chains, edge_ids)
         return self._groups[g]
+
+    def describe(self, group, cand):
+        """Per-path kind / chain / edge arrays (``rt_describe_paths``) of (group, candidate) pairs."""
+        group = np.ascontiguousarray(group, dtype=np.int32)
+        cand = np.ascontiguousarray(cand, dtype=np.int32)
+        n = len(group)
+        kind = np.zeros(n, dtype=np.int32)
+        chain = np.zeros((n, RT_MAX_ORDER), dtype=np.int32)
+        edge_polys = np.zeros((n, 2), dtype=np.int32)
+        edge_points = np.zeros((n, 6), dtype=np.float64)
+        _check(load().rt_describe_paths(self.handle, _ptr(group), _ptr(cand), n, _ptr(kind), _ptr(chain),
+                                        _ptr(edge_polys), _ptr(edge_points), 0), "rt_describe_paths")
+        return kind, chain, edge_polys, edge_points
 
     @property
     def total(self):
@@ -266,6 +284,51 @@ class Scene:
                                      out_group_ptr, out_cand_ptr, out_points_ptr, int(capacity), _ptr(found),
                                      _ptr(attempted), 1), "rt_solve_paths")
         return int(found[0]), int(attempted[0])
+
+    def fields(self, tx, rx, path_rx, path_kind, path_chain, path_edge_polys, path_edge_points, path_points,
+               frequencies, tx_gain=1.0, rx_gain=1.0, p_in=1.0, isotropic=True, alpha=10, aim_tx=None, aim_rx=None,
+               path_origin=None, path_e_in=None):
+        """Host-array form of ``rt_fields``; returns dict(field complex [P,F,3], power [P,F], angles [P,4], time [P],
+        status [P], power_db [R,F])."""
+        tx = _f64(tx).reshape(3)
+        rx = _f64(rx).reshape(-1, 3)
+        p_rx = np.ascontiguousarray(path_rx, dtype=np.int32)
+        n = len(p_rx)
+        p_kind = np.ascontiguousarray(path_kind, dtype=np.int32).reshape(n)
+        p_chain = np.ascontiguousarray(path_chain, dtype=np.int32).reshape(n, RT_MAX_ORDER)
+        p_ep = np.ascontiguousarray(path_edge_polys, dtype=np.int32).reshape(n, 2)
+        p_epts = _f64(path_edge_points).reshape(n, 6)
+        p_pts = _f64(path_points).reshape(n, RT_MAX_ORDER * 3)
+        freqs = _f64(np.atleast_1d(frequencies))
+        nf = len(freqs)
+        ap = AntennaParams(float(tx_gain), float(rx_gain), float(p_in), int(bool(isotropic)), int(alpha))
+        field = np.zeros((n, nf, 6), dtype=np.float64)
+        power = np.zeros((n, nf), dtype=np.float64)
+        angles = np.zeros((n, 4), dtype=np.float64)
+        time = np.zeros(n, dtype=np.float64)
+        status = np.zeros(n, dtype=np.int32)
+        power_db = np.zeros((len(rx), nf), dtype=np.float64)
+        keep = []
+        opts = None
+        if any(a is not None for a in (aim_tx, aim_rx, path_origin, path_e_in)):
+            def dev(a, shape):
+                if a is None:
+                    return None
+                a = _f64(a).reshape(shape)
+                keep.append(a)
+                return a.ctypes.data
+            e_in = None
+            if path_e_in is not None:
+                e = np.asarray(path_e_in, dtype=np.complex128).reshape(n, 3)
+                e_in = np.stack([e.real, e.imag], axis=-1).reshape(n, 6)
+            opts = FieldOptions(dev(aim_tx, (len(rx), 3)), dev(aim_rx, (len(rx), 3)), dev(path_origin, (n, 3)),
+                                dev(e_in, (n, 6)))
+        _check(load().rt_fields(self.handle, _ptr(tx), _ptr(rx), len(rx), _ptr(p_rx), _ptr(p_kind), _ptr(p_chain),
+                                _ptr(p_ep), _ptr(p_epts), _ptr(p_pts), n, _ptr(freqs), nf, ctypes.byref(ap),
+                                ctypes.byref(opts) if opts is not None else None, _ptr(field), _ptr(power), _ptr(angles), _ptr(time), _ptr(status), _ptr(power_db), 0),
+               "rt_fields")
+        cfield = field[..., 0::2] + 1j * field[..., 1::2]
+        return dict(field=cfield, power=power, angles=angles, time=time, status=status, power_db=power_db)
 
     def last_timing(self):
         ms = np.zeros(4, dtype=np.float64)

@@ -1,6 +1,752 @@
+// Field step: received field and power of every path, per-receiver totals
+// (reference electromagnetism.py:50-148 antenna frames, :154-215 source field and tree loss, :218-349 reflection,
+//  :353-507 UTD wedge diffraction, :610-644 antenna alignment on the shortest path, :648-802 driver and power;
+//  electromagnetism_utils.py:146-188; materials_properties.py:19-109).
+//
+// One thread per path, all carrier frequencies in a loop inside the thread (the path is read once, the geometry of
+// its interactions is reused by every frequency).  The reference aborts with an AssertionError where the physics
+// checks fail; here each path carries a status code instead (0 = fine) and the caller decides.
+#include <cmath>
+#include <vector>
+
+#include "rt_candidates.h"
 #include "rt_common.h"
-extern "C" int rt_fields(rt_scene *, rt_candidates *, const double *, const double *, int64_t, const int32_t *,
-                         const int32_t *, const int32_t *, const double *, int64_t, const double *, int32_t,
-                         const rt_antenna_params *, double *, double *, double *, double *, int32_t *, double *, int) {
-    RT_FAIL("rt_fields: not built yet");
+#include "rt_fresnel.h"
+
+#define N_MATERIALS 7
+#define MAX_FREQ 16
+
+struct FreqTable {
+    int n_freq;
+    double freq[MAX_FREQ], K[MAX_FREQ], lambda[MAX_FREQ];
+    double eps_re[MAX_FREQ][N_MATERIALS], eps_im[MAX_FREQ][N_MATERIALS];
+    double roughness[N_MATERIALS];
+};
+
+struct PathArrays {
+    const int32_t *rx;          // [n] receiver index
+    const int32_t *kind;        // [n] number of reflections + 256 if the path ends with a diffraction; 0 = line of sight
+    const int32_t *chain;       // [n * RT_MAX_ORDER] polygons of the reflections
+    const int32_t *edge_polys;  // [n * 2] the two polygons of the diffracting edge (0-face first)
+    const double *edge_pts;     // [n * 6] its endpoints
+    const double *pts;          // [n * RT_MAX_ORDER * 3] interaction points
+    int64_t n;
+    // optional (null = default)
+    const double *origin;       // [n * 3] first point of the path instead of the emitter
+    const double *e_in;         // [n * 6] field arriving at the first interaction instead of the emitter's own field
+    const double *aim_tx;       // [n_rx * 3] point the emitter's antenna is aimed at, per receiver
+    const double *aim_rx;       // [n_rx * 3] point the receiver's antenna is aimed at
+};
+
+enum FieldStatus {
+    ST_OK = 0,
+    ST_INCIDENCE = 1,       // electromagnetism.py:294 incidence angle outside (0, 90 deg)
+    ST_FRESNEL = 2,         // :268
+    ST_REFLECTED_GAIN = 3,  // :342
+    ST_WEDGE = 4,           // :408
+    ST_BETA = 5,            // :413
+    ST_INSIDE_WEDGE = 6,    // :425-426
+    ST_EDGE_ORIENTATION = 7,// :470
+    ST_DIFFRACTED_GAIN = 8, // :502
+    ST_CONCAVE = 9,         // geometry.py:916
+    ST_ORIGIN = 10          // electromagnetism_utils.py:151-152
+};
+
+// ---- small complex helpers -------------------------------------------------------------------------------------
+struct cd {
+    double re, im;
+};
+__device__ inline cd cmul(cd a, cd b) { return cd{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ inline cd cscale(double s, cd a) { return cd{s * a.re, s * a.im}; }
+__device__ inline cd cadd(cd a, cd b) { return cd{a.re + b.re, a.im + b.im}; }
+__device__ inline cd cexpj(double phi) {
+    double s, c;
+    sincos(phi, &s, &c);
+    return cd{c, s};
+}
+__device__ inline cd cdivc(cd a, cd b) {
+    const double d = b.re * b.re + b.im * b.im;
+    return cd{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+__device__ inline cd csqrt_(cd z) {
+    // principal square root, as numpy.sqrt on a complex
+    const double m = hypot(z.re, z.im);
+    double re = sqrt(0.5 * (m + fabs(z.re)));
+    double im = re > 0 ? 0.5 * fabs(z.im) / re : 0.0;
+    if (z.re < 0) {
+        const double t = re;
+        re = im;
+        im = t;
+    }
+    return cd{re, z.im < 0 ? -im : im};
+}
+struct c3 {
+    cd x, y, z;
+};
+__device__ inline double cnorm3(c3 v) {
+    return sqrt(v.x.re * v.x.re + v.x.im * v.x.im + v.y.re * v.y.re + v.y.im * v.y.im + v.z.re * v.z.re + v.z.im * v.z.im);
+}
+__device__ inline c3 cvec_scale(cd s, d3 v) { return c3{cscale(v.x, s), cscale(v.y, s), cscale(v.z, s)}; }
+__device__ inline cd cdot_real(c3 a, d3 b) { return cadd(cadd(cscale(b.x, a.x), cscale(b.y, a.y)), cscale(b.z, a.z)); }
+
+__device__ inline d3 vv_normalize(d3 v) {  // electromagnetism_utils.py:173-177
+    const double n = norm3(v);
+    if (n == 0) return mk3(0, 0, 0);
+    return divs(v, n);
+}
+
+struct AntennaFrame {  // electromagnetism.py:66-89: rows of mat are the antenna axes
+    d3 pos, ax, ay, az;
+};
+__device__ inline AntennaFrame align_antenna(d3 pos, d3 target) {
+    AntennaFrame f;
+    f.pos = pos;
+    f.az = vv_normalize(target - pos);
+    f.ax = vv_normalize(cross(f.az, mk3(0, 0, 1)));
+    f.ay = vv_normalize(cross(f.ax, f.az));
+    return f;
+}
+__device__ inline d3 w2a(const AntennaFrame &f, d3 v) { return mk3(dot(v, f.ax), dot(v, f.ay), dot(v, f.az)); }
+// electromagnetism_utils.py:146-161
+__device__ inline bool to_spherical(d3 p, double &r, double &el, double &az) {
+    if (p.x == 0 && p.y == 0 && p.z == 0) return false;
+    if (p.x == 0 && p.y == 0) {
+        r = p.z;
+        el = 0;
+        az = 0;
+        return true;
+    }
+    const double hxy = sqrt(p.x * p.x + p.y * p.y);
+    r = sqrt(hxy * hxy + p.z * p.z);
+    el = atan2(hxy, p.z);
+    az = atan2(p.y, p.x);
+    return true;
+}
+__device__ inline double radiation_pattern(double theta, const rt_antenna_params &ap) {  // electromagnetism.py:211-214
+    if (ap.isotropic) return 1.0;
+    return pow(cos(theta / 2), 2.0 * ap.alpha);
+}
+
+// Source field at `q` (electromagnetism.py:156-176), world frame.
+__device__ inline c3 source_field(const AntennaFrame &tx, d3 q, double K, const rt_antenna_params &ap, int &status) {
+    const d3 pa = w2a(tx, q - tx.pos);
+    double r, theta, phi;
+    if (!to_spherical(pa, r, theta, phi)) {
+        status = ST_ORIGIN;
+        return c3{{0, 0}, {0, 0}, {0, 0}};
+    }
+    const d3 r_vv = vv_normalize(pa);
+    const d3 pol_a = w2a(tx, tx.ax);
+    const d3 v = vv_normalize(cross(cross(r_vv, pol_a), r_vv));
+    const double Z0 = 120.0 * M_PI;
+    // -j K Z0 / (4 pi) exp(-j K r) / r F(theta)
+    const double mag = K * Z0 / (4.0 * M_PI) / r * radiation_pattern(theta, ap);
+    const cd ph = cexpj(-K * r);
+    const cd amp = cmul(cd{0.0, -mag}, ph);
+    const c3 ea = cvec_scale(amp, v);
+    // back to world: E_A @ mat
+    c3 ew;
+    ew.x = cadd(cadd(cscale(tx.ax.x, ea.x), cscale(tx.ay.x, ea.y)), cscale(tx.az.x, ea.z));
+    ew.y = cadd(cadd(cscale(tx.ax.y, ea.x), cscale(tx.ay.y, ea.y)), cscale(tx.az.y, ea.z));
+    ew.z = cadd(cadd(cscale(tx.ax.z, ea.x), cscale(tx.ay.z, ea.y)), cscale(tx.az.z, ea.z));
+    return ew;
+}
+
+// One reflection (electromagnetism.py:276-304, 247-273, 236-244, 308-311, 340): E <- (E·R) e^{-jK Sr} Si/(Si+Sr)
+__device__ inline c3 reflect_field(const SceneView &sc, c3 E, d3 p0, d3 p1, d3 p2, int poly, const FreqTable &ft, int f,
+                                   int &status) {
+    const d3 v0 = p1 - p0, v1 = p2 - p1;
+    const double Si = norm3(v0), Sr = norm3(v1);
+    const d3 si = divs(v0, Si), sr = divs(v1, Sr);
+    const d3 n = ld3(sc.planes + 4 * (size_t)poly);
+    const double theta_i = acos(dot(n, mk3(-si.x, -si.y, -si.z)));
+    if (!(0 < theta_i && theta_i < M_PI / 2)) {
+        if (status == ST_OK) status = ST_INCIDENCE;
+    }
+    const int m = sc.material[poly];
+    const cd eps{ft.eps_re[f][m], ft.eps_im[f][m]};
+    const double sin_i = sin(theta_i), cosi = cos(theta_i);
+    const cd root = csqrt_(cd{eps.re - sin_i * sin_i, eps.im});
+    const cd ec = cscale(cosi, eps);
+    const cd rp = cdivc(cd{ec.re - root.re, ec.im - root.im}, cd{ec.re + root.re, ec.im + root.im});
+    const cd rs = cdivc(cd{cosi - root.re, -root.im}, cd{cosi + root.re, root.im});
+    double r_par = hypot(rp.re, rp.im), r_per = hypot(rs.re, rs.im);
+    if (!(r_par <= 1 && r_per <= 1)) {
+        if (status == ST_OK) status = ST_FRESNEL;
+    }
+    const double rough = ft.roughness[m];
+    if (rough > ft.lambda[f] / (8 * cosi)) {
+        const double chi = exp(-2 * (ft.K[f] * ft.K[f]) * (rough * rough) * cosi * cosi);
+        r_par *= chi;
+        r_per *= chi;
+    }
+    const d3 e_per = vv_normalize(cross(si, sr));
+    const d3 ei_par = vv_normalize(cross(e_per, si));
+    const d3 er_par = vv_normalize(cross(e_per, sr));
+    // E @ R with R = e_per e_per^T r_per + ei_par er_par^T r_par
+    const cd a = cscale(r_per, cdot_real(E, e_per));
+    const cd b = cscale(r_par, cdot_real(E, ei_par));
+    const cd ph = cscale(Si / (Si + Sr), cexpj(-ft.K[f] * Sr));
+    c3 out;
+    out.x = cmul(cadd(cscale(e_per.x, a), cscale(er_par.x, b)), ph);
+    out.y = cmul(cadd(cscale(e_per.y, a), cscale(er_par.y, b)), ph);
+    out.z = cmul(cadd(cscale(e_per.z, a), cscale(er_par.z, b)), ph);
+    return out;
+}
+
+// UTD transition function (electromagnetism.py:355-363)
+__device__ inline cd transition_F(double x) {
+    const double factor = sqrt(M_PI / 2);
+    const double sqrtx = sqrt(x);
+    double S, C;
+    rt_fresnel(sqrtx / factor, &S, &C);
+    // 2j sqrt(x) e^{jx} factor ((1 - j)/2 - C + jS)
+    const cd inner{factor * (0.5 - C), factor * (-0.5 + S)};
+    const cd ex = cexpj(x);
+    return cmul(cmul(cd{0.0, 2.0 * sqrtx}, ex), inner);
+}
+__device__ inline double utd_A(double x, double n, bool plus) {  // electromagnetism.py:383-393, Python round = rint
+    const double N = rint(((plus ? M_PI : -M_PI) + x) / (2 * n * M_PI));
+    const double c = cos(n * M_PI * N - x / 2);
+    return 2 * c * c;
+}
+__device__ inline double py_mod_2pi(double a) {
+    double r = fmod(a, 2 * M_PI);
+    if (r < 0) r += 2 * M_PI;
+    return r;
+}
+__device__ inline double sgn(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); }
+
+// One wedge diffraction (electromagnetism.py:395-507)
+__device__ inline c3 diffract_field(const SceneView &sc, c3 E, d3 p0, d3 p1, d3 p2, int poly0, int poly1, d3 c0, d3 c1,
+                                    double K, int &status) {
+    const d3 v0 = p1 - p0, v1 = p2 - p1;
+    const double Si = norm3(v0), Sd = norm3(v1);
+    const d3 si = divs(v0, Si), sd = divs(v1, Sd);
+    const d3 n_0 = ld3(sc.planes + 4 * (size_t)poly0), n_1 = ld3(sc.planes + 4 * (size_t)poly1);
+    d3 e = vv_normalize(c1 - c0);
+    d3 t_0 = vv_normalize(cross(n_0, e));
+    const d3 mid = mk3((c0.x + c1.x) / 2, (c0.y + c1.y) / 2, (c0.z + c1.z) / 2);
+    if (!polygon_contains_point(sc, poly0, mid + 1e-6 * t_0, true, 1e-8)) {
+        e = mk3(-e.x, -e.y, -e.z);
+        t_0 = vv_normalize(cross(n_0, e));
+    }
+    if (!polygon_contains_point(sc, poly0, mid + 1e-6 * t_0, true, 1e-8)) {
+        if (status == ST_OK) status = ST_EDGE_ORIENTATION;
+    }
+    const double alpha = M_PI - acos(dot(n_0, n_1));
+    const double n = 2 - alpha / M_PI;
+    if (!(0 < alpha && alpha < M_PI && 1 <= n && n <= 2)) {
+        if (status == ST_OK) status = ST_WEDGE;
+    }
+    const double beta_0 = acos(dot(si, e));
+    if (!(0 <= beta_0 && beta_0 <= M_PI)) {
+        if (status == ST_OK) status = ST_BETA;
+    }
+    const d3 si_t = vv_normalize(si - dot(si, e) * e);
+    const d3 sd_t = vv_normalize(sd - dot(sd, e) * e);
+    const d3 msi_t = mk3(-si_t.x, -si_t.y, -si_t.z);
+    double phi_i = M_PI - (M_PI - acos(dot(msi_t, t_0))) * sgn(dot(msi_t, n_0));
+    double phi_d = M_PI - (M_PI - acos(dot(sd_t, t_0))) * sgn(dot(sd_t, n_0));
+    phi_i = py_mod_2pi(phi_i);
+    phi_d = py_mod_2pi(phi_d);
+    if (!(0 <= phi_i && phi_i <= n * M_PI && 0 <= phi_d && phi_d <= n * M_PI)) {
+        if (status == ST_OK) status = ST_INSIDE_WEDGE;
+    }
+    // common_factor = -exp(-j pi/4) / (2 n sqrt(2 pi K) sin(beta_0))
+    const double cf_mag = 1.0 / (2 * n * sqrt(2 * M_PI * K) * sin(beta_0));
+    const cd cf = cscale(-cf_mag, cexpj(-M_PI / 4));
+    const double sb = sin(beta_0);
+    const double L = sb * sb * Si * Sd / (Si + Sd);
+    const double dm = phi_d - phi_i, dp = phi_d + phi_i;
+    const double cot1 = 1.0 / tan((M_PI + dm) * 1 / (2 * n));
+    const double cot2 = 1.0 / tan((M_PI - dm) * 1 / (2 * n));
+    const double cot3 = 1.0 / tan((M_PI + dp) * 1 / (2 * n));
+    const double cot4 = 1.0 / tan((M_PI - dp) * 1 / (2 * n));
+    const cd F1 = transition_F(K * L * utd_A(dm, n, true));
+    const cd F2 = transition_F(K * L * utd_A(dm, n, false));
+    const cd F3 = transition_F(K * L * utd_A(dp, n, true));
+    const cd F4 = transition_F(K * L * utd_A(dp, n, false));
+    const cd D1 = cmul(cscale(cot1, cf), F1), D2 = cmul(cscale(cot2, cf), F2);
+    const cd D3 = cmul(cscale(cot3, cf), F3), D4 = cmul(cscale(cot4, cf), F4);
+    const cd Dsum = cadd(cadd(D1, D2), cadd(D3, D4));  // D_per = D_par (r_per = r_par = 1, :483-487)
+    const d3 phi_i_vv = vv_normalize(cross(mk3(-e.x, -e.y, -e.z), si));
+    const d3 phi_d_vv = vv_normalize(cross(e, sd));
+    const d3 b_i = vv_normalize(cross(phi_i_vv, si));
+    const d3 b_d = vv_normalize(cross(phi_d_vv, sd));
+    // E @ D, D = b_i b_d^T (-D_per) - phi_i phi_d^T D_par
+    const cd a = cmul(cdot_real(E, b_i), cd{-Dsum.re, -Dsum.im});
+    const cd b = cmul(cdot_real(E, phi_i_vv), cd{-Dsum.re, -Dsum.im});
+    const cd ph = cscale(sqrt(Si / (Sd * (Sd + Si))), cexpj(-K * Sd));
+    c3 out;
+    out.x = cmul(cadd(cscale(b_d.x, a), cscale(phi_d_vv.x, b)), ph);
+    out.y = cmul(cadd(cscale(b_d.y, a), cscale(phi_d_vv.y, b)), ph);
+    out.z = cmul(cadd(cscale(b_d.z, a), cscale(phi_d_vv.z, b)), ph);
+    if (!(cnorm3(E) >= cnorm3(out))) {
+        if (status == ST_OK) status = ST_DIFFRACTED_GAIN;
+    }
+    return out;
+}
+
+// Points of path i: P[0] = tx, interaction points, P[np-1] = receiver.  Returns the number of points.
+__device__ inline int path_points(const PathArrays &pa, int64_t i, d3 tx, const double *rx, d3 *P) {
+    const int kind = pa.kind[i];
+    const int n_int = (kind & 255) + (kind >> 8);
+    P[0] = pa.origin ? ld3(pa.origin + 3 * (size_t)i) : tx;
+    for (int k = 0; k < n_int; ++k) P[1 + k] = ld3(pa.pts + (size_t)i * RT_MAX_ORDER * 3 + 3 * k);
+    P[1 + n_int] = ld3(rx + 3 * (size_t)pa.rx[i]);
+    return n_int + 2;
+}
+
+__device__ inline double path_key_length(const PathArrays &pa, int64_t i, d3 tx, const double *rx) {
+    // a line of sight counts as length 0: it always wins (electromagnetism.py:615-617)
+    if (pa.kind[i] == 0) return 0.0;
+    d3 P[RT_MAX_ORDER + 2];
+    const int np = path_points(pa, i, tx, rx, P);
+    double len = 0;
+    for (int k = 0; k + 1 < np; ++k) len += norm3(P[k + 1] - P[k]);
+    return len;
+}
+
+// pass 1: shortest length per receiver
+__global__ void k_best_length(PathArrays pa, d3 tx, const double *__restrict__ rx, unsigned long long *best_len) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pa.n) return;
+    atomicMin(&best_len[pa.rx[i]], (unsigned long long)__double_as_longlong(path_key_length(pa, i, tx, rx)));
+}
+// pass 2: among equally short ones (exact ties only) the first in the order the paths were given
+__global__ void k_best_index(PathArrays pa, d3 tx, const double *__restrict__ rx, const unsigned long long *best_len,
+                             unsigned long long *best_idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pa.n) return;
+    if ((unsigned long long)__double_as_longlong(path_key_length(pa, i, tx, rx)) == best_len[pa.rx[i]])
+        atomicMin(&best_idx[pa.rx[i]], (unsigned long long)i);
+}
+
+// Loss the reference applies to a line of sight that crosses geometry the emitter-visibility mask did not contain:
+// whatever it crosses is treated as tree crowns (electromagnetism.py:179-199, geometry.py:868-921).
+__device__ inline double los_tree_factor(const SceneView &sc, d3 A, d3 B, double freq, int &status) {
+    double factor = 1.0;
+    int first = -1, second = -1, count = 0;
+    auto flush = [&]() {
+        if (count == 2) {
+            // geometry.py:89-106 for both polygons, then the ITU tree loss
+            d3 dir = vv_normalize(B - A);
+            d3 pts[2];
+            const int idx[2] = {first, second};
+            for (int q = 0; q < 2; ++q) {
+                const d3 n = ld3(sc.planes + 4 * (size_t)idx[q]);
+                const d3 pp = ld3(sc.verts + 3 * ((size_t)sc.vert_off[idx[q]] + 1));
+                const d3 w = A - pp;
+                const double s = -dot(w, n) / dot(dir, n);
+                pts[q] = (w + s * dir) + pp;
+            }
+            const double d = norm3(pts[0] - pts[1]);
+            if (d > 0) {
+                const double L_db = 0.39 * pow(freq / 1e6, 0.39) * pow(d, 0.25);
+                factor *= pow(10.0, -L_db / 10);
+            }
+        } else if (count > 2) {
+            if (status == ST_OK) status = ST_CONCAVE;
+        }
+    };
+    for (int p = 0; p < sc.n; ++p) {
+        if (!polygon_cuts_segment(sc, p, A, B)) continue;
+        if (count == 0) {
+            first = p;
+            count = 1;
+        } else if (sc.building[first] == sc.building[p]) {
+            if (count == 1) second = p;
+            ++count;
+        } else {
+            flush();  // geometry.py:890-892: the group is closed and the polygon that closed it is dropped
+            count = 0;
+        }
+    }
+    flush();
+    return factor;
+}
+
+struct FieldOut {
+    double *field;    // [n_paths * n_freq * 6]
+    double *power;    // [n_paths * n_freq]
+    double *angles;   // [n_paths * 4] degrees: tx elevation, tx azimuth, rx elevation, rx azimuth
+    double *time;     // [n_paths]
+    int32_t *status;  // [n_paths]
+    double *power_sum;// [n_rx * n_freq]
+};
+
+__global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, FreqTable ft, rt_antenna_params ap, d3 tx,
+                                                 const double *__restrict__ rx,
+                                                 const unsigned long long *__restrict__ best_idx, FieldOut out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pa.n) return;
+    const int r = pa.rx[i];
+    const int kind = pa.kind[i];
+    d3 P[RT_MAX_ORDER + 2];
+    const int np = path_points(pa, i, tx, rx, P);
+    const d3 R = P[np - 1];
+    // antennas aligned on the receiver's shortest path (electromagnetism.py:768-771)
+    d3 aim_t, aim_r;
+    if (pa.aim_tx && pa.aim_rx) {
+        aim_t = ld3(pa.aim_tx + 3 * (size_t)r);
+        aim_r = ld3(pa.aim_rx + 3 * (size_t)r);
+    } else {
+        d3 Q[RT_MAX_ORDER + 2];
+        const int nq = path_points(pa, (int64_t)best_idx[r], tx, rx, Q);
+        aim_t = Q[1];
+        aim_r = Q[nq - 2];
+    }
+    const AntennaFrame txa = align_antenna(tx, aim_t);
+    const AntennaFrame rxa = align_antenna(R, aim_r);
+
+    int status = ST_OK;
+    double len = 0;
+    for (int k = 0; k + 1 < np; ++k) len += norm3(P[k + 1] - P[k]);
+    out.time[i] = len / 299792458.0;
+    double rr, tx_el = 0, tx_az = 0, rx_el = 0, rx_az = 0;
+    if (!to_spherical(w2a(txa, P[1] - tx), rr, tx_el, tx_az)) status = ST_ORIGIN;
+    if (!to_spherical(w2a(rxa, P[np - 2] - R), rr, rx_el, rx_az)) status = ST_ORIGIN;
+    const double deg = 180.0 / M_PI;
+    out.angles[4 * i + 0] = tx_el * deg;
+    out.angles[4 * i + 1] = tx_az * deg;
+    out.angles[4 * i + 2] = rx_el * deg;
+    out.angles[4 * i + 3] = rx_az * deg;
+
+    const int n_refl = kind & 255;
+    const bool has_edge = (kind >> 8) != 0;
+    const int32_t *chain = pa.chain + (size_t)i * RT_MAX_ORDER;
+
+    for (int f = 0; f < ft.n_freq; ++f) {
+        const double K = ft.K[f];
+        int st = status;
+        c3 E;
+        if (pa.e_in) {
+            const double *q = pa.e_in + 6 * (size_t)i;
+            E = c3{{q[0], q[1]}, {q[2], q[3]}, {q[4], q[5]}};
+        } else {
+            E = source_field(txa, P[1], K, ap, st);
+        }
+        const double e0 = cnorm3(E);
+        if (kind == 0 && !pa.e_in) {
+            const double fac = los_tree_factor(sc, P[0], P[1], ft.freq[f], st);
+            E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
+        }
+        for (int k = 0; k < n_refl; ++k) {
+            E = reflect_field(sc, E, P[k], P[k + 1], P[k + 2], chain[k], ft, f, st);
+            if (!(e0 >= cnorm3(E)) && st == ST_OK) st = ST_REFLECTED_GAIN;  // electromagnetism.py:342 (E_i is the first field)
+        }
+        if (has_edge) {
+            const d3 c0 = ld3(pa.edge_pts + 6 * (size_t)i), c1 = ld3(pa.edge_pts + 6 * (size_t)i + 3);
+            E = diffract_field(sc, E, P[np - 3], P[np - 2], P[np - 1], pa.edge_polys[2 * i], pa.edge_polys[2 * i + 1], c0,
+                               c1, K, st);
+        }
+        // received power (electromagnetism.py:779-787)
+        const double Ae = (ft.lambda[f] * ft.lambda[f] / (4 * M_PI)) * ap.rx_gain * radiation_pattern(rx_el, ap);
+        c3 Ea;
+        Ea.x = cdot_real(E, rxa.ax);
+        Ea.y = cdot_real(E, rxa.ay);
+        Ea.z = cdot_real(E, rxa.az);
+        const double en = cnorm3(Ea);
+        const d3 pol_a = w2a(rxa, rxa.ax);
+        cd pe{0, 0};
+        if (en != 0) pe = cscale(1.0 / en, cdot_real(Ea, pol_a));
+        const double pol_eff = pe.re * pe.re + pe.im * pe.im;
+        const double re2 = Ea.x.re * Ea.x.re + Ea.y.re * Ea.y.re + Ea.z.re * Ea.z.re;
+        const double Z0 = 120.0 * M_PI;
+        double power = 1 / (2 * Z0) * Ae * re2;
+        power = power * pol_eff * ap.tx_gain;
+        double *fo = out.field + ((size_t)i * ft.n_freq + f) * 6;
+        fo[0] = E.x.re; fo[1] = E.x.im; fo[2] = E.y.re; fo[3] = E.y.im; fo[4] = E.z.re; fo[5] = E.z.im;
+        out.power[(size_t)i * ft.n_freq + f] = power;
+        atomicAdd(&out.power_sum[(size_t)r * ft.n_freq + f], power);
+        if (f == 0 || (status == ST_OK && st != ST_OK)) status = st;
+    }
+    out.status[i] = status;
+}
+
+__global__ void k_power_db(const double *__restrict__ sum, int64_t n, double p_in, double *__restrict__ db) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double P = sum[i];
+    db[i] = P != 0 ? 10 * log10(P / p_in) : -INFINITY;  // electromagnetism_utils.py:180-188
+}
+
+// ITU-R P.2040-2 table (materials_properties.py:47-109); index = material id used by the scene
+static void fill_materials(FreqTable &ft, int f, double freq) {
+    const double c0 = 299792458.0, eps0 = 8.8541878188e-12;
+    const double g = freq / 1e9;
+    const double eps[N_MATERIALS] = {1, 5.24, 3.91, 1.99, 6.31, 1, 15 * std::pow(g, -0.1)};
+    const double sigma[N_MATERIALS] = {0, 0.0462 * std::pow(g, 0.7822), 0.0238 * std::pow(g, 0.16),
+                                       0.0047 * std::pow(g, 1.0718), 0.0036 * std::pow(g, 1.3394), 1e7,
+                                       0.035 * std::pow(g, 1.63)};
+    ft.freq[f] = freq;
+    ft.lambda[f] = c0 / freq;
+    ft.K[f] = 2 * M_PI / ft.lambda[f];
+    for (int m = 0; m < N_MATERIALS; ++m) {
+        ft.eps_re[f][m] = eps[m];
+        ft.eps_im[f][m] = -sigma[m] / (eps0 * 2 * M_PI * freq);
+    }
+}
+
+// Per-path description arrays from the (group, candidate) pairs rt_solve_paths returns.
+__global__ void k_describe(const int32_t *__restrict__ group, const int32_t *__restrict__ cand, int64_t n, int n_groups,
+                           const int *__restrict__ g_refl, const int *__restrict__ g_edge,
+                           const int32_t *const *__restrict__ g_chains, const int32_t *const *__restrict__ g_edge_ids,
+                           const int32_t *__restrict__ edge_pairs, const double *__restrict__ edges,
+                           int32_t *__restrict__ kind, int32_t *__restrict__ chain, int32_t *__restrict__ edge_polys,
+                           double *__restrict__ edge_pts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = group[i];
+    for (int k = 0; k < RT_MAX_ORDER; ++k) chain[i * RT_MAX_ORDER + k] = -1;
+    edge_polys[2 * i] = edge_polys[2 * i + 1] = -1;
+    for (int k = 0; k < 6; ++k) edge_pts[6 * i + k] = 0.0;
+    if (g < 0 || g >= n_groups) {
+        kind[i] = 0;
+        return;
+    }
+    const int nr = g_refl[g];
+    kind[i] = nr + (g_edge[g] ? 256 : 0);
+    for (int k = 0; k < nr; ++k) chain[i * RT_MAX_ORDER + k] = g_chains[g][(size_t)cand[i] * nr + k];
+    if (g_edge[g]) {
+        const int e = g_edge_ids[g][cand[i]];
+        edge_polys[2 * i] = edge_pairs[2 * e];
+        edge_polys[2 * i + 1] = edge_pairs[2 * e + 1];
+        for (int k = 0; k < 6; ++k) edge_pts[6 * i + k] = edges[6 * (size_t)e + k];
+    }
+}
+
+extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group, const int32_t *path_cand,
+                                 int64_t n_paths, int32_t *out_kind, int32_t *out_chain, int32_t *out_edge_polys,
+                                 double *out_edge_points, int on_device) {
+    if (!cand) RT_FAIL("rt_describe_paths: null handle");
+    if (n_paths < 0) RT_FAIL("rt_describe_paths: negative size");
+    if (n_paths == 0) return 0;
+    if (!path_group || !path_cand || !out_kind || !out_chain || !out_edge_polys || !out_edge_points)
+        RT_FAIL("rt_describe_paths: null array");
+    rt_scene *scene = cand->scene;
+    RT_HIP(hipSetDevice(scene->device));
+    hipStream_t st = scene->stream;
+    const int ng = (int)cand->groups.size();
+    std::vector<int> h_refl(ng ? ng : 1), h_edge(ng ? ng : 1);
+    std::vector<const int32_t *> h_chains(ng ? ng : 1), h_eids(ng ? ng : 1);
+    for (int g = 0; g < ng; ++g) {
+        h_refl[g] = cand->groups[g].n_refl;
+        h_edge[g] = cand->groups[g].has_edge;
+        h_chains[g] = cand->groups[g].chains;
+        h_eids[g] = cand->groups[g].edge_ids;
+    }
+    if (!on_device) {
+        for (int64_t i = 0; i < n_paths; ++i) {
+            const int g = path_group[i];
+            if (g >= ng) RT_FAIL("rt_describe_paths: group out of range");
+            if (g >= 0 && (path_cand[i] < 0 || path_cand[i] >= cand->groups[g].count))
+                RT_FAIL("rt_describe_paths: candidate index out of range");
+        }
+    }
+    std::vector<void *> temps;
+    auto dalloc = [&](size_t bytes) -> void * {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
+        temps.push_back(d);
+        return d;
+    };
+    int rc = -1;
+    do {
+        int *d_refl = (int *)dalloc(sizeof(int) * h_refl.size()), *d_edge = (int *)dalloc(sizeof(int) * h_edge.size());
+        const int32_t **d_chains = (const int32_t **)dalloc(sizeof(void *) * h_chains.size());
+        const int32_t **d_eids = (const int32_t **)dalloc(sizeof(void *) * h_eids.size());
+        if (!d_refl || !d_edge || !d_chains || !d_eids) break;
+        if (hipMemcpyAsync(d_refl, h_refl.data(), sizeof(int) * h_refl.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (hipMemcpyAsync(d_edge, h_edge.data(), sizeof(int) * h_edge.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (hipMemcpyAsync(d_chains, h_chains.data(), sizeof(void *) * h_chains.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (hipMemcpyAsync(d_eids, h_eids.data(), sizeof(void *) * h_eids.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
+        const int32_t *d_group = path_group, *d_cand = path_cand;
+        int32_t *d_kind = out_kind, *d_chain = out_chain, *d_ep = out_edge_polys;
+        double *d_pts = out_edge_points;
+        const size_t n = (size_t)n_paths;
+        if (!on_device) {
+            int32_t *a = (int32_t *)dalloc(4 * n), *b = (int32_t *)dalloc(4 * n);
+            d_kind = (int32_t *)dalloc(4 * n);
+            d_chain = (int32_t *)dalloc(4 * n * RT_MAX_ORDER);
+            d_ep = (int32_t *)dalloc(8 * n);
+            d_pts = (double *)dalloc(48 * n);
+            if (!a || !b || !d_kind || !d_chain || !d_ep || !d_pts) break;
+            if (hipMemcpyAsync(a, path_group, 4 * n, hipMemcpyHostToDevice, st) != hipSuccess) break;
+            if (hipMemcpyAsync(b, path_cand, 4 * n, hipMemcpyHostToDevice, st) != hipSuccess) break;
+            d_group = a;
+            d_cand = b;
+        }
+        hipLaunchKernelGGL(k_describe, dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, st, d_group, d_cand, n_paths,
+                           ng, d_refl, d_edge, d_chains, d_eids, cand->d_edge_pairs, cand->d_edges, d_kind, d_chain, d_ep,
+                           d_pts);
+        if (hipGetLastError() != hipSuccess) break;
+        if (!on_device) {
+            if (hipMemcpyAsync(out_kind, d_kind, 4 * n, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+            if (hipMemcpyAsync(out_chain, d_chain, 4 * n * RT_MAX_ORDER, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+            if (hipMemcpyAsync(out_edge_polys, d_ep, 8 * n, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+            if (hipMemcpyAsync(out_edge_points, d_pts, 48 * n, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    for (void *p : temps) (void)hipFree(p);
+    if (rc) rt_set_error(std::string("rt_describe_paths: ") + hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, int64_t n_rx, const int32_t *path_rx,
+                         const int32_t *path_kind, const int32_t *path_chain, const int32_t *path_edge_polys,
+                         const double *path_edge_points, const double *path_points, int64_t n_paths,
+                         const double *freq_hz, int32_t n_freq, const rt_antenna_params *antenna,
+                         const rt_field_options *options, double *out_field, double *out_power, double *out_angles,
+                         double *out_time, int32_t *out_status, double *out_power_db, int on_device) {
+    if (!scene || !tx || !freq_hz || !antenna) RT_FAIL("rt_fields: null argument");
+    if (options && ((options->aim_tx == nullptr) != (options->aim_rx == nullptr)))
+        RT_FAIL("rt_fields: aim_tx and aim_rx go together");
+    if (n_freq < 1 || n_freq > MAX_FREQ) RT_FAIL("rt_fields: between 1 and 16 frequencies per call");
+    if (n_rx < 0 || n_paths < 0) RT_FAIL("rt_fields: negative size");
+    if (n_rx > 0 && (!rx || !out_power_db)) RT_FAIL("rt_fields: null receiver arrays");
+    if (n_paths > 0 && (!path_rx || !path_kind || !path_chain || !path_edge_polys || !path_edge_points || !path_points ||
+                        !out_field || !out_power || !out_angles || !out_time || !out_status))
+        RT_FAIL("rt_fields: null path arrays");
+    for (int f = 0; f < n_freq; ++f)
+        if (!(freq_hz[f] > 0)) RT_FAIL("rt_fields: frequencies must be positive");
+    if (n_rx == 0) return 0;
+    if (!on_device) {
+        // operand shapes are checked before a kernel dereferences them
+        const int n_poly = scene->view.n;
+        for (int64_t i = 0; i < n_paths; ++i) {
+            const int nr = path_kind[i] & 255, he = path_kind[i] >> 8;
+            if (path_rx[i] < 0 || path_rx[i] >= n_rx) RT_FAIL("rt_fields: receiver index out of range");
+            if (path_kind[i] < 0 || he > 1 || nr + he > RT_MAX_ORDER) RT_FAIL("rt_fields: bad path kind");
+            for (int k = 0; k < nr; ++k)
+                if (path_chain[i * RT_MAX_ORDER + k] < 0 || path_chain[i * RT_MAX_ORDER + k] >= n_poly)
+                    RT_FAIL("rt_fields: polygon index out of range");
+            if (he && (path_edge_polys[2 * i] < 0 || path_edge_polys[2 * i] >= n_poly || path_edge_polys[2 * i + 1] < 0 ||
+                       path_edge_polys[2 * i + 1] >= n_poly))
+                RT_FAIL("rt_fields: edge polygon index out of range");
+        }
+    }
+    RT_HIP(hipSetDevice(scene->device));
+    hipStream_t st = scene->stream;
+    FreqTable ft{};
+    ft.n_freq = n_freq;
+    for (int f = 0; f < n_freq; ++f) fill_materials(ft, f, freq_hz[f]);
+    const double rough[N_MATERIALS] = {NAN, 1e-4, 1e-3, 1e-4, 1e-6, 1e-6, 1e-2};
+    for (int m = 0; m < N_MATERIALS; ++m) ft.roughness[m] = rough[m];
+
+    std::vector<void *> temps;
+    auto dalloc = [&](size_t bytes) -> void * {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
+        temps.push_back(d);
+        return d;
+    };
+    auto cleanup = [&]() {
+        for (void *p : temps) (void)hipFree(p);
+    };
+#define F_HIP(call)                                                                                 \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            rt_set_error(std::string("rt_fields: ") + #call + ": " + hipGetErrorString(e_));        \
+            cleanup();                                                                              \
+            return -1;                                                                              \
+        }                                                                                           \
+    } while (0)
+#define F_PTR(p)                                                \
+    if (!(p)) {                                                 \
+        rt_set_error("rt_fields: out of device memory");        \
+        cleanup();                                              \
+        return -1;                                              \
+    }
+
+    PathArrays pa{};
+    pa.n = n_paths;
+    const double *d_rx = rx;
+    FieldOut fo{};
+    double *d_db = out_power_db;
+    const size_t np_ = (size_t)n_paths, nf = (size_t)n_freq;
+    if (on_device) {
+        pa.rx = path_rx; pa.kind = path_kind; pa.chain = path_chain; pa.edge_polys = path_edge_polys;
+        pa.edge_pts = path_edge_points; pa.pts = path_points;
+        fo.field = out_field; fo.power = out_power; fo.angles = out_angles; fo.time = out_time; fo.status = out_status;
+    } else {
+        int32_t *a = (int32_t *)dalloc(4 * np_), *b = (int32_t *)dalloc(4 * np_), *c = (int32_t *)dalloc(4 * np_ * RT_MAX_ORDER),
+                *d = (int32_t *)dalloc(8 * np_);
+        double *e = (double *)dalloc(48 * np_), *p = (double *)dalloc(sizeof(double) * RT_MAX_ORDER * 3 * np_);
+        double *r = (double *)dalloc(sizeof(double) * 3 * n_rx);
+        F_PTR(a); F_PTR(b); F_PTR(c); F_PTR(d); F_PTR(e); F_PTR(p); F_PTR(r);
+        if (n_paths) {
+            F_HIP(hipMemcpyAsync(a, path_rx, 4 * np_, hipMemcpyHostToDevice, st));
+            F_HIP(hipMemcpyAsync(b, path_kind, 4 * np_, hipMemcpyHostToDevice, st));
+            F_HIP(hipMemcpyAsync(c, path_chain, 4 * np_ * RT_MAX_ORDER, hipMemcpyHostToDevice, st));
+            F_HIP(hipMemcpyAsync(d, path_edge_polys, 8 * np_, hipMemcpyHostToDevice, st));
+            F_HIP(hipMemcpyAsync(e, path_edge_points, 48 * np_, hipMemcpyHostToDevice, st));
+            F_HIP(hipMemcpyAsync(p, path_points, sizeof(double) * RT_MAX_ORDER * 3 * np_, hipMemcpyHostToDevice, st));
+        }
+        F_HIP(hipMemcpyAsync(r, rx, sizeof(double) * 3 * n_rx, hipMemcpyHostToDevice, st));
+        pa.rx = a; pa.kind = b; pa.chain = c; pa.edge_polys = d; pa.edge_pts = e; pa.pts = p;
+        d_rx = r;
+        fo.field = (double *)dalloc(sizeof(double) * 6 * np_ * nf);
+        fo.power = (double *)dalloc(sizeof(double) * np_ * nf);
+        fo.angles = (double *)dalloc(sizeof(double) * 4 * np_);
+        fo.time = (double *)dalloc(sizeof(double) * np_);
+        fo.status = (int32_t *)dalloc(sizeof(int32_t) * np_);
+        d_db = (double *)dalloc(sizeof(double) * n_rx * nf);
+        F_PTR(fo.field); F_PTR(fo.power); F_PTR(fo.angles); F_PTR(fo.time); F_PTR(fo.status); F_PTR(d_db);
+    }
+    if (options) {
+        const double *opt_src[4] = {options->path_origin, options->path_e_in, options->aim_tx, options->aim_rx};
+        const size_t opt_bytes[4] = {24 * np_, 48 * np_, 24 * (size_t)n_rx, 24 * (size_t)n_rx};
+        const double *opt_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < 4; ++k) {
+            if (!opt_src[k]) continue;
+            if (on_device) {
+                opt_dev[k] = opt_src[k];
+            } else {
+                double *d = (double *)dalloc(opt_bytes[k]);
+                F_PTR(d);
+                if (opt_bytes[k]) F_HIP(hipMemcpyAsync(d, opt_src[k], opt_bytes[k], hipMemcpyHostToDevice, st));
+                opt_dev[k] = d;
+            }
+        }
+        pa.origin = opt_dev[0];
+        pa.e_in = opt_dev[1];
+        pa.aim_tx = opt_dev[2];
+        pa.aim_rx = opt_dev[3];
+    }
+    fo.power_sum = (double *)dalloc(sizeof(double) * n_rx * nf);
+    unsigned long long *best_len = (unsigned long long *)dalloc(sizeof(unsigned long long) * n_rx);
+    unsigned long long *best_idx = (unsigned long long *)dalloc(sizeof(unsigned long long) * n_rx);
+    F_PTR(fo.power_sum); F_PTR(best_len); F_PTR(best_idx);
+    F_HIP(hipMemsetAsync(fo.power_sum, 0, sizeof(double) * n_rx * nf, st));
+    F_HIP(hipMemsetAsync(best_len, 0xff, sizeof(unsigned long long) * n_rx, st));
+    F_HIP(hipMemsetAsync(best_idx, 0xff, sizeof(unsigned long long) * n_rx, st));
+    const d3 TX = ld3(tx);
+    if (n_paths > 0) {
+        const unsigned grid = (unsigned)((n_paths + 255) / 256);
+        hipLaunchKernelGGL(k_best_length, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len);
+        hipLaunchKernelGGL(k_best_index, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len, best_idx);
+        hipLaunchKernelGGL(k_fields, dim3((unsigned)((n_paths + 127) / 128)), dim3(128), 0, st, scene->view, pa, ft, *antenna,
+                           TX, d_rx, best_idx, fo);
+    }
+    hipLaunchKernelGGL(k_power_db, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, fo.power_sum,
+                       (int64_t)(n_rx * nf), antenna->p_in, d_db);
+    F_HIP(hipGetLastError());
+    if (!on_device) {
+        if (n_paths) {
+            F_HIP(hipMemcpyAsync(out_field, fo.field, sizeof(double) * 6 * np_ * nf, hipMemcpyDeviceToHost, st));
+            F_HIP(hipMemcpyAsync(out_power, fo.power, sizeof(double) * np_ * nf, hipMemcpyDeviceToHost, st));
+            F_HIP(hipMemcpyAsync(out_angles, fo.angles, sizeof(double) * 4 * np_, hipMemcpyDeviceToHost, st));
+            F_HIP(hipMemcpyAsync(out_time, fo.time, sizeof(double) * np_, hipMemcpyDeviceToHost, st));
+            F_HIP(hipMemcpyAsync(out_status, fo.status, sizeof(int32_t) * np_, hipMemcpyDeviceToHost, st));
+        }
+        F_HIP(hipMemcpyAsync(out_power_db, d_db, sizeof(double) * n_rx * nf, hipMemcpyDeviceToHost, st));
+    }
+    F_HIP(hipStreamSynchronize(st));
+    cleanup();
+    return 0;
 }

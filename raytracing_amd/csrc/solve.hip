@@ -21,30 +21,12 @@
 #include <algorithm>
 #include <cstring>
 
+#include "rt_candidates.h"
 #include "rt_common.h"
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out);
 
 #define MIN_DISTANCE_TOL 0.005 /* ray_tracing.py:252 */
-
-struct CandGroup {
-    int n_refl = 0;
-    int has_edge = 0;
-    int64_t count = 0;
-    int32_t *chains = nullptr;    // device [count * n_refl]
-    int32_t *edge_ids = nullptr;  // device [count]
-};
-
-struct rt_candidates {
-    rt_scene *scene = nullptr;
-    int max_order = 0;
-    std::vector<CandGroup> groups;
-    int64_t n_edges = 0;
-    double *d_edges = nullptr;    // [n_edges * 6]
-    int32_t *d_edge_pairs = nullptr;
-    uint8_t *d_ev = nullptr;      // [n]
-    std::vector<void *> allocations;
-};
 
 struct PathRec {
     int32_t rx, group, cand, nseg;
