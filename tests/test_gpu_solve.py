@@ -118,3 +118,25 @@ def test_solve_quirks(places):
         problem.solve(max_order=1, receivers_indexs=[7])
     with pytest.raises(AssertionError):
         RayTracingProblem(tx.reshape(1, 3), place, n_screens=7)
+
+
+def test_multithread_solve_place_single_gpu(tmp_path, monkeypatch):
+    """The reference's coverage-map entry point end to end on one GPU: files written, table consistent."""
+    from raytracing_amd import electromagnetism_utils as emu
+    from raytracing_amd import geometry as geom
+    from raytracing_amd.multithread_solve import multithread_solve_place
+    from raytracing_amd.ray_tracing import RayTracingProblem
+
+    monkeypatch.setenv("RAYTRACING_AMD_RESULTS", str(tmp_path))
+    place = geom.load_place("data/small.geojson")
+    tx, rx = small_tx_rx(6)
+    place.add_set_of_points(rx)
+    em_path, rays_path = multithread_solve_place(place, tx.reshape(1, 3), "small", order=2)
+    df = emu.load_df(em_path)
+    assert set(df["rx_id"]) == set(range(6)) and (df["path_type"] == "LOS").sum() == 6
+    db = emu.get_power_db_each_receiver(df)
+    assert np.isfinite(db).all() and (db < 0).all()
+    back = RayTracingProblem.from_json(rays_path)
+    direct = RayTracingProblem(tx.reshape(1, 3), place)
+    direct.solve(max_order=2)
+    assert back.path_set() == direct.path_set()
