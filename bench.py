@@ -109,8 +109,8 @@ def main():
     vis = scene.visibility_matrix(False)
     cube = geom.Cube.by_point_and_side_length(tx, 0.2)
     ev = np.zeros(len(polygons), dtype=bool)
-    for screen in cube.polygons:
-        ev |= scene.face_visibility(screen.points, screen.get_parametric(), -1, False)
+    for v in scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False):
+        ev |= v
     cand = scene.enumerate(vis, ev, np.zeros((0, 2), np.int32), np.zeros((0, 2, 3)), 2, with_diffraction=False)
     precompute_s = time.perf_counter() - t_pre
 

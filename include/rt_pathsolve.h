@@ -60,7 +60,15 @@ int rt_contains_points(rt_scene *scene, int32_t polygon, const double *points, i
  * rt_visibility_matrix writes the symmetrised N*N matrix (geometry.py:1046). */
 int rt_face_visibility(rt_scene *scene, const double *face_verts, int32_t n_face_verts, const double *face_normal,
                        int32_t self_index, int strict, uint8_t *out);
+/* several faces in one launch (the six screens of the emitter's cube): face_off[n_faces+1] offsets into face_verts,
+ * face_normals[n_faces*3], self_index[n_faces] or NULL (= all -1), out[n_faces*N]. */
+int rt_faces_visibility(rt_scene *scene, int32_t n_faces, const int32_t *face_off, const double *face_verts,
+                        const double *face_normals, const int32_t *self_index, int strict, uint8_t *out);
 int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_device);
+/* Work counters of the visibility painter accumulated since the last call, then zeroed (profiling aid, no reference
+ * counterpart): candidates, listed canvas polygons, canvas edges entering a candidate, edge cuts, candidates settled by
+ * the interior-sample shortcut, polygons shown visible, canvas-edge examinations, edge examinations. out8[8]. */
+int rt_debug_visibility_stats(unsigned long long *out8);
 
 /* ---- sharp edges: polygons_sharp_edges_iter (geometry.py:482-565) -----------------------------------------------
  * Writes up to `capacity` edges in ascending (i, j) order: pairs[2*e] = (i, j), edges[6*e] = the shared edge with its

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "rt_segment_hits": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rt_contains_points": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int, c_double, c_void_p, c_int]),
     "rt_face_visibility": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_void_p]),
+    "rt_faces_visibility": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rt_debug_visibility_stats": (c_int, [c_void_p]),
     "rt_visibility_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "rt_sharp_edges": (c_int, [c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
     "rt_solve_reflections": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
@@ -227,6 +229,19 @@ class Scene:
         out = np.zeros(self.n, dtype=np.uint8)
         _check(load().rt_face_visibility(self.handle, _ptr(pts), len(pts), _ptr(normal), int(self_index),
                                          int(bool(strict)), _ptr(out)), "rt_face_visibility")
+        return out.astype(bool)
+
+    def faces_visibility(self, faces, strict=False):
+        """Visibility vectors of several faces in one launch; ``faces`` = list of (points (V,3), parametric (4,),
+        self_index)."""
+        off = np.zeros(len(faces) + 1, dtype=np.int32)
+        np.cumsum([len(f[0]) for f in faces], out=off[1:])
+        verts = _f64(np.concatenate([np.asarray(f[0], dtype=float).reshape(-1, 3) for f in faces]))
+        normals = _f64(np.array([np.asarray(f[1], dtype=float)[:3] for f in faces]))
+        selfs = np.array([int(f[2]) for f in faces], dtype=np.int32)
+        out = np.zeros((len(faces), self.n), dtype=np.uint8)
+        _check(load().rt_faces_visibility(self.handle, len(faces), _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs),
+                                          int(bool(strict)), _ptr(out)), "rt_faces_visibility")
         return out.astype(bool)
 
     def visibility_matrix(self, strict=False):

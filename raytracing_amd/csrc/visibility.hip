@@ -7,9 +7,9 @@
 // when its (azimuth, polar) polygon is a valid ring and some part of it is not covered by the polygons painted before
 // it.  Last, B must face A: some vertex p of A has normalize(p - centre(B))·n_B > 1e-4.
 //
-// "Painted before" is a pairwise relation on the sort keys, so no sort and no sequential canvas are needed: every
-// (A, B) pair is decided independently against the set {C valid, C before B, box(C) meets box(B)}.  A polygon hidden
-// by the canvas lies inside it, so adding it to the canvas changes nothing: the set may contain hidden polygons.
+// The canvas a polygon is tested against holds the polygons that passed before it; a polygon hidden by the canvas
+// lies inside it, so leaving it out changes nothing and keeps the canvas small.  Faces are independent: one wave
+// paints one face, walking its candidates in sorted order.
 //
 // Coverage is decided exactly with witness points.  If part of B is uncovered, the uncovered region is bounded by
 // pieces of B's edges (region on B's inner side) and pieces of the C's edges (region on that C's outer side).  Every
@@ -17,9 +17,10 @@
 // nothing changes, so one point next to the middle of each piece (DELTA off the edge, on the side named above)
 // decides it: B is visible iff some such point is inside B and outside every C.
 //
-// Kernels: k_vis_prepare (one thread per (face, polygon): mapping, keys, ring validity) and k_vis_paint (persistent
-// waves pulling (face, polygon) pairs from a counter; within a pair, lanes work on different polygons / pieces while
-// the polygon being tested against is wave-uniform and comes through scalar loads).
+// Kernels: k_vis_prepare (one thread per (face, polygon): mapping, keys, ring validity), k_vis_sort (one workgroup per
+// face: bitonic sort of its candidates by the painter's key) and k_vis_paint (persistent waves pulling faces from a
+// counter; inside a face, lanes work on different canvas polygons / edge pieces while the polygon being tested against
+// is wave-uniform).
 #include <algorithm>
 #include <cstring>
 
@@ -30,6 +31,10 @@
 #define VIS_DELTA 2.5e-10    /* witness offset from its edge, radians */
 #define VIS_MIN_PIECE 1e-9   /* shorter pieces of an edge are not examined */
 #define VIS_ON_LINE 1e-9     /* an endpoint this close to an edge's line cuts the edge at its foot */
+
+// Work counters of the painter (candidates, listed polygons, edges examined, pieces examined, shortcut hits, polygons
+// shown visible, edge_has_witness calls from canvas edges, cut gathers), summed over a launch; read by the profiling scripts.
+__device__ unsigned long long g_vis_stats[8];
 
 struct PolyMeta {
     double key1, key2;
@@ -183,8 +188,9 @@ __device__ inline bool painted_before(const PolyMeta &c, int ci, const PolyMeta 
     return ci < bi;
 }
 
-// even-odd point-in-ring, ring data wave-uniform
-__device__ inline bool pip_ring(const double *__restrict__ x, const double *__restrict__ y, int nv, double px, double py) {
+// even-odd point-in-ring
+template <typename P>
+__device__ inline bool pip_ring(P x, P y, int nv, double px, double py) {
     bool in = false;
     double ax = x[nv - 1], ay = y[nv - 1];
     for (int k = 0; k < nv; ++k) {
@@ -200,33 +206,78 @@ __device__ inline bool pip_ring(const double *__restrict__ x, const double *__re
 }
 
 struct PaintScratch {
-    int32_t *list;    // per wave [n]
+    int32_t *list;    // per wave [n]: canvas polygons whose box meets the current polygon's
+    int32_t *canvas;  // per wave [n]: polygons painted so far
+    double *cbox;     // per wave [n*4]: their boxes (xmin, xmax, ymin, ymax)
     double *splits;   // per wave [split_cap]
     int64_t split_cap;
+    int32_t *work;    // per wave [2 * vtot]: (entry, vertex) of canvas edges that enter the current polygon
+};
+
+// The polygons one coverage decision works on: entry 0 = the polygon B being decided, entries 1..count-1 = the canvas
+// polygons whose box meets B's.  Two views with the same interface: straight from global memory, or a copy staged in
+// LDS (a single wave chasing list -> record -> offsets -> coordinates through global memory is latency-bound; staged,
+// the same loops run out of LDS).
+struct GlobalSet {
+    const SceneView *sc;
+    const double *sph_f;
+    const PolyMeta *meta_f;
+    const int32_t *list;
+    int B, n;
+    __device__ int count() const { return n; }
+    __device__ int poly(int i) const { return i == 0 ? B : list[i - 1]; }
+    __device__ int nv(int i) const {
+        const int P = poly(i);
+        return sc->vert_off[P + 1] - sc->vert_off[P];
+    }
+    __device__ const double *x(int i) const { return sph_f + (size_t)sc->vert_off[poly(i)] * 2; }
+    __device__ const double *y(int i) const { return x(i) + nv(i); }
+    __device__ void box(int i, double &x0, double &x1, double &y0, double &y1) const {
+        const PolyMeta &m = meta_f[poly(i)];
+        x0 = m.xmin; x1 = m.xmax; y0 = m.ymin; y1 = m.ymax;
+    }
+    __device__ int sgn(int i) const { return meta_f[poly(i)].sgn; }
+};
+
+#define LS_MAX_POLY 96
+#define LS_MAX_COORD 1280  /* doubles: 640 vertices */
+struct LocalStore {
+    int nvs[LS_MAX_POLY], offs[LS_MAX_POLY], sgns[LS_MAX_POLY];
+    double boxes[LS_MAX_POLY * 4];
+    double xy[LS_MAX_COORD];
+};
+struct LocalSet {
+    LocalStore *st;
+    int n;
+    __device__ int count() const { return n; }
+    __device__ int nv(int i) const { return st->nvs[i]; }
+    __device__ const double *x(int i) const { return st->xy + st->offs[i]; }
+    __device__ const double *y(int i) const { return st->xy + st->offs[i] + st->nvs[i]; }
+    __device__ void box(int i, double &x0, double &x1, double &y0, double &y1) const {
+        x0 = st->boxes[4 * i]; x1 = st->boxes[4 * i + 1]; y0 = st->boxes[4 * i + 2]; y1 = st->boxes[4 * i + 3];
+    }
+    __device__ int sgn(int i) const { return st->sgns[i]; }
 };
 
 // Is the witness next to the middle of piece (t0, t1) of edge a->b, on side `side` (+1 = left of a->b), inside B and
 // outside every listed polygon?
-__device__ inline bool witness_uncovered(const SceneView &sc, const double *sph_f, const PolyMeta *meta_f, int B,
-                                         const int32_t *list, int n_list, double ax, double ay, double bx, double by,
-                                         double t0, double t1, double side, bool need_in_b) {
+template <typename Set>
+__device__ inline bool witness_uncovered(const Set &ps, double ax, double ay, double bx, double by, double t0, double t1,
+                                         double side, bool need_in_b) {
     const double ex = bx - ax, ey = by - ay;
     const double len = sqrt(ex * ex + ey * ey);
     const double tm = 0.5 * (t0 + t1);
     const double wx = ax + tm * ex - side * VIS_DELTA * (ey / len);
     const double wy = ay + tm * ey + side * VIS_DELTA * (ex / len);
     if (need_in_b) {
-        const int v0 = sc.vert_off[B], nv = sc.vert_off[B + 1] - v0;
-        const double *x = sph_f + (size_t)v0 * 2;
-        if (!pip_ring(x, x + nv, nv, wx, wy)) return false;
+        if (!pip_ring(ps.x(0), ps.y(0), ps.nv(0), wx, wy)) return false;
     }
-    for (int i = 0; i < n_list; ++i) {
-        const int C = list[i];
-        const PolyMeta &mc = meta_f[C];
-        if (wx < mc.xmin || wx > mc.xmax || wy < mc.ymin || wy > mc.ymax) continue;
-        const int v0 = sc.vert_off[C], nv = sc.vert_off[C + 1] - v0;
-        const double *x = sph_f + (size_t)v0 * 2;
-        if (pip_ring(x, x + nv, nv, wx, wy)) return false;
+    const int n = ps.count();
+    for (int i = 1; i < n; ++i) {
+        double x0, x1, y0, y1;
+        ps.box(i, x0, x1, y0, y1);
+        if (wx < x0 || wx > x1 || wy < y0 || wy > y1) continue;
+        if (pip_ring(ps.x(i), ps.y(i), ps.nv(i), wx, wy)) return false;
     }
     return true;
 }
@@ -257,158 +308,425 @@ __device__ inline int edge_cuts(double ax, double ay, double bx, double by, doub
     return k;
 }
 
-// Examine every piece of edge a->b (owner side `side`): returns true (wave-uniform) when a witness proves B visible.
-__device__ bool edge_has_witness(const SceneView &sc, const double *sph_f, const PolyMeta *meta_f, int B,
-                                 const int32_t *list, int n_list, int owner, double ax, double ay, double bx, double by,
-                                 double side, bool need_in_b, double *splits, int64_t split_cap, int *lds_count) {
+// Cut parameters of the edge being examined: the first SPLIT_LDS live in LDS, the rare overflow in global memory.
+#define SPLIT_LDS 192
+struct SplitBuf {
+    double *lds;     // [SPLIT_LDS]
+    double *glob;    // [cap]
+    int64_t cap;
+    __device__ void put(int i, double t) const {
+        if (i < SPLIT_LDS) lds[i] = t;
+        else if (i < cap) glob[i] = t;
+    }
+    __device__ double get(int i) const { return i < SPLIT_LDS ? lds[i] : glob[i]; }
+};
+
+// Examine every piece of edge a->b of entry `owner` (witness side `side`): returns true (wave-uniform) when a witness
+// proves B visible.
+template <typename Set>
+__device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay, double bx, double by, double side,
+                                 bool need_in_b, const SplitBuf &splits, int *lds_count) {
     const int lane = threadIdx.x & 63;
     const double ex = bx - ax, ey = by - ay;
     const double len = sqrt(ex * ex + ey * ey);
     if (!(len > VIS_MIN_PIECE)) return false;
-    // ---- gather the cuts: lanes = polygons of {B} ∪ list, each walks its own ring
+    // ---- gather the cuts: lanes = entries, each walks its own ring
     if (lane == 0) {
         *lds_count = 1;
-        splits[0] = 0.0;
+        splits.put(0, 0.0);
     }
     __builtin_amdgcn_wave_barrier();
-    for (int base = -1; base < n_list; base += 64) {
-        const int li = base + lane;  // -1 stands for B itself
-        if (li < n_list) {
-            const int P = li < 0 ? B : list[li];
-            if (P != owner) {
-                const PolyMeta &mp = meta_f[P];
-                // the other ring can only cut this edge where their boxes meet
-                const bool near = !(mp.xmax < fmin(ax, bx) - VIS_ON_LINE || mp.xmin > fmax(ax, bx) + VIS_ON_LINE ||
-                                    mp.ymax < fmin(ay, by) - VIS_ON_LINE || mp.ymin > fmax(ay, by) + VIS_ON_LINE);
-                if (near) {
-                    const int v0 = sc.vert_off[P], nv = sc.vert_off[P + 1] - v0;
-                    const double *x = sph_f + (size_t)v0 * 2, *y = x + nv;
-                    double cx = x[nv - 1], cy = y[nv - 1];
-                    for (int v = 0; v < nv; ++v) {
-                        const double dx = x[v], dy = y[v];
-                        double t[3];
-                        const int k = edge_cuts(ax, ay, bx, by, cx, cy, dx, dy, t);
-                        if (k > 0) {
-                            const int slot = atomicAdd(lds_count, k);
-                            for (int q = 0; q < k; ++q)
-                                if (slot + q < split_cap) splits[slot + q] = t[q];
-                        }
-                        cx = dx;
-                        cy = dy;
+    const int n = ps.count();
+    for (int base = 0; base < n; base += 64) {
+        const int li = base + lane;
+        if (li < n && li != owner) {
+            double x0, x1, y0, y1;
+            ps.box(li, x0, x1, y0, y1);
+            // the other ring can only cut this edge where their boxes meet
+            const bool near = !(x1 < fmin(ax, bx) - VIS_ON_LINE || x0 > fmax(ax, bx) + VIS_ON_LINE ||
+                                y1 < fmin(ay, by) - VIS_ON_LINE || y0 > fmax(ay, by) + VIS_ON_LINE);
+            if (near) {
+                const int nv = ps.nv(li);
+                const double *x = ps.x(li), *y = ps.y(li);
+                double cx = x[nv - 1], cy = y[nv - 1];
+                for (int v = 0; v < nv; ++v) {
+                    const double dx = x[v], dy = y[v];
+                    double t[3];
+                    const int k = edge_cuts(ax, ay, bx, by, cx, cy, dx, dy, t);
+                    if (k > 0) {
+                        const int slot = atomicAdd(lds_count, k);
+                        for (int q = 0; q < k; ++q) splits.put(slot + q, t[q]);
                     }
+                    cx = dx;
+                    cy = dy;
                 }
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
     int n_splits = *lds_count;
     n_splits = __builtin_amdgcn_readfirstlane(n_splits);
-    if (n_splits > split_cap) n_splits = (int)split_cap;  // cannot happen: capacity is 3 cuts per scene edge + 1
+    if (n_splits > SPLIT_LDS) __threadfence_block();
+    if (n_splits > splits.cap) n_splits = (int)splits.cap;  // cannot happen: capacity is 3 cuts per scene edge + 1
+    if (lane == 0) {
+        atomicAdd(&g_vis_stats[3], (unsigned long long)n_splits);
+        atomicAdd(&g_vis_stats[7], 1ull);
+    }
     // ---- every piece (t_j, next larger cut or 1)
     bool found = false;
     for (int base = 0; base < n_splits && !found; base += 64) {
         const int j = base + lane;
         bool mine = false;
         if (j < n_splits) {
-            const double t0 = splits[j];
+            const double t0 = splits.get(j);
             double t1 = 1.0;
             for (int i = 0; i < n_splits; ++i) {
-                const double ti = splits[i];
+                const double ti = splits.get(i);
                 if (ti > t0 && ti < t1) t1 = ti;
             }
-            if ((t1 - t0) * len > VIS_MIN_PIECE)
-                mine = witness_uncovered(sc, sph_f, meta_f, B, list, n_list, ax, ay, bx, by, t0, t1, side, need_in_b);
+            if ((t1 - t0) * len > VIS_MIN_PIECE) mine = witness_uncovered(ps, ax, ay, bx, by, t0, t1, side, need_in_b);
         }
         found = __any(mine);
     }
     return found;
 }
 
-__global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, const double *__restrict__ sph,
-                                                    const PolyMeta *__restrict__ meta, PaintScratch ps, int strict,
-                                                    unsigned long long *work_counter, uint8_t *__restrict__ out) {
-    __shared__ int lds_counts[4];
-    const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave_in_block;
-    int32_t *list = ps.list + wave_id * sc.n;
-    double *splits = ps.splits + wave_id * ps.split_cap;
-    int *lds_count = &lds_counts[wave_in_block];
-    const int64_t total = (int64_t)fb.n_faces * sc.n;
-    const int CHUNK = 8;
-    for (;;) {
-        unsigned long long start = 0;
-        if (lane == 0) start = atomicAdd(work_counter, (unsigned long long)CHUNK);
-        start = __shfl(start, 0);
-        if ((int64_t)start >= total) break;
-        for (int w = 0; w < CHUNK; ++w) {
-            const int64_t item = (int64_t)start + w;
-            if (item >= total) break;
-            const int f = (int)(item / sc.n), B = (int)(item % sc.n);
-            const PolyMeta *meta_f = meta + (size_t)f * sc.n;
-            const double *sph_f = sph + (size_t)f * sc.vtot * 2;
-            const PolyMeta mb = meta_f[B];
-            if (strict ? mb.state == 0 : mb.state != 2) continue;  // wave-uniform
-            bool visible = true;
-            if (!strict) {
-                // ---- polygons painted before B whose box meets B's box
-                int n_list = 0;
-                for (int base = 0; base < sc.n; base += 64) {
-                    const int C = base + lane;
-                    bool take = false;
-                    if (C < sc.n && C != B) {
-                        const PolyMeta &mc = meta_f[C];
-                        take = mc.state == 2 && painted_before(mc, C, mb, B) &&
-                               !(mc.xmax < mb.xmin || mc.xmin > mb.xmax || mc.ymax < mb.ymin || mc.ymin > mb.ymax);
+// Decide whether entry 0 of `ps` has a part outside the union of the other entries (wave-uniform result).
+// Called by all waves of the workgroup with identical arguments (the result is uniform over the workgroup): the cheap
+// shortcuts are computed by every wave, the edge examinations are dealt out to the waves and joined through `flag`.
+template <typename Set>
+__device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *lds_count, int32_t *work, int *flag) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int n = ps.count();
+    const int nv = ps.nv(0);
+    const double *x = ps.x(0), *y = ps.y(0);
+    double bx0, bx1, by0, by1;
+    ps.box(0, bx0, bx1, by0, by1);
+    bool visible = false;
+    // ---- shortcut: a few points inside B (vertex average and the points halfway to some vertices); one of them
+    // outside every other entry proves B visible.  Lanes = entries.
+    {
+        double gx = 0, gy = 0;
+        for (int v = 0; v < nv; ++v) {
+            gx += x[v];
+            gy += y[v];
+        }
+        gx /= nv;
+        gy /= nv;
+        const int n_samples = nv < 8 ? nv + 1 : 9;
+        for (int sidx = 0; sidx < n_samples && !visible; ++sidx) {
+            const double px = sidx == 0 ? gx : 0.5 * (gx + x[(sidx - 1) * nv / (n_samples - 1)]);
+            const double py = sidx == 0 ? gy : 0.5 * (gy + y[(sidx - 1) * nv / (n_samples - 1)]);
+            if (!pip_ring(x, y, nv, px, py)) continue;  // wave-uniform
+            bool covered = false;
+            for (int base = 1; base < n && !covered; base += 64) {
+                const int li = base + lane;
+                bool in = false;
+                if (li < n) {
+                    double x0, x1, y0, y1;
+                    ps.box(li, x0, x1, y0, y1);
+                    if (!(px < x0 || px > x1 || py < y0 || py > y1)) {
+                        const int cn = ps.nv(li);
+                        const double *cx = ps.x(li), *cy = ps.y(li);
+                        // closed test: a point on another entry's boundary proves nothing
+                        in = pip_ring(cx, cy, cn, px, py) || pip_ring(cx, cy, cn, px + VIS_DELTA, py + VIS_DELTA) ||
+                             pip_ring(cx, cy, cn, px - VIS_DELTA, py - VIS_DELTA);
                     }
-                    const unsigned long long m = __ballot(take);
-                    if (take) list[n_list + __popcll(m & ((1ull << lane) - 1))] = C;
-                    n_list += __popcll(m);
                 }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-                visible = n_list == 0;
-                if (!visible) {
-                    // ---- B's own edges, witness on B's inner side
-                    const int v0 = sc.vert_off[B], nv = sc.vert_off[B + 1] - v0;
-                    const double *x = sph_f + (size_t)v0 * 2, *y = x + nv;
-                    for (int v = 0; v < nv && !visible; ++v) {
-                        const int u = v == 0 ? nv - 1 : v - 1;
-                        visible = edge_has_witness(sc, sph_f, meta_f, B, list, n_list, B, x[u], y[u], x[v], y[v],
-                                                   (double)mb.sgn, false, splits, ps.split_cap, lds_count);
+                covered = __any(in);
+            }
+            visible = !covered;
+        }
+        if (visible && lane == 0) atomicAdd(&g_vis_stats[4], 1ull);
+    }
+    if (visible) return true;
+    // ---- shortcut: B inside ONE other entry (all of B's vertices strictly inside it and no edge of it meets B's ring)
+    // is hidden.  Lanes = entries.
+    {
+        bool hidden = false;
+        for (int base = 1; base < n && !hidden; base += 64) {
+            const int li = base + lane;
+            bool inside = false;
+            if (li < n) {
+                double x0, x1, y0, y1;
+                ps.box(li, x0, x1, y0, y1);
+                if (x0 < bx0 && x1 > bx1 && y0 < by0 && y1 > by1) {
+                    const int cn = ps.nv(li);
+                    const double *cx = ps.x(li), *cy = ps.y(li);
+                    inside = true;
+                    for (int v = 0; v < nv && inside; ++v) {
+                        // the vertex and four points 2e-9 around it must all be inside: strictly inside with margin
+                        inside = pip_ring(cx, cy, cn, x[v], y[v]) && pip_ring(cx, cy, cn, x[v] + 8 * VIS_DELTA, y[v]) &&
+                                 pip_ring(cx, cy, cn, x[v] - 8 * VIS_DELTA, y[v]) && pip_ring(cx, cy, cn, x[v], y[v] + 8 * VIS_DELTA) &&
+                                 pip_ring(cx, cy, cn, x[v], y[v] - 8 * VIS_DELTA);
                     }
-                    // ---- edges of the painted polygons that reach into B's box, witness on their outer side
-                    for (int i = 0; i < n_list && !visible; ++i) {
-                        const int C = list[i];
-                        const PolyMeta &mc = meta_f[C];
-                        const int c0 = sc.vert_off[C], cn = sc.vert_off[C + 1] - c0;
-                        const double *cx = sph_f + (size_t)c0 * 2, *cy = cx + cn;
-                        for (int v = 0; v < cn && !visible; ++v) {
-                            const int u = v == 0 ? cn - 1 : v - 1;
-                            const double ax = cx[u], ay = cy[u], bx = cx[v], by = cy[v];
-                            if (fmax(ax, bx) < mb.xmin || fmin(ax, bx) > mb.xmax || fmax(ay, by) < mb.ymin ||
-                                fmin(ay, by) > mb.ymax)
-                                continue;
-                            visible = edge_has_witness(sc, sph_f, meta_f, B, list, n_list, C, ax, ay, bx, by,
-                                                       -(double)mc.sgn, true, splits, ps.split_cap, lds_count);
+                    for (int q = 0; q < cn && inside; ++q) {
+                        const int p = q == 0 ? cn - 1 : q - 1;
+                        for (int v = 0; v < nv && inside; ++v) {
+                            const int u = v == 0 ? nv - 1 : v - 1;
+                            if (segments_meet(cx[p], cy[p], cx[q], cy[q], x[u], y[u], x[v], y[v])) inside = false;
                         }
                     }
                 }
             }
-            if (visible && lane == 0) {
-                // ---- B must face A (geometry.py:1004-1014)
-                const double *bb = sc.bbox + 6 * (size_t)B;
-                const d3 cb = mk3((bb[0] + bb[3]) / 2, (bb[1] + bb[4]) / 2, (bb[2] + bb[5]) / 2);
-                const d3 nb = ld3(sc.planes + 4 * (size_t)B);
-                const int a0 = fb.a_off[f], an = fb.a_off[f + 1] - a0;
-                bool facing = false;
-                for (int v = 0; v < an && !facing; ++v) {
-                    d3 dvec = ld3(fb.a_verts + 3 * (size_t)(a0 + v)) - cb;
-                    dvec = divs(dvec, norm3(dvec));
-                    facing = dot(dvec, nb) > TOL_DOT;
+            hidden = __any(inside);
+        }
+        if (hidden) return false;
+    }
+    // ---- B's own edges, witness on B's inner side
+    const double sgn_b = (double)ps.sgn(0);
+    for (int v = wave; v < nv; v += n_waves) {
+        if (*(volatile int *)flag) break;
+        const int u = v == 0 ? nv - 1 : v - 1;
+        if (edge_has_witness(ps, 0, x[u], y[u], x[v], y[v], sgn_b, false, splits, lds_count) && lane == 0) *flag = 1;
+    }
+    __syncthreads();
+    if (*(volatile int *)flag) return true;
+    // ---- edges of the other entries that enter B (an endpoint inside B or a crossing with B's ring): collected with
+    // lanes = entries, then examined one by one, witness on their outer side
+    int n_work = 0;
+    for (int base = 1; base < n; base += 64) {
+        const int li = base + lane;
+        const int cn = li < n ? ps.nv(li) : 0;
+        const double *cx = li < n ? ps.x(li) : x, *cy = li < n ? ps.y(li) : y;
+        for (int v = 0;; ++v) {
+            const bool act = v < cn;
+            if (!__any(act)) break;
+            bool rel = false;
+            if (act) {
+                const int u = v == 0 ? cn - 1 : v - 1;
+                const double ax = cx[u], ay = cy[u], ex = cx[v], ey = cy[v];
+                if (!(fmax(ax, ex) < bx0 || fmin(ax, ex) > bx1 || fmax(ay, ey) < by0 || fmin(ay, ey) > by1)) {
+                    rel = pip_ring(x, y, nv, ax, ay) || pip_ring(x, y, nv, ex, ey);
+                    for (int q = 0; q < nv && !rel; ++q) {
+                        const int p = q == 0 ? nv - 1 : q - 1;
+                        rel = segments_meet(ax, ay, ex, ey, x[p], y[p], x[q], y[q]);
+                    }
                 }
-                if (facing) out[(size_t)f * sc.n + B] = 1;
             }
+            const unsigned long long mk = __ballot(rel);
+            if (rel) {
+                const int slot = n_work + __popcll(mk & ((1ull << lane) - 1));
+                work[2 * slot] = li;
+                work[2 * slot + 1] = v;
+            }
+            n_work += __popcll(mk);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane == 0 && wave == 0) atomicAdd(&g_vis_stats[2], (unsigned long long)n_work);
+    for (int w = wave; w < n_work; w += n_waves) {
+        if (*(volatile int *)flag) break;
+        const int li = work[2 * w], v = work[2 * w + 1];
+        const int cn = ps.nv(li);
+        const double *cx = ps.x(li), *cy = ps.y(li);
+        const int u = v == 0 ? cn - 1 : v - 1;
+        if (lane == 0) atomicAdd(&g_vis_stats[6], 1ull);
+        if (edge_has_witness(ps, li, cx[u], cy[u], cx[v], cy[v], -(double)ps.sgn(li), true, splits, lds_count) && lane == 0)
+            *flag = 1;
+    }
+    __syncthreads();
+    return *(volatile int *)flag != 0;
+}
+
+// painter's order (geometry.py:980-984; Python's sort is stable, ties keep the scene order); -1 sorts last
+__device__ inline bool order_less(const PolyMeta *meta_f, int a, int b) {
+    if (a < 0) return false;
+    if (b < 0) return true;
+    return painted_before(meta_f[a], a, meta_f[b], b);
+}
+
+// one workgroup per face: candidates (valid rings in front of the face) sorted by the painter's key
+__global__ __launch_bounds__(256) void k_vis_sort(int n, const PolyMeta *__restrict__ meta, int32_t *__restrict__ order,
+                                                   int m_stride, int32_t *__restrict__ counts) {
+    __shared__ int cnt;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const PolyMeta *meta_f = meta + (size_t)f * n;
+    int32_t *ord = order + (size_t)f * m_stride;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int b = tid; b < n; b += 256)
+        if (meta_f[b].state == 2) ord[atomicAdd(&cnt, 1)] = b;
+    __syncthreads();
+    const int m = cnt;
+    int m_pad = 1;
+    while (m_pad < m) m_pad <<= 1;
+    for (int i = m + tid; i < m_pad; i += 256) ord[i] = -1;
+    __syncthreads();
+    for (int k = 2; k <= m_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m_pad; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int a = ord[i], b = ord[l];
+                    const bool up = (i & k) == 0;
+                    if (up ? order_less(meta_f, b, a) : order_less(meta_f, a, b)) {
+                        ord[i] = b;
+                        ord[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) counts[f] = m;
+}
+
+__device__ inline bool faces_viewer(const SceneView &sc, const FaceBatch &fb, int f, int B) {
+    // geometry.py:1004-1014
+    const double *bb = sc.bbox + 6 * (size_t)B;
+    const d3 cb = mk3((bb[0] + bb[3]) / 2, (bb[1] + bb[4]) / 2, (bb[2] + bb[5]) / 2);
+    const d3 nb = ld3(sc.planes + 4 * (size_t)B);
+    const int a0 = fb.a_off[f], an = fb.a_off[f + 1] - a0;
+    for (int v = 0; v < an; ++v) {
+        d3 dvec = ld3(fb.a_verts + 3 * (size_t)(a0 + v)) - cb;
+        dvec = divs(dvec, norm3(dvec));
+        if (dot(dvec, nb) > TOL_DOT) return true;
+    }
+    return false;
+}
+
+// One workgroup (4 waves) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
+// polygons whose box meets it and stages them in LDS; all waves then decide coverage together.
+__global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, const double *__restrict__ sph,
+                                                    const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
+                                                    int m_stride, const int32_t *__restrict__ counts, PaintScratch ps,
+                                                    int strict, unsigned long long *work_counter,
+                                                    uint8_t *__restrict__ out) {
+    __shared__ int lds_counts[4];
+    __shared__ LocalStore store_;
+    __shared__ double lds_splits[4][SPLIT_LDS];
+    __shared__ int s_face, s_nlist, s_fits, s_flag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LocalStore *store = &store_;
+    int32_t *list = ps.list + (int64_t)blockIdx.x * sc.n;
+    int32_t *canvas = ps.canvas + (int64_t)blockIdx.x * sc.n;
+    double *cbox = ps.cbox + (int64_t)blockIdx.x * sc.n * 4;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+    const SplitBuf splits{lds_splits[wave], ps.splits + wave_id * ps.split_cap, ps.split_cap};
+    int32_t *work = ps.work + wave_id * 2 * (int64_t)sc.vtot;
+    int *lds_count = &lds_counts[wave];
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long fq = atomicAdd(work_counter, 1ull);
+            s_face = fq < (unsigned long long)fb.n_faces ? (int)fq : -1;
+        }
+        __syncthreads();
+        const int f = s_face;
+        if (f < 0) break;
+        const PolyMeta *meta_f = meta + (size_t)f * sc.n;
+        const double *sph_f = sph + (size_t)f * sc.vtot * 2;
+        uint8_t *out_f = out + (size_t)f * sc.n;
+        if (strict) {
+            // z filter and normal filter only (geometry.py:974 skipped)
+            for (int B = threadIdx.x; B < sc.n; B += blockDim.x)
+                if (meta_f[B].state != 0 && faces_viewer(sc, fb, f, B)) out_f[B] = 1;
+            continue;
+        }
+        const int32_t *ord = order + (size_t)f * m_stride;
+        const int m = counts[f];
+        int n_canvas = 0;
+        for (int k = 0; k < m; ++k) {
+            const int B = ord[k];  // uniform over the workgroup
+            const PolyMeta mb = meta_f[B];
+            if (wave == 0) {
+                // ---- canvas polygons whose box meets B's box
+                int n_list = 0;
+                for (int base = 0; base < n_canvas; base += 64) {
+                    const int ci = base + lane;
+                    bool take = false;
+                    int C = -1;
+                    if (ci < n_canvas) {
+                        const double *cb = cbox + 4 * (size_t)ci;
+                        take = !(cb[1] < mb.xmin || cb[0] > mb.xmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                        C = canvas[ci];
+                    }
+                    const unsigned long long mk = __ballot(take);
+                    if (take) list[n_list + __popcll(mk & ((1ull << lane) - 1))] = C;
+                    n_list += __popcll(mk);
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                if (lane == 0) {
+                    atomicAdd(&g_vis_stats[0], 1ull);
+                    atomicAdd(&g_vis_stats[1], (unsigned long long)n_list);
+                }
+                // ---- stage B and the listed polygons in LDS when they fit
+                const int n_entries = n_list + 1;
+                int total = 0;
+                bool fits = n_list > 0 && n_entries <= LS_MAX_POLY;
+                if (fits) {
+                    for (int base = 0; base < n_entries; base += 64) {
+                        const int li = base + lane;
+                        int nv2 = 0;
+                        if (li < n_entries) {
+                            const int P = li == 0 ? B : list[li - 1];
+                            nv2 = 2 * (sc.vert_off[P + 1] - sc.vert_off[P]);
+                        }
+                        int incl = nv2;  // inclusive prefix over the wave
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int t = __shfl_up(incl, off);
+                            if (lane >= off) incl += t;
+                        }
+                        if (li < n_entries && total + incl <= LS_MAX_COORD) {
+                            store->offs[li] = total + incl - nv2;
+                            store->nvs[li] = nv2 / 2;
+                        }
+                        total += __shfl(incl, 63);
+                    }
+                    fits = total <= LS_MAX_COORD;
+                }
+                if (fits) {
+                    __builtin_amdgcn_wave_barrier();
+                    for (int base = 0; base < n_entries; base += 64) {
+                        const int li = base + lane;
+                        if (li < n_entries) {
+                            const int P = li == 0 ? B : list[li - 1];
+                            const PolyMeta &mp = meta_f[P];
+                            store->sgns[li] = mp.sgn;
+                            store->boxes[4 * li] = mp.xmin;
+                            store->boxes[4 * li + 1] = mp.xmax;
+                            store->boxes[4 * li + 2] = mp.ymin;
+                            store->boxes[4 * li + 3] = mp.ymax;
+                            const double *src = sph_f + (size_t)sc.vert_off[P] * 2;
+                            double *dst = store->xy + store->offs[li];
+                            const int cnt = 2 * store->nvs[li];
+                            for (int q = 0; q < cnt; ++q) dst[q] = src[q];
+                        }
+                    }
+                }
+                if (lane == 0) {
+                    s_nlist = n_list;
+                    s_fits = fits ? 1 : 0;
+                    s_flag = 0;
+                }
+            }
+            __syncthreads();
+            const int n_list = s_nlist;
+            bool visible = n_list == 0;
+            if (!visible) {
+                if (s_fits) {
+                    LocalSet ls{store, n_list + 1};
+                    visible = polygon_uncovered(ls, splits, lds_count, work, &s_flag);
+                } else {
+                    GlobalSet gs{&sc, sph_f, meta_f, list, B, n_list + 1};
+                    visible = polygon_uncovered(gs, splits, lds_count, work, &s_flag);
+                }
+            }
+            if (visible) {
+                if (threadIdx.x == 0) {
+                    atomicAdd(&g_vis_stats[5], 1ull);
+                    canvas[n_canvas] = B;
+                    double *cb = cbox + 4 * (size_t)n_canvas;
+                    cb[0] = mb.xmin; cb[1] = mb.xmax; cb[2] = mb.ymin; cb[3] = mb.ymax;
+                    if (faces_viewer(sc, fb, f, B)) out_f[B] = 1;
+                    __threadfence_block();
+                }
+                ++n_canvas;
+            }
+            __syncthreads();  // canvas / LDS store are rewritten for the next candidate
         }
     }
 }
@@ -439,14 +757,20 @@ static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, c
     const int n_faces = (int)a_self.size();
     if (n_faces == 0) return 0;
     hipStream_t st = scene->stream;
-    DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_splits, b_counter;
-    const int n_blocks = 512;  // persistent workgroups of 4 waves
+    DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work;
+    // persistent workgroups of 4 waves, one face per workgroup at a time
+    int n_blocks = n_faces > 1024 ? 1024 : n_faces;
     const int64_t split_cap = 3 * (int64_t)sc.vtot + 8;
+    int m_stride = 1;
+    while (m_stride < sc.n) m_stride <<= 1;
+    const size_t n_waves = (size_t)n_blocks * 4;
     if (b_off.alloc(sizeof(int32_t) * a_off.size()) || b_verts.alloc(sizeof(double) * a_verts.size()) ||
         b_normal.alloc(sizeof(double) * a_normal.size()) || b_self.alloc(sizeof(int32_t) * a_self.size()) ||
         b_sph.alloc(sizeof(double) * 2 * (size_t)sc.vtot * n_faces) || b_meta.alloc(sizeof(PolyMeta) * (size_t)sc.n * n_faces) ||
-        b_list.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks * 4) ||
-        b_splits.alloc(sizeof(double) * (size_t)split_cap * n_blocks * 4) || b_counter.alloc(sizeof(unsigned long long)))
+        b_list.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) || b_canvas.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) ||
+        b_cbox.alloc(sizeof(double) * 4 * (size_t)sc.n * n_blocks) || b_splits.alloc(sizeof(double) * (size_t)split_cap * n_waves) ||
+        b_counter.alloc(sizeof(unsigned long long)) || b_order.alloc(sizeof(int32_t) * (size_t)m_stride * n_faces) ||
+        b_counts.alloc(sizeof(int32_t) * (size_t)n_faces) || b_work.alloc(sizeof(int32_t) * 2 * (size_t)sc.vtot * n_waves))
         RT_FAIL("visibility: out of device memory");
     RT_HIP(hipMemcpyAsync(b_off.p, a_off.data(), sizeof(int32_t) * a_off.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(b_verts.p, a_verts.data(), sizeof(double) * a_verts.size(), hipMemcpyHostToDevice, st));
@@ -458,28 +782,47 @@ static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, c
                  (const int32_t *)b_self.p};
     hipLaunchKernelGGL(k_vis_prepare, dim3((sc.n + 255) / 256, n_faces), dim3(256), 0, st, sc, fb, (double *)b_sph.p,
                        (PolyMeta *)b_meta.p);
-    PaintScratch ps{(int32_t *)b_list.p, (double *)b_splits.p, split_cap};
+    if (!strict)
+        hipLaunchKernelGGL(k_vis_sort, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,
+                           (int32_t *)b_order.p, m_stride, (int32_t *)b_counts.p);
+    PaintScratch ps{(int32_t *)b_list.p, (int32_t *)b_canvas.p, (double *)b_cbox.p, (double *)b_splits.p, split_cap,
+                    (int32_t *)b_work.p};
     hipLaunchKernelGGL(k_vis_paint, dim3(n_blocks), dim3(256), 0, st, sc, fb, (const double *)b_sph.p,
-                       (const PolyMeta *)b_meta.p, ps, strict, (unsigned long long *)b_counter.p, d_out);
+                       (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride, (const int32_t *)b_counts.p, ps,
+                       strict, (unsigned long long *)b_counter.p, d_out);
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(st));
     return 0;
 }
 
+extern "C" int rt_faces_visibility(rt_scene *scene, int32_t n_faces, const int32_t *face_off, const double *face_verts,
+                                   const double *face_normals, const int32_t *self_index, int strict, uint8_t *out) {
+    if (!scene || !face_off || !face_verts || !face_normals || !out) RT_FAIL("rt_faces_visibility: null argument");
+    if (n_faces < 0) RT_FAIL("rt_faces_visibility: negative count");
+    if (n_faces == 0) return 0;
+    if (n_faces > 65535) RT_FAIL("rt_faces_visibility: at most 65535 faces per call");
+    if (face_off[0] != 0) RT_FAIL("rt_faces_visibility: face_off must start at 0");
+    for (int f = 0; f < n_faces; ++f) {
+        if (face_off[f + 1] - face_off[f] < 3) RT_FAIL("rt_faces_visibility: a face needs at least 3 vertices");
+        if (self_index && (self_index[f] < -1 || self_index[f] >= scene->view.n))
+            RT_FAIL("rt_faces_visibility: self_index out of range");
+    }
+    RT_HIP(hipSetDevice(scene->device));
+    std::vector<int32_t> a_off(face_off, face_off + n_faces + 1), a_self(n_faces, -1);
+    if (self_index) a_self.assign(self_index, self_index + n_faces);
+    std::vector<double> a_verts(face_verts, face_verts + 3 * (size_t)face_off[n_faces]);
+    std::vector<double> a_normal(face_normals, face_normals + 3 * (size_t)n_faces);
+    DevBuf d_out;
+    if (d_out.alloc((size_t)scene->view.n * n_faces)) RT_FAIL("rt_faces_visibility: out of device memory");
+    if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_out.p)) return -1;
+    RT_HIP(hipMemcpy(out, d_out.p, (size_t)scene->view.n * n_faces, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int rt_face_visibility(rt_scene *scene, const double *face_verts, int32_t n_face_verts,
                                   const double *face_normal, int32_t self_index, int strict, uint8_t *out) {
-    if (!scene || !face_verts || !face_normal || !out) RT_FAIL("rt_face_visibility: null argument");
-    if (n_face_verts < 3) RT_FAIL("rt_face_visibility: a face needs at least 3 vertices");
-    if (self_index < -1 || self_index >= scene->view.n) RT_FAIL("rt_face_visibility: self_index out of range");
-    RT_HIP(hipSetDevice(scene->device));
-    std::vector<int32_t> a_off{0, n_face_verts}, a_self{self_index};
-    std::vector<double> a_verts(face_verts, face_verts + 3 * (size_t)n_face_verts);
-    std::vector<double> a_normal(face_normal, face_normal + 3);
-    DevBuf d_out;
-    if (d_out.alloc(scene->view.n)) RT_FAIL("rt_face_visibility: out of device memory");
-    if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_out.p)) return -1;
-    RT_HIP(hipMemcpy(out, d_out.p, scene->view.n, hipMemcpyDeviceToHost));
-    return 0;
+    const int32_t off[2] = {0, n_face_verts};
+    return rt_faces_visibility(scene, 1, off, face_verts, face_normal, &self_index, strict, out);
 }
 
 extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_device) {
@@ -489,9 +832,10 @@ extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, i
     const int n = sc.n;
     DevBuf d_rows, d_sym;
     if (d_rows.alloc((size_t)n * n)) RT_FAIL("rt_visibility_matrix: out of device memory");
-    // batches of faces sized so the per-face scratch (mapped vertices + per-polygon records) stays under ~1 GiB
-    const size_t per_face = sizeof(double) * 2 * (size_t)sc.vtot + sizeof(PolyMeta) * (size_t)n;
-    int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)1 << 30) / per_face));
+    // batches of faces sized so the per-face scratch (mapped vertices + per-polygon records) stays under ~24 GiB: one
+    // batch for every scene of the reference (a batch ends when its slowest face ends, so fewer batches is faster)
+    const size_t per_face = sizeof(double) * 2 * (size_t)sc.vtot + (sizeof(PolyMeta) + 8) * (size_t)n;
+    int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)24 << 30) / per_face));
     batch = std::min(batch, 65535);
     for (int f0 = 0; f0 < n; f0 += batch) {
         const int f1 = std::min(n, f0 + batch);
@@ -516,5 +860,14 @@ extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, i
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(scene->stream));
     if (!on_device) RT_HIP(hipMemcpy(out, d_dst, (size_t)n * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Painter work counters accumulated since the last call (profiling aid; zeroes them).
+extern "C" int rt_debug_visibility_stats(unsigned long long *out8) {
+    if (!out8) RT_FAIL("rt_debug_visibility_stats: null argument");
+    RT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vis_stats), sizeof(unsigned long long) * 8));
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_vis_stats), zero, sizeof(zero)));
     return 0;
 }

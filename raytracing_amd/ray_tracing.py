@@ -63,11 +63,8 @@ class RayTracingProblem:
         cube = geom.Cube.by_point_and_side_length(emitter, 2 * 0.1)
         self.distance_to_screen = cube.polygons[0].distance_to_point(emitter)
 
-        visibilities = []
-        for i in range(self.n_screens):
-            screen = cube.polygons[i]
-            vis = scene.face_visibility(screen.points, screen.get_parametric(), -1, False)
-            visibilities.append((int(np.sum(vis)), vis))
+        screens = [(cube.polygons[i].points, cube.polygons[i].get_parametric(), -1) for i in range(self.n_screens)]
+        visibilities = [(int(np.sum(vis)), vis) for vis in scene.faces_visibility(screens, False)]
         visibilities.sort(key=lambda x: x[0], reverse=True)
         self.emitter_visibility = visibilities[0][1].copy()
         for _, vis in visibilities[1:self.n_screens]:
