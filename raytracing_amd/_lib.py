@@ -40,6 +40,7 @@ _SIGNATURES = {
     "rt_face_visibility": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_void_p]),
     "rt_faces_visibility": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_debug_visibility_stats": (c_int, [c_void_p]),
+    "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
     "rt_visibility_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "rt_sharp_edges": (c_int, [c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
     "rt_solve_reflections": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
@@ -230,6 +231,10 @@ class Scene:
         _check(load().rt_face_visibility(self.handle, _ptr(pts), len(pts), _ptr(normal), int(self_index),
                                          int(bool(strict)), _ptr(out)), "rt_face_visibility")
         return out.astype(bool)
+
+    def set_occlusion_mode(self, mode):
+        """0: obstruction tests walk the scene's grid (default); 1: they test every polygon (cross-check)."""
+        _check(load().rt_debug_set_occlusion_mode(self.handle, int(mode)), "rt_debug_set_occlusion_mode")
 
     def faces_visibility(self, faces, strict=False):
         """Visibility vectors of several faces in one launch; ``faces`` = list of (points (V,3), parametric (4,),

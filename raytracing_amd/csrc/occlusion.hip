@@ -2,10 +2,11 @@
 //
 // Work mapping: one lane per segment; every lane of a wave walks the same polygon, so the polygon's plane and box
 // are wave-uniform and come through the scalar data path (no per-lane memory traffic at all in the inner loop).
-// Per (segment, polygon) the loop does a plane crossing and a padded box test; only a lane whose crossing point lies
-// in the polygon's padded box runs the exact test of the reference (projection along the segment, extent overlap,
-// boundary-inclusive point-in-polygon, 1e-8 < t < 1-1e-8).  The padded pre-test can only let too many pairs through,
-// never too few, so the result is the exact test's.
+// Per (segment, polygon) the loop does a plane crossing and a padded box test; a pair whose crossing point lies in the
+// polygon's padded box is parked in a per-wave LDS queue, and the queue is emptied 64 pairs at a time through the exact
+// test of the reference (projection along the segment, extent overlap, boundary-inclusive point-in-polygon,
+// 1e-8 < t < 1-1e-8), so the expensive test always runs with full waves.  The padded pre-test can only let too many
+// pairs through, never too few, so the result is the exact test's.
 #include "rt_common.h"
 
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -13,56 +14,250 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r * (2.0 - x * r);  // one Newton step: plenty for a pre-test with a 1e-6 pad
 }
 
-template <bool MASKED>
-__global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__restrict__ segs, int64_t n_seg,
-                                                   const uint8_t *__restrict__ mask, int poly_chunk,
-                                                   uint8_t *__restrict__ out) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = s < n_seg;
-    d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
-    if (active) {
-        A = ld3(segs + 6 * s);
-        B = ld3(segs + 6 * s + 3);
-    }
-    const d3 V = B - A;
-    const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
-    bool hit = false;
-    const int p_begin = blockIdx.y * poly_chunk;
-    const int p_end = p_begin + poly_chunk < sc.n ? p_begin + poly_chunk : sc.n;
-    for (int p = p_begin; p < p_end; ++p) {
-        if (MASKED) {
-            if (!mask[p]) continue;  // wave-uniform
-        }
-        const double *pl = sc.planes + 4 * (size_t)p;
-        const double *bb = sc.bbox + 6 * (size_t)p;
-        const double nx = pl[0], ny = pl[1], nz = pl[2], d = pl[3];
-        const double den = V.x * nx + V.y * ny + V.z * nz;
-        const double num = d + (A.x * nx + A.y * ny + A.z * nz);
-        // t = -num/den must lie in (1e-8, 1 - 1e-8); compared without dividing, with room for rounding (1e-11 is
-        // far above the error of num for coordinates of a few km and far below 1e-8 |den| unless the segment grazes
-        // the plane): a segment that merely starts or ends on the polygon is rejected here
-        const double ad = fabs(den);
-        const double sn = den < 0.0 ? num : -num;
-        bool cand = active && !hit && sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
-        const double t = sn * fast_rcp(ad);
-        const double hx = A.x + t * V.x, hy = A.y + t * V.y, hz = A.z + t * V.z;
-        cand = cand && hx >= bb[0] - pad && hx <= bb[3] + pad && hy >= bb[1] - pad && hy <= bb[4] + pad &&
-               hz >= bb[2] - pad && hz <= bb[5] + pad;
-        if (cand) {
-            if (polygon_cuts_segment(sc, p, A, B)) hit = true;
-        }
-        if ((p & 31) == 31) {
-            if (__all(hit || !active)) break;
+// Runs the exact test for up to 64 parked (segment lane, polygon) pairs of a wave, one pair per lane.
+__device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double *__restrict__ segs, int64_t s_base,
+                                               int p_begin, const uint32_t *entries, int n_entries, int lane,
+                                               volatile uint8_t *wave_hit, uint8_t *__restrict__ out) {
+    if (lane < n_entries) {
+        const uint32_t e = entries[lane];
+        const int L = (int)(e & 63u);
+        if (!wave_hit[L]) {
+            const int64_t s = s_base + L;
+            if (polygon_cuts_segment(sc, p_begin + (int)(e >> 6), ld3(segs + 6 * s), ld3(segs + 6 * s + 3))) {
+                wave_hit[L] = 1;
+                out[s] = 1;  // out starts at zero; several polygon chunks may set the same byte
+            }
         }
     }
-    if (active && hit) out[s] = 1;  // out starts at zero; several polygon chunks may set the same byte
 }
 
-int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out) {
+// n_dev, when given, holds the segment count on the device (clamped to n_cap; a count above n_cap means the producer
+// overflowed its queue and the launch does nothing).
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__restrict__ segs, int64_t n_cap,
+                                                   const unsigned long long *__restrict__ n_dev,
+                                                   const uint8_t *__restrict__ mask, int poly_chunk,
+                                                   uint8_t *__restrict__ out) {
+    __shared__ uint32_t wave_queue[4][128];
+    __shared__ uint8_t wave_hits[4][64];
+    int64_t n_seg = n_cap;
+    if (n_dev) {
+        const unsigned long long nd = *n_dev;
+        if (nd > (unsigned long long)n_cap) return;
+        n_seg = (int64_t)nd;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *wq = wave_queue[wave];
+    volatile uint8_t *wave_hit = wave_hits[wave];
+    const int p_begin = blockIdx.y * poly_chunk;
+    const int p_end = p_begin + poly_chunk < sc.n ? p_begin + poly_chunk : sc.n;
+    for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s_base = tile + wave * 64;
+        const int64_t s = s_base + lane;
+        const bool active = s < n_seg;
+        d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
+        if (active) {
+            A = ld3(segs + 6 * s);
+            B = ld3(segs + 6 * s + 3);
+        }
+        const d3 V = B - A;
+        const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
+        bool hit = false;
+        int qn = 0;  // wave-uniform
+        wave_hit[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int p = p_begin; p < p_end; ++p) {
+            if (MASKED) {
+                if (!mask[p]) continue;  // wave-uniform
+            }
+            const double *pl = sc.planes + 4 * (size_t)p;
+            const double *bb = sc.bbox + 6 * (size_t)p;
+            const double nx = pl[0], ny = pl[1], nz = pl[2], d = pl[3];
+            const double den = V.x * nx + V.y * ny + V.z * nz;
+            const double num = d + (A.x * nx + A.y * ny + A.z * nz);
+            // t = -num/den must lie in (1e-8, 1 - 1e-8); compared without dividing, with room for rounding (1e-11 is
+            // far above the error of num for coordinates of a few km and far below 1e-8 |den| unless the segment
+            // grazes the plane): a segment that merely starts or ends on the polygon is rejected here
+            const double ad = fabs(den);
+            const double sn = den < 0.0 ? num : -num;
+            bool cand = active && !hit && sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
+            const double t = sn * fast_rcp(ad);
+            const double hx = A.x + t * V.x, hy = A.y + t * V.y, hz = A.z + t * V.z;
+            cand = cand && hx >= bb[0] - pad && hx <= bb[3] + pad && hy >= bb[1] - pad && hy <= bb[4] + pad &&
+                   hz >= bb[2] - pad && hz <= bb[5] + pad;
+            // pairs that pass the padded pre-test are parked and examined exactly 64 at a time, all lanes busy
+            const unsigned long long m = __ballot(cand);
+            if (m != 0) {
+                if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)(p - p_begin) << 6) | (uint32_t)lane;
+                qn += __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) {
+                    qn -= 64;
+                    obstruct_drain(sc, segs, s_base, p_begin, wq + qn, 64, lane, wave_hit, out);
+                    __builtin_amdgcn_wave_barrier();
+                    hit = wave_hit[lane] != 0;
+                    if (__all(hit || !active)) {
+                        qn = 0;
+                        break;
+                    }
+                }
+            }
+        }
+        if (qn > 0) obstruct_drain(sc, segs, s_base, p_begin, wq, qn, lane, wave_hit, out);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Grid walk: one lane per segment, each lane visiting only the cells its own segment passes over (within RT_GRID_PAD)
+// and testing the polygons registered there.  The walk goes cell column by cell column along the segment's major
+// horizontal axis, from the segment's start; within a column the segment spans at most three cells of the minor axis,
+// and a cell whose highest polygon lies below the segment's stretch over the column is skipped.  Lanes advance
+// independently (a lane's next record comes from its own cell list, through the vector memory path), so the walk is
+// efficient when the segments of a wave are neighbours — the solve emits them in fans for that reason.  The pre-test
+// and the parked exact tests are the every-polygon kernel's.  The polygons too large for the grid (the ground) are
+// tested first by every segment.  Every polygon the exact test could flag has its crossing point inside its own
+// padded box, hence inside a cell it is registered in, and that cell is on the segment's walk.
+__device__ __forceinline__ bool occ_pretest(const OccRec *__restrict__ r, const SceneView &sc, d3 A, d3 V, double pad) {
+    const double nx = r->nx, ny = r->ny, nz = r->nz, d = r->d;
+    const double den = V.x * nx + V.y * ny + V.z * nz;
+    const double num = d + (A.x * nx + A.y * ny + A.z * nz);
+    const double ad = fabs(den);
+    const double sn = den < 0.0 ? num : -num;
+    bool cand = sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
+    const double t = sn * fast_rcp(ad);
+    const double hx = A.x + t * V.x - sc.gx0, hy = A.y + t * V.y - sc.gy0, hz = A.z + t * V.z - sc.gz0;
+    return cand && hx >= (double)r->lo[0] - pad && hx <= (double)r->hi[0] + pad && hy >= (double)r->lo[1] - pad &&
+           hy <= (double)r->hi[1] + pad && hz >= (double)r->lo[2] - pad && hz <= (double)r->hi[2] + pad;
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, const double *__restrict__ segs, int64_t n_cap,
+                                                        const unsigned long long *__restrict__ n_dev,
+                                                        const uint8_t *__restrict__ mask, uint8_t *__restrict__ out) {
+    __shared__ uint32_t wave_queue[4][128];
+    __shared__ uint8_t wave_hits[4][64];
+    int64_t n_seg = n_cap;
+    if (n_dev) {
+        const unsigned long long nd = *n_dev;
+        if (nd > (unsigned long long)n_cap) return;
+        n_seg = (int64_t)nd;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *wq = wave_queue[wave];
+    volatile uint8_t *wave_hit = wave_hits[wave];
+    const OccCell global_cell = sc.cells[sc.gnx * sc.gny];
+    for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s_base = tile + wave * 64;
+        const int64_t s = s_base + lane;
+        const bool active = s < n_seg;
+        d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
+        if (active) {
+            A = ld3(segs + 6 * s);
+            B = ld3(segs + 6 * s + 3);
+        }
+        const d3 V = B - A;
+        const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
+        // walk set-up: u = major horizontal axis, w = minor, both relative to the grid origin; the columns are visited
+        // from the segment's start towards its end
+        const bool major_x = fabs(V.x) >= fabs(V.y);
+        const double au = major_x ? A.x - sc.gx0 : A.y - sc.gy0, aw = major_x ? A.y - sc.gy0 : A.x - sc.gx0;
+        const double du = major_x ? V.x : V.y, dw = major_x ? V.y : V.x;
+        const int nu = major_x ? sc.gnx : sc.gny, nw = major_x ? sc.gny : sc.gnx;
+        const double inv_du = fabs(du) > 1e-12 ? 1.0 / du : 0.0;
+        const double gp = RT_GRID_PAD + 1e-9 * (fabs(au) + fabs(aw) + fabs(du));
+        const double fi_lo = floor((fmin(au, au + du) - gp) * sc.ginv), fi_hi = floor((fmax(au, au + du) + gp) * sc.ginv);
+        const bool outside = !active || fi_hi < 0.0 || fi_lo > (double)(nu - 1);
+        const int i_first = outside ? 0 : (int)fmax(fi_lo, 0.0), i_last = outside ? -1 : (int)fmin(fi_hi, (double)(nu - 1));
+        const int step = du >= 0.0 ? 1 : -1;
+        int cols_left = i_last - i_first + 1;           // columns not yet entered
+        int i = (step > 0 ? i_first : i_last) - step;  // current column
+        int j = 1, j_hi = 0;
+        int k = active ? global_cell.begin : 0, k_end = active ? global_cell.end : 0;
+        double z_low = 0.0;  // lowest point of the segment over the current column, relative to the grid origin
+        // moves to the next cell that has records and is not entirely below the segment; false when the walk is over
+        auto next_cell = [&]() -> bool {
+            while (true) {
+                ++j;
+                if (j > j_hi) {
+                    if (cols_left <= 0) return false;
+                    --cols_left;
+                    i += step;
+                    // minor-axis cells of column i: the segment's extent over the padded slab of the column
+                    double ta = 0.0, tb = 1.0;
+                    if (inv_du != 0.0) {
+                        const double t0 = (i * sc.gside - gp - au) * inv_du, t1 = ((i + 1) * sc.gside + gp - au) * inv_du;
+                        ta = fmax(0.0, fmin(t0, t1));
+                        tb = fmin(1.0, fmax(t0, t1));
+                    }
+                    const double wa = aw + ta * dw, wb = aw + tb * dw;
+                    const double fj_lo = floor((fmin(wa, wb) - gp) * sc.ginv), fj_hi = floor((fmax(wa, wb) + gp) * sc.ginv);
+                    if (fj_hi < 0.0 || fj_lo > (double)(nw - 1)) {
+                        j = 1;
+                        j_hi = 0;
+                        continue;
+                    }
+                    j = (int)fmax(fj_lo, 0.0);
+                    j_hi = (int)fmin(fj_hi, (double)(nw - 1));
+                    z_low = fmin(A.z + ta * V.z, A.z + tb * V.z) - sc.gz0 - pad;
+                }
+                const OccCell cell = sc.cells[major_x ? j * sc.gnx + i : i * sc.gnx + j];
+                if (cell.end > cell.begin && !(z_low > (double)cell.zmax)) {
+                    k = cell.begin;
+                    k_end = cell.end;
+                    return true;
+                }
+            }
+        };
+        bool finished = !active;
+        if (active && k >= k_end) finished = !next_cell();
+        int qn = 0;  // wave-uniform
+        wave_hit[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        while (__any(!finished)) {
+            bool cand = false;
+            int poly = 0;
+            if (!finished) {
+                const OccRec *r = sc.cell_recs + k;
+                poly = r->poly;
+                bool wanted = true;
+                if (MASKED) wanted = mask[poly] != 0;
+                if (wanted) cand = occ_pretest(r, sc, A, V, pad);
+                ++k;
+                if (k >= k_end) finished = !next_cell();
+            }
+            const unsigned long long m = __ballot(cand);
+            if (m != 0) {
+                if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)poly << 6) | (uint32_t)lane;
+                qn += __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) {
+                    qn -= 64;
+                    obstruct_drain(sc, segs, s_base, 0, wq + qn, 64, lane, wave_hit, out);
+                    __builtin_amdgcn_wave_barrier();
+                    if (wave_hit[lane]) finished = true;
+                }
+            }
+        }
+        if (qn > 0) obstruct_drain(sc, segs, s_base, 0, wq, qn, lane, wave_hit, out);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const unsigned long long *__restrict__ n_dev) {
+    const unsigned long long nd = *n_dev;
+    const int64_t n = nd > (unsigned long long)n_cap ? 0 : (int64_t)nd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0;
+}
+
+// Obstruction flags of n_seg segments (or, with d_count, of the *d_count <= n_seg segments the device holds, the grid
+// being sized for n_hint of them).
+int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out,
+                       const unsigned long long *d_count, int64_t n_hint) {
     if (n_seg == 0) return 0;
     const int block = 256;
-    const int64_t grid = (n_seg + block - 1) / block;
-    if (grid > 0x7fffffffLL) RT_FAIL("rt_obstruct_segments: too many segments for one launch");
+    const int64_t n_grid = d_count ? (n_hint < 1 ? 1 : (n_hint > n_seg ? n_seg : n_hint)) : n_seg;
+    int64_t grid = (n_grid + block - 1) / block;
+    if (grid > (1 << 20)) grid = 1 << 20;  // the kernel strides over the rest
     // few segments: split the polygon list over grid.y so the launch still fills the chip (target >= ~2048 waves)
     const int64_t waves = grid * (block / RT_WAVE);
     int64_t ny = waves >= 2048 ? 1 : (2048 + waves - 1) / waves;
@@ -70,15 +265,25 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, con
     ny = ny > max_ny ? max_ny : ny;
     ny = ny < 1 ? 1 : ny;
     int poly_chunk = (int)((scene->view.n + ny - 1) / ny);
-    poly_chunk = (poly_chunk + 31) & ~31;  // keeps the early-exit test aligned
     ny = (scene->view.n + poly_chunk - 1) / poly_chunk;
-    RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_seg, scene->stream));
-    if (d_mask)
+    if (d_count)
+        hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)(grid < 1024 ? grid : 1024)), dim3(block), 0, scene->stream,
+                           d_out, n_seg, d_count);
+    else
+        RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_seg, scene->stream));
+    if (scene->occlusion_mode == 0) {
+        if (d_mask)
+            hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view,
+                               d_segs, n_seg, d_count, d_mask, d_out);
+        else
+            hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view,
+                               d_segs, n_seg, d_count, d_mask, d_out);
+    } else if (d_mask)
         hipLaunchKernelGGL(k_obstruct<true>, dim3((unsigned)grid, (unsigned)ny), dim3(block), 0, scene->stream,
-                           scene->view, d_segs, n_seg, d_mask, poly_chunk, d_out);
+                           scene->view, d_segs, n_seg, d_count, d_mask, poly_chunk, d_out);
     else
         hipLaunchKernelGGL(k_obstruct<false>, dim3((unsigned)grid, (unsigned)ny), dim3(block), 0, scene->stream,
-                           scene->view, d_segs, n_seg, d_mask, poly_chunk, d_out);
+                           scene->view, d_segs, n_seg, d_count, d_mask, poly_chunk, d_out);
     RT_HIP(hipGetLastError());
     return 0;
 }
@@ -91,7 +296,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
     if (!segs || !out) RT_FAIL("rt_obstruct_segments: null array");
     RT_HIP(hipSetDevice(scene->device));
     if (on_device) {
-        if (rt_launch_obstruct(scene, segs, n_seg, mask, out)) return -1;
+        if (rt_launch_obstruct(scene, segs, n_seg, mask, out, nullptr, 0)) return -1;
         RT_HIP(hipStreamSynchronize(scene->stream));
         return 0;
     }
@@ -105,7 +310,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
         if (hipMemcpyAsync(d_segs, segs, sizeof(double) * 6 * n_seg, hipMemcpyHostToDevice, scene->stream) != hipSuccess)
             break;
         if (mask && hipMemcpyAsync(d_mask, mask, scene->view.n, hipMemcpyHostToDevice, scene->stream) != hipSuccess) break;
-        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, d_out)) break;
+        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, d_out, nullptr, 0)) break;
         if (hipMemcpyAsync(out, d_out, n_seg, hipMemcpyDeviceToHost, scene->stream) != hipSuccess) break;
         if (hipStreamSynchronize(scene->stream) != hipSuccess) break;
         rc = 0;

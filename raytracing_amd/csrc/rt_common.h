@@ -45,6 +45,23 @@ void rt_set_error(const std::string &msg);
 // ---------------------------------------------------------------------------------------------------------------
 // scene: structure-of-arrays in device memory (all read-only after creation)
 // ---------------------------------------------------------------------------------------------------------------
+// One polygon as the obstruction pre-test wants it, 64 bytes: plane in fp64, box in fp32 relative to the grid origin
+// and rounded outwards (the pre-test only has to be conservative).
+struct OccRec {
+    double nx, ny, nz, d;
+    float lo[3], hi[3];
+    int32_t poly;
+    int32_t pad_;
+};
+
+// One grid cell: its records are cell_recs[begin, end); zmax = top of the highest polygon registered in it, relative to
+// the grid origin and rounded up (a segment passing above it skips the cell).
+struct OccCell {
+    int32_t begin, end;
+    float zmax;
+    int32_t pad_;
+};
+
 struct SceneView {
     int32_t n;               // polygons
     int32_t vtot;            // vertices
@@ -57,11 +74,18 @@ struct SceneView {
     const double *uv;        // [vtot*2] vertices in the polygon's own frame (first two coordinates)
     const int32_t *material; // [n]
     const int32_t *building; // [n]
+    // Uniform grid of square cells over the horizontal extent of the scene (buildings are extrusions, so a 2-D grid
+    // separates them well).  Cell c = row * gnx + column lists every polygon whose footprint comes within RT_GRID_PAD of
+    // it; the extra cell gnx*gny lists the polygons too large to be worth registering cell by cell (the ground), which
+    // every segment tests.
+    double gx0, gy0, gz0;    // grid origin (minimum corner of the scene)
+    double gside, ginv;      // cell side and its inverse
+    int32_t gnx, gny;
+    const OccCell *cells;    // [gnx*gny + 1]
+    const OccRec *cell_recs;
 };
 
-struct TimingSlot {
-    hipEvent_t start = nullptr, stop = nullptr;
-};
+#define RT_GRID_PAD 1e-5
 
 struct rt_scene {
     int device = 0;
@@ -74,6 +98,14 @@ struct rt_scene {
     // growable workspace owned by the solve
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // solve state that outlives a call, so that a call in a loop allocates nothing: device counters, their pinned host
+    // mirror, timing events, and the sizes the last call needed (the next call's launch and queue sizes start there)
+    unsigned long long *d_counters = nullptr;  // [16]
+    unsigned long long *h_counters = nullptr;  // [16] pinned
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    int64_t hint_paths = 0, hint_segments = 0;
+    int occlusion_mode = 0;  // 0 = grid walk, 1 = every polygon (kept for cross-checking the grid)
     // timing of the last solve
     double last_ms[4] = {0, 0, 0, 0};
     int64_t last_launches[4] = {0, 0, 0, 0};

@@ -1,4 +1,5 @@
 // Scene handle: uploads the polygon list once and derives frames, bounding boxes and in-plane coordinates.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -24,6 +25,127 @@ static int upload(rt_scene *s, const std::vector<T> &h, const T **dptr) {
     s->allocations.push_back(d);
     if (!h.empty()) RT_HIP(hipMemcpy(d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     *dptr = (const T *)d;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// obstruction grid
+// ---------------------------------------------------------------------------------------------------------------
+static float round_down(double v) {
+    float f = (float)v;
+    return (double)f > v ? std::nextafterf(f, -INFINITY) : f;
+}
+static float round_up(double v) {
+    float f = (float)v;
+    return (double)f < v ? std::nextafterf(f, INFINITY) : f;
+}
+
+// does the 2-D segment P->Q come within the box [x0,x1]x[y0,y1]?  (slab clipping; errs on the side of yes)
+static bool segment_meets_box(double px, double py, double qx, double qy, double x0, double y0, double x1, double y1) {
+    double t0 = 0.0, t1 = 1.0;
+    const double d[2] = {qx - px, qy - py}, p[2] = {px, py}, lo[2] = {x0, y0}, hi[2] = {x1, y1};
+    for (int a = 0; a < 2; ++a) {
+        if (std::fabs(d[a]) < 1e-300) {
+            if (p[a] < lo[a] || p[a] > hi[a]) return false;
+        } else {
+            double ta = (lo[a] - p[a]) / d[a], tb = (hi[a] - p[a]) / d[a];
+            if (ta > tb) std::swap(ta, tb);
+            t0 = std::max(t0, ta);
+            t1 = std::min(t1, tb);
+        }
+    }
+    return t0 <= t1 + 1e-12;
+}
+
+static int build_grid(rt_scene *s, int n_poly, const int32_t *vert_off, const double *verts, const double *planes) {
+    const double *bb = s->h_bbox.data();
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n_poly; ++i)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::fmin(lo[k], bb[6 * (size_t)i + k]);
+            hi[k] = std::fmax(hi[k], bb[6 * (size_t)i + 3 + k]);
+        }
+    const double pad = RT_GRID_PAD;
+    const double w = std::fmax(hi[0] - lo[0], 1e-3), h = std::fmax(hi[1] - lo[1], 1e-3);
+    // about one cell per polygon: a handful of records per occupied cell
+    double side = std::sqrt(w * h / std::fmax(16.0, (double)n_poly));
+    side = std::fmax(side, std::fmax(w, h) / 1024.0);
+    const int gnx = std::max(1, (int)std::ceil(w / side)), gny = std::max(1, (int)std::ceil(h / side));
+    const int n_cells = gnx * gny;
+    const size_t big_limit = std::max<size_t>(64, (size_t)n_cells / 8);
+    std::vector<std::vector<int32_t>> cells((size_t)n_cells + 1);
+    std::vector<int32_t> mine;
+    for (int i = 0; i < n_poly; ++i) {
+        const double *b = bb + 6 * (size_t)i;
+        const int c0 = std::min(gnx - 1, std::max(0, (int)std::floor((b[0] - pad - lo[0]) / side)));
+        const int c1 = std::min(gnx - 1, std::max(0, (int)std::floor((b[3] + pad - lo[0]) / side)));
+        const int r0 = std::min(gny - 1, std::max(0, (int)std::floor((b[1] - pad - lo[1]) / side)));
+        const int r1 = std::min(gny - 1, std::max(0, (int)std::floor((b[4] + pad - lo[1]) / side)));
+        const int v0 = vert_off[i], nv = vert_off[i + 1] - v0;
+        const double *pv = verts + 3 * (size_t)v0;
+        mine.clear();
+        for (int r = r0; r <= r1; ++r)
+            for (int c = c0; c <= c1; ++c) {
+                const double x0 = lo[0] + c * side - 2 * pad, x1 = lo[0] + (c + 1) * side + 2 * pad;
+                const double y0 = lo[1] + r * side - 2 * pad, y1 = lo[1] + (r + 1) * side + 2 * pad;
+                // footprint test: a side of the polygon crosses the cell, or the cell's centre is inside the footprint
+                bool touches = false;
+                for (int v = 0; v < nv && !touches; ++v) {
+                    const double *P = pv + 3 * v, *Q = pv + 3 * ((v + 1) % nv);
+                    touches = segment_meets_box(P[0], P[1], Q[0], Q[1], x0, y0, x1, y1);
+                }
+                if (!touches)
+                    touches = pip_inclusive(
+                        nv, [&](int k, double &x, double &y) { x = pv[3 * k]; y = pv[3 * k + 1]; }, 0.5 * (x0 + x1),
+                        0.5 * (y0 + y1));
+                if (touches) mine.push_back(r * gnx + c);
+            }
+        if (mine.size() > big_limit) {
+            cells[n_cells].push_back(i);
+        } else {
+            for (int32_t c : mine) cells[c].push_back(i);
+        }
+    }
+    std::vector<OccCell> cell_table((size_t)n_cells + 1);
+    std::vector<OccRec> recs;
+    for (int c = 0; c <= n_cells; ++c) {
+        OccCell &cell = cell_table[c];
+        cell.begin = (int32_t)recs.size();
+        cell.zmax = -INFINITY;
+        cell.pad_ = 0;
+        for (int32_t i : cells[c]) {
+            OccRec r;
+            const double *pl = planes + 4 * (size_t)i, *b = bb + 6 * (size_t)i;
+            r.nx = pl[0];
+            r.ny = pl[1];
+            r.nz = pl[2];
+            r.d = pl[3];
+            for (int a = 0; a < 3; ++a) {
+                r.lo[a] = round_down(b[a] - lo[a]);
+                r.hi[a] = round_up(b[3 + a] - lo[a]);
+            }
+            r.poly = i;
+            r.pad_ = 0;
+            cell.zmax = std::fmax(cell.zmax, r.hi[2]);
+            recs.push_back(r);
+        }
+        cell.end = (int32_t)recs.size();
+    }
+    s->view.gx0 = lo[0];
+    s->view.gy0 = lo[1];
+    s->view.gz0 = lo[2];
+    s->view.gside = side;
+    s->view.ginv = 1.0 / side;
+    s->view.gnx = gnx;
+    s->view.gny = gny;
+    if (upload(s, cell_table, &s->view.cells)) return -1;
+    if (upload(s, recs, &s->view.cell_recs)) return -1;
+    return 0;
+}
+
+extern "C" int rt_debug_set_occlusion_mode(rt_scene *s, int mode) {
+    if (!s || mode < 0 || mode > 1) RT_FAIL("rt_debug_set_occlusion_mode: bad argument");
+    s->occlusion_mode = mode;
     return 0;
 }
 
@@ -90,7 +212,23 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
     bool ok = upload(s, s->h_vert_off, &s->view.vert_off) == 0 && upload(s, s->h_verts, &s->view.verts) == 0 &&
               upload(s, s->h_planes, &s->view.planes) == 0 && upload(s, frames, &s->view.frames) == 0 &&
               upload(s, s->h_bbox, &s->view.bbox) == 0 && upload(s, uv, &s->view.uv) == 0 &&
-              upload(s, mat, &s->view.material) == 0 && upload(s, bld, &s->view.building) == 0;
+              upload(s, mat, &s->view.material) == 0 && upload(s, bld, &s->view.building) == 0 &&
+              build_grid(s, n_poly, vert_off, verts, planes) == 0;
+    if (ok) {
+        void *d = nullptr;
+        if (hipMalloc(&d, 16 * sizeof(unsigned long long)) == hipSuccess) {
+            s->allocations.push_back(d);
+            s->d_counters = (unsigned long long *)d;
+        } else {
+            rt_set_error("rt_scene_create: out of device memory");
+            ok = false;
+        }
+        if (ok && hipHostMalloc((void **)&s->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+            rt_set_error("rt_scene_create: pinned host allocation failed");
+            s->h_counters = nullptr;
+            ok = false;
+        }
+    }
     if (ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         rt_set_error("rt_scene_create: hipStreamCreate failed");
         ok = false;
@@ -112,8 +250,10 @@ extern "C" void rt_scene_destroy(rt_scene *s) {
         (void)hipStreamSynchronize(s->stream);
         (void)hipStreamDestroy(s->stream);
     }
+    for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->ws) (void)hipFree(s->ws);
+    if (s->h_counters) (void)hipHostFree(s->h_counters);
     delete s;
 }
 

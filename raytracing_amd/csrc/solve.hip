@@ -24,13 +24,14 @@
 #include "rt_candidates.h"
 #include "rt_common.h"
 
-int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out);
+int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out,
+                       const unsigned long long *d_count, int64_t n_hint);
 
 #define MIN_DISTANCE_TOL 0.005 /* ray_tracing.py:252 */
 
 struct PathRec {
     int32_t rx, group, cand, nseg;
-    int64_t seg0;
+    int64_t seg0, seg_stride;  // segment k of the path is segs[seg0 + k * seg_stride]
     double pts[RT_MAX_ORDER * 3];
 };
 
@@ -449,9 +450,23 @@ __device__ __forceinline__ double fast_rcp_s(double x) {
     return r * (2.0 - x * r);
 }
 
+// Adds `each` per calling lane to *counter with one atomic per wave (the calling lanes may be any subset of the wave)
+// and returns the calling lane's own base.
+__device__ __forceinline__ unsigned long long wave_reserve(unsigned long long *counter, unsigned each) {
+    const unsigned long long m = __ballot(1);
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1));
+    unsigned long long base = 0;
+    if (rank == 0) base = atomicAdd(counter, (unsigned long long)each * (unsigned)__popcll(m));
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+    return (((unsigned long long)hi << 32) | lo) + (unsigned long long)each * rank;
+}
+
+// nseg must be the same for every calling lane
 __device__ inline bool reserve(const Queues &q, int nseg, int64_t &path_slot, int64_t &seg_slot) {
-    path_slot = (int64_t)atomicAdd(&q.counters[0], 1ull);
-    seg_slot = (int64_t)atomicAdd(&q.counters[1], (unsigned long long)nseg);
+    path_slot = (int64_t)wave_reserve(&q.counters[0], 1u);
+    seg_slot = (int64_t)wave_reserve(&q.counters[1], (unsigned)nseg);
     return path_slot < q.path_cap && seg_slot + nseg <= q.seg_cap;
 }
 
@@ -510,6 +525,7 @@ __device__ inline void reflect_exact(const SceneView &sc, const int32_t *__restr
     rec.cand = (int32_t)c;
     rec.nseg = K + 1;
     rec.seg0 = ss;
+    rec.seg_stride = 1;
     a = tx;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
@@ -555,25 +571,35 @@ __global__ __launch_bounds__(256) void k_reflect(SceneView sc, const int32_t *__
     const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
     int qn = 0;  // wave-uniform
     uint32_t *wq = wave_queue[wave];
-    for (int64_t r = r_begin; r < r_end; ++r) {
-        const d3 R = ld3(rx + 3 * r);  // wave-uniform
-        const d3 dir = R - im;
-        const double t = -gk * fast_rcp_s(dot(dir, nk));
-        const double pad = 1e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 1e-6;
-        const double hx = im.x + t * dir.x, hy = im.y + t * dir.y, hz = im.z + t * dir.z;
-        const bool cand = active && t > -1e-6 && t < 1.0 + 1e-6 && hx >= b0 - pad && hx <= b3 + pad && hy >= b1 - pad &&
-                          hy <= b4 + pad && hz >= b2 - pad && hz <= b5 + pad;
-        const unsigned long long m = __ballot(cand);
-        if (m == 0) continue;
-        if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)lane << 16) | (uint32_t)(r - r_begin);
-        qn += __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (qn >= 64) {
-            const uint32_t e = wq[qn - 64 + lane];
-            qn -= 64;
-            const int64_t rr = r_begin + (e & 0xffffu);
-            reflect_exact<K>(sc, chains, c_base + (e >> 16), group, tx, ld3(rx + 3 * rr), rr, q);
+    // four receivers per trip: their pre-tests are independent, which hides the fp64 latency of one behind the others
+    for (int64_t r4 = r_begin; r4 < r_end; r4 += 4) {
+        bool pass[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = r4 + j < r_end ? r4 + j : r_end - 1;
+            const d3 R = ld3(rx + 3 * r);  // wave-uniform
+            const d3 dir = R - im;
+            const double t = -gk * fast_rcp_s(dot(dir, nk));
+            const double pad = 1e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 1e-6;
+            const double hx = im.x + t * dir.x, hy = im.y + t * dir.y, hz = im.z + t * dir.z;
+            pass[j] = active && r4 + j < r_end && t > -1e-6 && t < 1.0 + 1e-6 && hx >= b0 - pad && hx <= b3 + pad &&
+                      hy >= b1 - pad && hy <= b4 + pad && hz >= b2 - pad && hz <= b5 + pad;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long m = __ballot(pass[j]);
+            if (m == 0) continue;
+            if (pass[j])
+                wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)lane << 16) | (uint32_t)(r4 + j - r_begin);
+            qn += __popcll(m);
             __builtin_amdgcn_wave_barrier();
+            if (qn >= 64) {
+                const uint32_t e = wq[qn - 64 + lane];
+                qn -= 64;
+                const int64_t rr = r_begin + (e & 0xffffu);
+                reflect_exact<K>(sc, chains, c_base + (e >> 16), group, tx, ld3(rx + 3 * rr), rr, q);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     if (lane < qn) {
@@ -646,67 +672,142 @@ __global__ void k_rd_filter(const AliveRec *__restrict__ in, const uint8_t *__re
     out[slot] = in[i];
 }
 
-// Diffraction candidates: lane = alive (M reflections + edge) record, or for M = 0 an edge of the 1-diffraction
-// group; loop = receivers of the block's tile.
+// Receiver-independent part of one diffraction candidate: the edge-aligned frame (geometry.py:736-742), the edge and
+// the point before it (emitter or last reflection point) in that frame.
+struct DiffSetup {
+    double fx[3], fy[3], fz[3];
+    double xe, ye, ze, z1;
+    double ax, ay, az, rhoA;
+    double A[3];
+    int32_t cand, src;  // candidate index in its group; alive record (M > 0)
+};
+
 template <int M>
-__global__ __launch_bounds__(256) void k_diffract(SceneView sc, const AliveRec *__restrict__ alive,
-                                                   const int32_t *__restrict__ edge_ids, int64_t count, int group,
-                                                   const double *__restrict__ edges, d3 tx,
-                                                   const double *__restrict__ rx, int64_t rx0, int64_t rx1, int rx_tile,
-                                                   Queues q) {
+__global__ void k_diffract_setup(const AliveRec *__restrict__ alive, const int32_t *__restrict__ edge_ids, int64_t count,
+                                 const double *__restrict__ edges, d3 tx, DiffSetup *__restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = idx < count;
-    int32_t cand = 0;
+    if (idx >= count) return;
+    int32_t cand = (int32_t)idx;
     d3 A = tx;
-    if (active) {
-        if (M == 0) {
-            cand = (int32_t)idx;
-        } else {
-            cand = alive[idx].cand;
-            A = ld3(alive[idx].pts + 3 * (M - 1));
-        }
+    if (M > 0) {
+        cand = alive[idx].cand;
+        A = ld3(alive[idx].pts + 3 * (M - 1));
     }
-    const double *e = edges + 6 * (size_t)(active ? edge_ids[cand] : 0);
+    const double *e = edges + 6 * (size_t)edge_ids[cand];
     const d3 P0 = ld3(e), P1 = ld3(e + 3);
-    // edge-aligned frame (geometry.py:736-742)
     d3 fx, fy, fz;
     frame_from_vector(P1 - P0, fx, fy, fz);
-    const double xe = dot(P0, fx), ye = dot(P0, fy), ze = dot(P0, fz), z1 = dot(P1, fz);
-    const double ax = dot(A, fx), ay = dot(A, fy), az = dot(A, fz);
-    const double rhoA = sqrt((xe - ax) * (xe - ax) + (ye - ay) * (ye - ay));
+    DiffSetup S;
+    st3(S.fx, fx);
+    st3(S.fy, fy);
+    st3(S.fz, fz);
+    S.xe = dot(P0, fx);
+    S.ye = dot(P0, fy);
+    S.ze = dot(P0, fz);
+    S.z1 = dot(P1, fz);
+    S.ax = dot(A, fx);
+    S.ay = dot(A, fy);
+    S.az = dot(A, fz);
+    S.rhoA = sqrt((S.xe - S.ax) * (S.xe - S.ax) + (S.ye - S.ay) * (S.ye - S.ay));
+    st3(S.A, A);
+    S.cand = cand;
+    S.src = (int32_t)idx;
+    out[idx] = S;
+}
 
-    const int64_t r_begin = rx0 + (int64_t)blockIdx.y * rx_tile;
-    const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
-    for (int64_t r = r_begin; r < r_end; ++r) {
-        const d3 R = ld3(rx + 3 * r);
-        const double bx = dot(R, fx), by = dot(R, fy), bz = dot(R, fz);
-        const double rhoB = sqrt((xe - bx) * (xe - bx) + (ye - by) * (ye - by));
-        const double sum = rhoA + rhoB;
-        // Keller cone: (z - zA)/|X - A| = (zB - z)/|B - X|  <=>  z = zA + (zB - zA) rhoA/(rhoA + rhoB)
-        const double z = az + (bz - az) * (rhoA / sum);
-        if (!(active && sum > 0.0 && z >= ze - 1e-6 && z <= z1 + 1e-6)) continue;
-        // back to world coordinates (geometry.py:746-748, 831)
-        const d3 D = (xe * fx + ye * fy) + z * fz;
-        // point_on_edge_ (geometry.py:470-479)
-        const double tol = 1e-8;
-        const double dx = dot(D, fx), dy = dot(D, fy), dz = dot(D, fz);
-        if (!(xe - tol <= dx && dx <= xe + tol && ye - tol <= dy && dy <= ye + tol && ze - tol <= dz && dz <= z1 + tol))
-            continue;
-        if (!(norm3(A - D) >= MIN_DISTANCE_TOL)) continue;  // ray_tracing.py:268-272 on lines[:-1]
-        int64_t ps, ss;
-        if (!reserve(q, 2, ps, ss)) continue;
-        PathRec &rec = q.paths[ps];
-        rec.rx = (int32_t)r;
+// The diffraction point of one (candidate, receiver) pair and its receiver-dependent checks.
+__device__ __forceinline__ bool keller_point(const DiffSetup &S, d3 R, d3 &D) {
+    const d3 fx = ld3(S.fx), fy = ld3(S.fy), fz = ld3(S.fz);
+    const double bx = dot(R, fx), by = dot(R, fy), bz = dot(R, fz);
+    const double rhoB = sqrt((S.xe - bx) * (S.xe - bx) + (S.ye - by) * (S.ye - by));
+    const double sum = S.rhoA + rhoB;
+    // Keller cone: (z - zA)/|X - A| = (zB - z)/|B - X|  <=>  z = zA + (zB - zA) rhoA/(rhoA + rhoB)
+    const double z = S.az + (bz - S.az) * (S.rhoA / sum);
+    if (!(sum > 0.0 && z >= S.ze - 1e-6 && z <= S.z1 + 1e-6)) return false;
+    // back to world coordinates (geometry.py:746-748, 831)
+    D = (S.xe * fx + S.ye * fy) + z * fz;
+    // point_on_edge_ (geometry.py:470-479)
+    const double tol = 1e-8;
+    const double dx = dot(D, fx), dy = dot(D, fy), dz = dot(D, fz);
+    if (!(S.xe - tol <= dx && dx <= S.xe + tol && S.ye - tol <= dy && dy <= S.ye + tol && S.ze - tol <= dz &&
+          dz <= S.z1 + tol))
+        return false;
+    return norm3(ld3(S.A) - D) >= MIN_DISTANCE_TOL;  // ray_tracing.py:268-272 on lines[:-1]
+}
+
+// Diffraction candidates: a block takes DIFF_CHUNK candidates and 256 receivers, lane = receiver, every lane of a wave
+// on the same candidate.  The pairs that survive are noted in LDS; the block then reserves room for all of them with
+// one pair of atomics and writes their records candidate by candidate, receiver by receiver: the segments leave in
+// fans (same edge point, neighbouring receivers), which is the order the obstruction kernel likes, first all
+// "point before -> edge" segments of a wave, then all "edge -> receiver" ones.
+#define DIFF_CHUNK 32
+template <int M>
+__global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ setup, const AliveRec *__restrict__ alive,
+                                                   int64_t count, int group, const double *__restrict__ rx, int64_t rx0,
+                                                   int64_t rx1, Queues q) {
+    __shared__ DiffSetup s_setup[DIFF_CHUNK];
+    __shared__ uint16_t s_list[4][DIFF_CHUNK * 64];
+    __shared__ int s_count[4];
+    __shared__ long long s_base[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c_begin = (int64_t)blockIdx.x * DIFF_CHUNK;
+    const int n_c = (int)(count - c_begin < DIFF_CHUNK ? count - c_begin : DIFF_CHUNK);
+    {
+        const double *src = (const double *)(setup + c_begin);
+        double *dst = (double *)s_setup;
+        const int n_words = n_c * (int)(sizeof(DiffSetup) / sizeof(double));
+        for (int i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t r_wave = rx0 + (int64_t)blockIdx.y * 256 + wave * 64;
+    const int64_t r = r_wave + lane;
+    const bool active = r < rx1;
+    const d3 R = ld3(rx + 3 * (active ? r : rx0));
+    uint16_t *list = s_list[wave];
+    int n = 0;  // wave-uniform
+    for (int c = 0; c < n_c; ++c) {
+        d3 D;
+        const bool ok = active && keller_point(s_setup[c], R, D);
+        const unsigned long long m = __ballot(ok);
+        if (ok) list[n + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((c << 6) | lane);
+        n += __popcll(m);
+    }
+    if (lane == 0) s_count[wave] = n;
+    __syncthreads();
+    const int total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+    if (total == 0) return;
+    if (threadIdx.x == 0) {
+        s_base[0] = (long long)atomicAdd(&q.counters[0], (unsigned long long)total);
+        s_base[1] = (long long)atomicAdd(&q.counters[1], 2ull * (unsigned long long)total);
+    }
+    __syncthreads();
+    if (s_base[0] + total > q.path_cap || s_base[1] + 2 * (long long)total > q.seg_cap) return;  // host redoes the chunk
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += s_count[w];
+    const int64_t p0 = s_base[0] + before, s0 = s_base[1] + 2 * (int64_t)before;
+    for (int j = lane; j < n; j += 64) {
+        const unsigned e = list[j];
+        const DiffSetup &S = s_setup[e >> 6];
+        const int64_t rr = r_wave + (e & 63u);
+        const d3 RR = ld3(rx + 3 * rr);
+        d3 D;
+        (void)keller_point(S, RR, D);
+        PathRec &rec = q.paths[p0 + j];
+        rec.rx = (int32_t)rr;
         rec.group = group;
-        rec.cand = cand;
+        rec.cand = S.cand;
         rec.nseg = 2;
-        rec.seg0 = ss;
-        for (int i = 0; i < M; ++i) st3(rec.pts + 3 * i, ld3(alive[idx].pts + 3 * i));
+        rec.seg0 = s0 + j;
+        rec.seg_stride = n;
+        if (M > 0) {
+            const AliveRec &al = alive[c_begin + (e >> 6)];
+            for (int i = 0; i < M; ++i) st3(rec.pts + 3 * i, ld3(al.pts + 3 * i));
+        }
         st3(rec.pts + 3 * M, D);
-        st3(q.segs + 6 * ss, A);
-        st3(q.segs + 6 * ss + 3, D);
-        st3(q.segs + 6 * (ss + 1), D);
-        st3(q.segs + 6 * (ss + 1) + 3, R);
+        st3(q.segs + 6 * (s0 + j), ld3(S.A));
+        st3(q.segs + 6 * (s0 + j) + 3, D);
+        st3(q.segs + 6 * (s0 + n + j), D);
+        st3(q.segs + 6 * (s0 + n + j) + 3, RR);
     }
 }
 
@@ -727,7 +828,7 @@ struct OutArrays {
 __global__ void k_los_finalize(const uint8_t *__restrict__ hit, int64_t rx0, int64_t n, OutArrays out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || hit[i]) return;
-    const int64_t slot = (int64_t)atomicAdd(out.count, 1ull);
+    const int64_t slot = (int64_t)wave_reserve(out.count, 1u);
     if (slot >= out.cap) return;
     out.rx[slot] = (int32_t)(rx0 + i);
     out.group[slot] = -1;
@@ -735,37 +836,82 @@ __global__ void k_los_finalize(const uint8_t *__restrict__ hit, int64_t rx0, int
     for (int k = 0; k < RT_MAX_ORDER * 3; ++k) out.pts[slot * RT_MAX_ORDER * 3 + k] = 0.0;
 }
 
-__global__ void k_finalize(const PathRec *__restrict__ paths, const uint8_t *__restrict__ hit, int64_t n, OutArrays out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PathRec &p = paths[i];
-    for (int k = 0; k < p.nseg; ++k)
-        if (hit[p.seg0 + k]) return;
-    const int64_t slot = (int64_t)atomicAdd(out.count, 1ull);
-    if (slot >= out.cap) return;
-    out.rx[slot] = p.rx;
-    out.group[slot] = p.group;
-    out.cand[slot] = p.cand;
-    for (int k = 0; k < RT_MAX_ORDER * 3; ++k) out.pts[slot * RT_MAX_ORDER * 3 + k] = p.pts[k];
+// Keeps the queued paths none of whose segments is obstructed.  counters[0], counters[1] = paths and segments the
+// producers asked for; when either exceeds its queue the records are incomplete and nothing is done (the host redoes
+// the chunk with larger queues).  A wave looks at 512 paths and reserves the room of its survivors with one atomic.
+#define FINALIZE_ITEMS 8
+__global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ paths, const uint8_t *__restrict__ hit,
+                                                   const unsigned long long *__restrict__ counters, int64_t path_cap,
+                                                   int64_t seg_cap, OutArrays out) {
+    const unsigned long long np = counters[0], ns = counters[1];
+    if (np > (unsigned long long)path_cap || ns > (unsigned long long)seg_cap) return;
+    const int64_t n = (int64_t)np;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t base = wave_id * 64 * FINALIZE_ITEMS; base < n; base += n_waves * 64 * FINALIZE_ITEMS) {
+        bool keep[FINALIZE_ITEMS];
+        int before[FINALIZE_ITEMS];
+        int total = 0;
+#pragma unroll
+        for (int j = 0; j < FINALIZE_ITEMS; ++j) {
+            const int64_t i = base + j * 64 + lane;
+            bool ok = i < n;
+            if (ok) {
+                const PathRec &p = paths[i];
+                for (int k = 0; k < p.nseg; ++k) ok = ok && !hit[p.seg0 + k * p.seg_stride];
+            }
+            keep[j] = ok;
+            const unsigned long long m = __ballot(ok);
+            before[j] = total + __popcll(m & ((1ull << lane) - 1));
+            total += __popcll(m);
+        }
+        if (total == 0) continue;
+        unsigned long long slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(out.count, (unsigned long long)total);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)slot0);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(slot0 >> 32));
+        slot0 = ((unsigned long long)hi << 32) | lo;
+#pragma unroll
+        for (int j = 0; j < FINALIZE_ITEMS; ++j) {
+            if (!keep[j]) continue;
+            const int64_t slot = (int64_t)slot0 + before[j];
+            if (slot >= out.cap) continue;
+            const PathRec &p = paths[base + j * 64 + lane];
+            out.rx[slot] = p.rx;
+            out.group[slot] = p.group;
+            out.cand[slot] = p.cand;
+            for (int k = 0; k < RT_MAX_ORDER * 3; ++k) out.pts[slot * RT_MAX_ORDER * 3 + k] = p.pts[k];
+        }
+    }
 }
+
+__global__ void k_set_counter(unsigned long long *c, unsigned long long v) { *c = v; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // solve host side
 // ---------------------------------------------------------------------------------------------------------------
 
 struct EventTimer {
-    hipStream_t st;
+    rt_scene *sc;
     std::vector<hipEvent_t> ev[4];
-    explicit EventTimer(hipStream_t s) : st(s) {}
+    explicit EventTimer(rt_scene *s) : sc(s) { sc->events_used = 0; }
+    hipEvent_t take() {
+        if (sc->events_used == sc->event_pool.size()) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreate(&e);
+            sc->event_pool.push_back(e);
+        }
+        return sc->event_pool[sc->events_used++];
+    }
     void begin(int fam) {
-        hipEvent_t a, b;
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, st);
+        hipEvent_t a = take(), b = take();
+        (void)hipEventRecord(a, sc->stream);
         ev[fam].push_back(a);
         ev[fam].push_back(b);
     }
-    void end(int fam) { (void)hipEventRecord(ev[fam].back(), st); }
+    void end(int fam) { (void)hipEventRecord(ev[fam].back(), sc->stream); }
+    // after the stream has been synchronised
     void collect(double *ms, int64_t *launches) {
         for (int f = 0; f < 4; ++f) {
             ms[f] = 0;
@@ -774,9 +920,9 @@ struct EventTimer {
                 float t = 0;
                 if (hipEventElapsedTime(&t, ev[f][i], ev[f][i + 1]) == hipSuccess) ms[f] += t;
             }
-            for (hipEvent_t e : ev[f]) (void)hipEventDestroy(e);
             ev[f].clear();
         }
+        sc->events_used = 0;
     }
 };
 
@@ -789,12 +935,17 @@ static void launch_reflect(rt_scene *s, const CandGroup &g, int group, d3 tx, co
 }
 
 template <int M>
-static void launch_diffract(rt_scene *s, const AliveRec *alive, const int32_t *edge_ids, int64_t count, int group,
-                            const double *edges, d3 tx, const double *rx, int64_t rx0, int64_t rx1, int rx_tile,
-                            const Queues &q) {
-    dim3 grid(blocks_for(count, 256), blocks_for(rx1 - rx0, rx_tile));
-    hipLaunchKernelGGL(k_diffract<M>, grid, dim3(256), 0, s->stream, s->view, alive, edge_ids, count, group, edges, tx,
-                       rx, rx0, rx1, rx_tile, q);
+static void launch_diffract(rt_scene *s, const DiffSetup *setup, const AliveRec *alive, int64_t count, int group,
+                            const double *rx, int64_t rx0, int64_t rx1, const Queues &q) {
+    dim3 grid(blocks_for(count, DIFF_CHUNK), blocks_for(rx1 - rx0, 256));
+    hipLaunchKernelGGL(k_diffract<M>, grid, dim3(256), 0, s->stream, setup, alive, count, group, rx, rx0, rx1, q);
+}
+
+template <int M>
+static void launch_diffract_setup(rt_scene *s, const AliveRec *alive, const int32_t *edge_ids, int64_t count,
+                                  const double *edges, d3 tx, DiffSetup *out) {
+    hipLaunchKernelGGL(k_diffract_setup<M>, dim3(blocks_for(count, 256)), dim3(256), 0, s->stream, alive, edge_ids, count,
+                       edges, tx, out);
 }
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -855,8 +1006,8 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         return -1;                                                     \
     }
 
-    unsigned long long *d_counters = (unsigned long long *)temp_alloc(sizeof(unsigned long long) * 8);
-    SOLVE_PTR(d_counters);
+    unsigned long long *d_counters = scene->d_counters;  // 0 paths, 1 segments, 2 results, 4-5 pre-pass
+    unsigned long long *h_counters = scene->h_counters;
     SOLVE_HIP(hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 8, st));
     if (on_device) {
         out.rx = out_rx;
@@ -880,7 +1031,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     out.cap = capacity;
     out.count = d_counters + 2;
 
-    EventTimer timer(st);
+    EventTimer timer(scene);
 
     // ---- receiver-independent half of the reflection+diffraction groups -------------------------------------
     const int mo = cand->max_order;
@@ -912,7 +1063,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_HIP(hipStreamSynchronize(st));
         if (n0 == 0) continue;
         timer.begin(2);
-        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, hit)) {
+        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, hit, nullptr, 0)) {
             free_temps();
             return -1;
         }
@@ -932,12 +1083,43 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         alive_count[m] = (int64_t)n1;
     }
 
+    // ---- receiver-independent part of every diffraction candidate (edge frames) ------------------------------
+    std::vector<DiffSetup *> diff_setup(mo, nullptr);
+    std::vector<int64_t> diff_count(mo, 0);
+    bool any_diffraction = false;
+    for (int m = 0; m < mo; ++m) {
+        const CandGroup &g = cand->groups[mo + m];
+        const int64_t cnt = m == 0 ? g.count : alive_count[m];
+        diff_count[m] = cnt;
+        if (cnt == 0) continue;
+        any_diffraction = true;
+        diff_setup[m] = (DiffSetup *)temp_alloc(sizeof(DiffSetup) * cnt);
+        SOLVE_PTR(diff_setup[m]);
+        timer.begin(1);
+        switch (m) {
+            case 0: launch_diffract_setup<0>(scene, nullptr, g.edge_ids, cnt, cand->d_edges, TX, diff_setup[m]); break;
+            case 1: launch_diffract_setup<1>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, TX, diff_setup[m]); break;
+            case 2: launch_diffract_setup<2>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, TX, diff_setup[m]); break;
+            default: launch_diffract_setup<3>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, TX, diff_setup[m]); break;
+        }
+        timer.end(1);
+    }
+
     // ---- receivers, in chunks whose survivors fit the workspace ---------------------------------------------
+    // One host synchronisation per chunk: the kernels after the candidate kernels take their sizes from the device
+    // counters (their grids are sized from what the previous call needed and stride over the rest), and the host
+    // reads the counters once at the end of the chunk.
     int64_t chunk = n_rx;
     const int64_t max_pairs_per_launch = 1ll << 36;
     if (total_cand > 0 && chunk * total_cand > max_pairs_per_launch) chunk = std::max<int64_t>(1, max_pairs_per_launch / total_cand);
     int64_t path_cap = std::max<int64_t>(1 << 16, std::min<int64_t>(chunk * std::max<int64_t>(total_cand, 1) / 64 + 4096, 1ll << 26));
-    const int rx_tile = 32;
+    path_cap = std::max<int64_t>(path_cap, scene->hint_paths + scene->hint_paths / 8);
+    // receivers per block of a candidate kernel: few enough that the launch has several waves per SIMD
+    int64_t cand_blocks = 0;
+    for (const CandGroup &g : cand->groups) cand_blocks += blocks_for(g.count, 256);
+    int rx_tile = (int)std::min<int64_t>(32, std::max<int64_t>(4, chunk * std::max<int64_t>(cand_blocks, 1) / 4096));
+    rx_tile &= ~3;
+    unsigned long long found_before = 0;
 
     for (int64_t r0 = 0; r0 < n_rx;) {
         const int64_t r1 = std::min(n_rx, r0 + chunk);
@@ -967,12 +1149,11 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         hipLaunchKernelGGL(k_los_segments, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, d_lsegs);
         timer.end(3);
         timer.begin(2);
-        if (rt_launch_obstruct(scene, d_lsegs, nr, cand->d_ev, d_lhits)) {
+        if (rt_launch_obstruct(scene, d_lsegs, nr, cand->d_ev, d_lhits, nullptr, 0)) {
             free_temps();
             return -1;
         }
         timer.end(2);
-        scene->last_segments += nr;
         timer.begin(3);
         hipLaunchKernelGGL(k_los_finalize, dim3(blocks_for(nr, 256)), dim3(256), 0, st, d_lhits, r0, nr, out);
         timer.end(3);
@@ -991,58 +1172,52 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         }
         timer.end(0);
         // diffractions
-        timer.begin(1);
-        for (int m = 0; m < mo; ++m) {
-            const CandGroup &g = cand->groups[mo + m];
-            const int64_t cnt = m == 0 ? g.count : alive_count[m];
-            if (cnt == 0) continue;
-            switch (m) {
-                case 0: launch_diffract<0>(scene, nullptr, g.edge_ids, cnt, mo + m, cand->d_edges, TX, d_rx, r0, r1, rx_tile, q); break;
-                case 1: launch_diffract<1>(scene, alive[m], g.edge_ids, cnt, mo + m, cand->d_edges, TX, d_rx, r0, r1, rx_tile, q); break;
-                case 2: launch_diffract<2>(scene, alive[m], g.edge_ids, cnt, mo + m, cand->d_edges, TX, d_rx, r0, r1, rx_tile, q); break;
-                default: launch_diffract<3>(scene, alive[m], g.edge_ids, cnt, mo + m, cand->d_edges, TX, d_rx, r0, r1, rx_tile, q); break;
+        if (any_diffraction) {
+            timer.begin(1);
+            for (int m = 0; m < mo; ++m) {
+                const int64_t cnt = diff_count[m];
+                if (cnt == 0) continue;
+                switch (m) {
+                    case 0: launch_diffract<0>(scene, diff_setup[m], nullptr, cnt, mo + m, d_rx, r0, r1, q); break;
+                    case 1: launch_diffract<1>(scene, diff_setup[m], alive[m], cnt, mo + m, d_rx, r0, r1, q); break;
+                    case 2: launch_diffract<2>(scene, diff_setup[m], alive[m], cnt, mo + m, d_rx, r0, r1, q); break;
+                    default: launch_diffract<3>(scene, diff_setup[m], alive[m], cnt, mo + m, d_rx, r0, r1, q); break;
+                }
             }
+            timer.end(1);
         }
-        timer.end(1);
-        unsigned long long counts[2] = {0, 0};
-        SOLVE_HIP(hipMemcpyAsync(counts, d_counters, sizeof(counts), hipMemcpyDeviceToHost, st));
+        // obstruction of the queued segments and the final filter, sized on the device
+        const int64_t seg_hint = scene->hint_segments > 0 ? scene->hint_segments : std::min<int64_t>(seg_cap, 1 << 22);
+        const int64_t path_hint = scene->hint_paths > 0 ? scene->hint_paths : std::min<int64_t>(path_cap, 1 << 21);
+        timer.begin(2);
+        if (rt_launch_obstruct(scene, q.segs, seg_cap, nullptr, d_hits, d_counters + 1, seg_hint)) {
+            free_temps();
+            return -1;
+        }
+        timer.end(2);
+        timer.begin(3);
+        hipLaunchKernelGGL(k_finalize, dim3(std::min<unsigned>(blocks_for(path_hint, 256 * FINALIZE_ITEMS), 1u << 16)), dim3(256), 0, st, q.paths,
+                           d_hits, d_counters, path_cap, seg_cap, out);
+        timer.end(3);
+        SOLVE_HIP(hipMemcpyAsync(h_counters, d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         SOLVE_HIP(hipStreamSynchronize(st));
         SOLVE_HIP(hipGetLastError());
-        if ((int64_t)counts[0] > path_cap || (int64_t)counts[1] > seg_cap) {
-            // survivors did not fit: grow the queues and redo this chunk (nothing of it has reached the outputs
-            // except its line-of-sight paths, which are taken back)
-            const int64_t need = std::max<int64_t>((int64_t)counts[0], ((int64_t)counts[1] + 2) / 3);
+        const int64_t n_paths = (int64_t)h_counters[0], n_segs = (int64_t)h_counters[1];
+        if (n_paths > path_cap || n_segs > seg_cap) {
+            // survivors did not fit: nothing of this chunk but its lines of sight reached the outputs; take those
+            // back, grow the queues and redo the chunk
+            const int64_t need = std::max<int64_t>(n_paths, (n_segs + 2) / 3);
             path_cap = need + need / 8 + 1024;
-            unsigned long long found = 0;
-            SOLVE_HIP(hipMemcpy(&found, out.count, sizeof(found), hipMemcpyDeviceToHost));
-            // count LOS paths of this chunk to roll the cursor back
-            std::vector<uint8_t> lh(nr);
-            SOLVE_HIP(hipMemcpy(lh.data(), d_lhits, nr, hipMemcpyDeviceToHost));
-            unsigned long long los_n = 0;
-            for (uint8_t h : lh) los_n += h ? 0 : 1;
-            found -= los_n;
-            SOLVE_HIP(hipMemcpy(out.count, &found, sizeof(found), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, out.count, found_before);
             continue;
         }
-        const int64_t n_paths = (int64_t)counts[0], n_segs = (int64_t)counts[1];
-        if (n_segs > 0) {
-            timer.begin(2);
-            if (rt_launch_obstruct(scene, q.segs, n_segs, nullptr, d_hits)) {
-                free_temps();
-                return -1;
-            }
-            timer.end(2);
-            scene->last_segments += n_segs;
-            timer.begin(3);
-            hipLaunchKernelGGL(k_finalize, dim3(blocks_for(n_paths, 256)), dim3(256), 0, st, q.paths, d_hits, n_paths, out);
-            timer.end(3);
-        }
+        found_before = h_counters[2];
+        scene->hint_paths = std::max<int64_t>(n_paths, 1);
+        scene->hint_segments = std::max<int64_t>(n_segs, 1);
+        scene->last_segments += nr + n_segs;
         r0 = r1;
     }
-    unsigned long long found = 0;
-    SOLVE_HIP(hipMemcpyAsync(&found, out.count, sizeof(found), hipMemcpyDeviceToHost, st));
-    SOLVE_HIP(hipStreamSynchronize(st));
-    SOLVE_HIP(hipGetLastError());
+    const unsigned long long found = found_before;
     *n_found = (int64_t)found;
     if (!on_device) {
         const int64_t m = std::min<int64_t>((int64_t)found, capacity);

@@ -11,13 +11,18 @@ name = sys.argv[1]
 order = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 n_side = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 diff = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-place = geom.load_place(f"data/{name}.geojson")
+import os
+path = f"data/{name}.geojson"
+if not os.path.exists(path):
+    path = f"data/{name}/{name}.geojson"
+place = geom.load_place(path)
 lo, hi = place.get_domain()
 tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
 rx = scenarios.lattice_receivers(place, n_side, 1.5)
 polygons = place.get_polygons_list()
 print(name, "polygons", len(polygons), "rx", len(rx), flush=True)
 scene = _lib.Scene(geom.scene_arrays_of(polygons))
+scene.set_occlusion_mode(int(os.environ.get("RT_OCC_MODE", "0")))
 t = time.time(); pairs, edges = scene.sharp_edges(); print("sharp edges", len(pairs), f"{time.time()-t:.3f}s", flush=True)
 t = time.time(); vis = scene.visibility_matrix(False); print("visibility", int(vis.sum()), f"{time.time()-t:.3f}s", flush=True)
 cube = geom.Cube.by_point_and_side_length(tx, 0.2)

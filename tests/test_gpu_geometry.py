@@ -43,6 +43,54 @@ def test_obstruction_matches_oracle(places, name, n):
         assert list(np.flatnonzero(h)) == go.polygons_obstruct_line_path(polys, s.reshape(2, 3), return_indices=True)
 
 
+def awkward_segments(place, n, seed):
+    """Segments that stress the grid walk: axis-aligned, vertical, along cell borders, far outside the scene, very
+    long, very short, ending on polygon vertices."""
+    rng = np.random.default_rng(seed)
+    lo, hi = place.get_domain()
+    ext = hi - lo
+    segs = [random_segments(place, n, seed)]
+    a = rng.uniform(lo, hi + [0, 0, 10], size=(n, 3))
+    for axis in range(3):  # axis-aligned
+        b = a.copy()
+        b[:, axis] = rng.uniform(lo[axis] - 5, hi[axis] + 15, size=n)
+        segs.append(np.concatenate([a, b], axis=1))
+    far = a + rng.normal(size=(n, 3)) * ext * 20  # one end far outside the scene
+    segs.append(np.concatenate([far, a], axis=1))
+    segs.append(np.concatenate([a + ext * 30, far + ext * 30], axis=1))  # entirely outside
+    tiny = a + rng.normal(size=(n, 3)) * 1e-3
+    segs.append(np.concatenate([a, tiny], axis=1))
+    verts = np.concatenate([p.points for p in place.get_polygons_list()])
+    pick = verts[rng.integers(0, len(verts), size=n)]
+    segs.append(np.concatenate([a, pick], axis=1))  # ending on a polygon vertex
+    segs.append(np.concatenate([pick + [0, 0, 30.0], pick - [0, 0, 30.0]], axis=1))  # down a building edge
+    pick2 = verts[rng.integers(0, len(verts), size=n)]
+    segs.append(np.concatenate([pick2 + [0, 0, 0.5], pick + [0, 0, 0.5]], axis=1))  # vertex to vertex, lifted
+    return np.concatenate(segs)
+
+
+@pytest.mark.parametrize("name,n", [("small", 300), ("place_levant", 500), ("place_saint_jean/place_saint_jean", 2000),
+                                    ("lln", 3000)])
+def test_obstruction_grid_walk_equals_every_polygon_walk(places, name, n):
+    """The obstruction kernel walks a uniform grid; the flags must be those of the walk over every polygon."""
+    from raytracing_amd import geometry as geom
+
+    place = places(name)
+    scene = geom.scene_arrays_of(place.get_polygons_list()).device_scene()
+    segs = awkward_segments(place, n, 7)
+    mask = np.zeros(scene.n, dtype=bool)
+    mask[::2] = True
+    try:
+        scene.set_occlusion_mode(1)
+        want, want_masked = scene.obstructed(segs), scene.obstructed(segs, mask=mask)
+    finally:
+        scene.set_occlusion_mode(0)
+    got, got_masked = scene.obstructed(segs), scene.obstructed(segs, mask=mask)
+    assert want.sum() > n // 10 and (~want).sum() > n // 10
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got_masked, want_masked)
+
+
 def test_obstruction_api_and_edge_cases(places):
     from raytracing_amd import geometry as geom
 
