@@ -22,6 +22,69 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (half the 157.3 TFLOP/s fp32 vector rate)
+HBM_PEAK_GBS = 8000.0
+
+
+def measured_traffic(family):
+    """HBM bytes per launch of the family's kernels from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
+    collected in separate rocprofv3 runs of this script; scripts/pmc_traffic.py turns them into this file)."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(family)
+    except (OSError, ValueError):
+        return None
+
+
+def large_workload(local_rank, dev):
+    """The same solve on a coverage-map-sized batch: lln.geojson, one emitter, 100x100 receivers, reflections and
+    diffractions up to order 2 (config 3 of BASELINE.json on one GPU).  Reported beside the headline, not as it."""
+    import torch
+
+    from raytracing_amd import _lib, scenarios
+    from raytracing_amd import geometry as geom
+
+    t0 = time.perf_counter()
+    place, tx, rx = scenarios.lln_grid(100)
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons), device=local_rank)
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.zeros(len(polygons), dtype=bool)
+    for v in scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False):
+        ev |= v
+    cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+    precompute_s = time.perf_counter() - t0
+    n_rx = len(rx)
+    d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
+    cap = 1 << 21
+    o_rx = torch.empty(cap, dtype=torch.int32, device=dev)
+    o_group = torch.empty_like(o_rx)
+    o_cand = torch.empty_like(o_rx)
+    o_pts = torch.empty((cap, _lib.RT_MAX_ORDER, 3), dtype=torch.float64, device=dev)
+    best, timing, found, attempted = None, None, 0, 0
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        found, attempted = scene.solve_paths_device(cand, tx, d_rx.data_ptr(), n_rx, o_rx.data_ptr(), o_group.data_ptr(),
+                                                    o_cand.data_ptr(), o_pts.data_ptr(), cap)
+        dt = time.perf_counter() - t
+        if best is None or dt < best:
+            best, timing = dt, scene.last_timing()
+    counts = [int(c) for c in cand.counts]
+    mo = cand.max_order
+    reflect_flop = 40.0 * n_rx * sum((g + 1) * counts[g] for g in range(mo))
+    out = {"workload": f"lln.geojson ({len(polygons)} polygons), 1 TX, 100x100 RX, reflections+diffractions up to order 2",
+           "precompute_s": round(precompute_s, 3), "solve_ms": 1e3 * best, "path_solves": int(attempted),
+           "path_solves_per_s": attempted / best, "valid_paths": int(found), "candidates": counts,
+           "segments": int(timing["segments"]), "kernel_ms": {k: float(v) for k, v in timing["ms"].items()},
+           "reflect_tflops_fp64": reflect_flop / (timing["ms"]["reflect"] * 1e-3) / 1e12,
+           "reflect_frac_of_fp64_vector_peak": reflect_flop / (timing["ms"]["reflect"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+           "obstruct_segments_per_s": timing["segments"] / (timing["ms"]["obstruct"] * 1e-3)}
+    cand.close()
+    scene.close()
+    return out
 
 
 def cpu_baseline_worker(args):
@@ -80,6 +143,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the coverage-map-sized extra measurement")
     ap.add_argument("--n-side", type=int, default=32)
     args = ap.parse_args()
 
@@ -166,16 +230,39 @@ def main():
     if rank == 0:
         n_poly = len(polygons)
         pairs = n_rx * cand.total
-        # algorithmic work per launch: obstruction = 13 flop per (segment, polygon); candidate kernels = 40 flop per
-        # interaction of every (receiver, candidate) pair
-        flops = {
-            "obstruct": 13.0 * n_poly * segments / max(1, args.steps),
-            "reflect": 40.0 * float(n_rx) * sum((g + 1) * int(cand.counts[g]) for g in range(cand.max_order)),
+        steps = max(1, args.steps)
+        ms = {k: fam_ms[k] / steps for k in fam_ms}
+        launches = {k: fam_launches[k] / steps for k in fam_ms}
+        seg_per_step = segments / steps
+        # algorithmic work per step.  Candidate kernels: 40 flop per interaction of every (receiver, candidate) pair
+        # (mirror image, plane crossing, containment and spacing checks).  Obstruction: every segment is read once
+        # (48 B) and its flag written once (1 B); the scene's pre-test records (64 B per polygon) and vertices are
+        # read once per launch.
+        reflect_flop = 40.0 * float(n_rx) * sum((g + 1) * int(cand.counts[g]) for g in range(cand.max_order))
+        scene_bytes = 64.0 * n_poly + 24.0 * int(arrays.verts.shape[0])
+        obstruct_bytes = 49.0 * seg_per_step + scene_bytes * launches["obstruct"]
+        by_kernel = {
+            "reflect": {"kernel": "k_reflect<1>+k_reflect<2>", "bound": "valu_fp64",
+                        "achieved": reflect_flop / (ms["reflect"] * 1e-3) / 1e12 if ms["reflect"] > 0 else 0.0,
+                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "ms_per_step": ms["reflect"],
+                        "launches_per_step": launches["reflect"], "algorithmic_flop_per_step": reflect_flop},
+            "obstruct": {"kernel": "k_obstruct<false>+k_obstruct<true>", "bound": "hbm",
+                         "achieved": obstruct_bytes / (ms["obstruct"] * 1e-3) / 1e9 if ms["obstruct"] > 0 else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": ms["obstruct"],
+                         "launches_per_step": launches["obstruct"], "algorithmic_bytes_per_step": obstruct_bytes,
+                         "segment_polygon_tests_per_s": seg_per_step * n_poly / (ms["obstruct"] * 1e-3)
+                         if ms["obstruct"] > 0 else 0.0},
         }
-        dominant = max(("reflect", "obstruct"), key=lambda k: fam_ms[k])
-        per_step_ms = fam_ms[dominant] / args.steps
-        achieved = flops[dominant] / (per_step_ms * 1e-3) / 1e12 if per_step_ms > 0 else 0.0
-        kernel_names = {"reflect": "k_reflect<1>+k_reflect<2>", "obstruct": "k_obstruct"}
+        for v in by_kernel.values():
+            v["frac"] = v["achieved"] / v["peak"]
+        dominant = max(by_kernel, key=lambda k: by_kernel[k]["ms_per_step"])
+        roof = dict(by_kernel[dominant])
+        detail = measured_traffic(dominant)
+        roof["traffic"] = detail["bytes_per_launch"] if detail else None
+        roof["traffic_detail"] = detail
+        roof["achieved_per_launch_basis"] = "algorithmic bytes (or flop) per step / launches per step / mean launch time"
+        roof["note"] = ("launch- and latency-bound at this size (a step is ~10 launches of 2-40 us over 3 M pairs); "
+                        "see large_workload for the same kernels on a coverage-map-sized batch")
         out = {
             "metric": "path-solves/sec (RX x candidate paths, whole node)",
             "value": attempted_all * args.steps / elapsed,
@@ -194,14 +281,14 @@ def main():
                        "receivers_per_gpu": n_rx, "candidates_per_receiver": 1 + cand.total,
                        "candidates_by_order": [int(c) for c in cand.counts[:cand.max_order]],
                        "valid_paths_all_gpus": paths_all, "precompute_s": round(precompute_s, 3)},
-            "roofline": {"bound": "valu_fp64", "kernel": kernel_names[dominant], "achieved": achieved,
-                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                         "ms_per_step_by_kernel": {k: fam_ms[k] / args.steps for k in fam_ms},
-                         "launches_per_step": {k: fam_launches[k] / args.steps for k in fam_ms},
-                         "algorithmic_flop_per_step": flops, "segments_per_step": segments / args.steps,
-                         "pairs_per_step": pairs},
+            "roofline": roof,
+            "roofline_by_kernel": by_kernel,
+            "kernel_ms_per_step": ms,
+            "segments_per_step": seg_per_step,
+            "pairs_per_step": pairs,
         }
+        if not args.no_large and world == 1:
+            out["large_workload"] = large_workload(local_rank, dev)
         if not args.no_cpu_baseline and world == 1:
             chains2, _ = cand.group(1)
             out["cpu_baseline"] = cpu_baseline(place, tx, rx, chains2)

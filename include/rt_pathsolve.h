@@ -65,9 +65,9 @@ int rt_face_visibility(rt_scene *scene, const double *face_verts, int32_t n_face
 int rt_faces_visibility(rt_scene *scene, int32_t n_faces, const int32_t *face_off, const double *face_verts,
                         const double *face_normals, const int32_t *self_index, int strict, uint8_t *out);
 int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_device);
-/* Obstruction tests walk a uniform grid over the scene (mode 0, the default); mode 1 tests every polygon instead.
- * Both give the same flags; the switch exists so that tests can check one against the other (no reference
- * counterpart). */
+/* Obstruction tests either walk every polygon (mode 1) or a uniform grid over the scene (mode 2); mode 0, the
+ * default, picks by scene size.  Both give the same flags; the switch exists so that tests can check one against the
+ * other (no reference counterpart). */
 int rt_debug_set_occlusion_mode(rt_scene *scene, int mode);
 /* Work counters of the visibility painter accumulated since the last call, then zeroed (profiling aid, no reference
  * counterpart): candidates, listed canvas polygons, canvas edges entering a candidate, edge cuts, candidates settled by

@@ -233,7 +233,7 @@ class Scene:
         return out.astype(bool)
 
     def set_occlusion_mode(self, mode):
-        """0: obstruction tests walk the scene's grid (default); 1: they test every polygon (cross-check)."""
+        """0: obstruction kernel chosen by scene size (default); 1: every-polygon walk; 2: grid walk."""
         _check(load().rt_debug_set_occlusion_mode(self.handle, int(mode)), "rt_debug_set_occlusion_mode")
 
     def faces_visibility(self, faces, strict=False):

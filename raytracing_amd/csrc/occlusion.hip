@@ -31,13 +31,31 @@ __device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double
     }
 }
 
-// n_dev, when given, holds the segment count on the device (clamped to n_cap; a count above n_cap means the producer
-// overflowed its queue and the launch does nothing).
+__device__ __forceinline__ bool occ_pretest(const OccRec *__restrict__ r, const SceneView &sc, d3 A, d3 V, double pad) {
+    const double nx = r->nx, ny = r->ny, nz = r->nz, d = r->d;
+    const double den = V.x * nx + V.y * ny + V.z * nz;
+    const double num = d + (A.x * nx + A.y * ny + A.z * nz);
+    const double ad = fabs(den);
+    const double sn = den < 0.0 ? num : -num;
+    bool cand = sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
+    const double t = sn * fast_rcp(ad);
+    const double hx = A.x + t * V.x - sc.gx0, hy = A.y + t * V.y - sc.gy0, hz = A.z + t * V.z - sc.gz0;
+    return cand && hx >= (double)r->lo[0] - pad && hx <= (double)r->hi[0] + pad && hy >= (double)r->lo[1] - pad &&
+           hy <= (double)r->hi[1] + pad && hz >= (double)r->lo[2] - pad && hz <= (double)r->hi[2] + pad;
+}
+
+// Every-polygon walk.  n_dev, when given, holds the segment count on the device (clamped to n_cap; a count above n_cap
+// means the producer overflowed its queue and the launch does nothing).  The block stages the pre-test records of its
+// polygon range through LDS, OBS_STAGE at a time, so the inner loop reads them at LDS latency.
+#define OBS_STAGE 128
+#define RT_GRID_MIN_POLYGONS 512
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__restrict__ segs, int64_t n_cap,
                                                    const unsigned long long *__restrict__ n_dev,
                                                    const uint8_t *__restrict__ mask, int poly_chunk,
                                                    uint8_t *__restrict__ out) {
+    __shared__ OccRec s_rec[OBS_STAGE];
+    __shared__ uint8_t s_mask[OBS_STAGE];
     __shared__ uint32_t wave_queue[4][128];
     __shared__ uint8_t wave_hits[4][64];
     int64_t n_seg = n_cap;
@@ -63,48 +81,49 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
         const d3 V = B - A;
         const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
         bool hit = false;
-        int qn = 0;  // wave-uniform
+        bool wave_done = !__any(active);  // wave-uniform
+        int qn = 0;                       // wave-uniform
         wave_hit[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        for (int p = p_begin; p < p_end; ++p) {
-            if (MASKED) {
-                if (!mask[p]) continue;  // wave-uniform
+        for (int p0 = p_begin; p0 < p_end; p0 += OBS_STAGE) {
+            if (__syncthreads_and(wave_done)) break;  // also: the previous stage has been consumed
+            const int cnt = p_end - p0 < OBS_STAGE ? p_end - p0 : OBS_STAGE;
+            {
+                const uint4 *src = (const uint4 *)(sc.poly_recs + p0);
+                uint4 *dst = (uint4 *)s_rec;
+                for (int i = threadIdx.x; i < cnt * 4; i += blockDim.x) dst[i] = src[i];
+                if (MASKED) {
+                    for (int i = threadIdx.x; i < cnt; i += blockDim.x) s_mask[i] = mask[p0 + i];
+                }
             }
-            const double *pl = sc.planes + 4 * (size_t)p;
-            const double *bb = sc.bbox + 6 * (size_t)p;
-            const double nx = pl[0], ny = pl[1], nz = pl[2], d = pl[3];
-            const double den = V.x * nx + V.y * ny + V.z * nz;
-            const double num = d + (A.x * nx + A.y * ny + A.z * nz);
-            // t = -num/den must lie in (1e-8, 1 - 1e-8); compared without dividing, with room for rounding (1e-11 is
-            // far above the error of num for coordinates of a few km and far below 1e-8 |den| unless the segment
-            // grazes the plane): a segment that merely starts or ends on the polygon is rejected here
-            const double ad = fabs(den);
-            const double sn = den < 0.0 ? num : -num;
-            bool cand = active && !hit && sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
-            const double t = sn * fast_rcp(ad);
-            const double hx = A.x + t * V.x, hy = A.y + t * V.y, hz = A.z + t * V.z;
-            cand = cand && hx >= bb[0] - pad && hx <= bb[3] + pad && hy >= bb[1] - pad && hy <= bb[4] + pad &&
-                   hz >= bb[2] - pad && hz <= bb[5] + pad;
-            // pairs that pass the padded pre-test are parked and examined exactly 64 at a time, all lanes busy
-            const unsigned long long m = __ballot(cand);
-            if (m != 0) {
-                if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)(p - p_begin) << 6) | (uint32_t)lane;
-                qn += __popcll(m);
-                __builtin_amdgcn_wave_barrier();
-                if (qn >= 64) {
-                    qn -= 64;
-                    obstruct_drain(sc, segs, s_base, p_begin, wq + qn, 64, lane, wave_hit, out);
+            __syncthreads();
+            if (wave_done) continue;
+            for (int r = 0; r < cnt; ++r) {
+                if (MASKED) {
+                    if (!s_mask[r]) continue;  // wave-uniform
+                }
+                const bool cand = active && !hit && occ_pretest(&s_rec[r], sc, A, V, pad);
+                // pairs that pass the padded pre-test are parked and examined exactly 64 at a time, all lanes busy
+                const unsigned long long m = __ballot(cand);
+                if (m != 0) {
+                    if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)(p0 + r - p_begin) << 6) | (uint32_t)lane;
+                    qn += __popcll(m);
                     __builtin_amdgcn_wave_barrier();
-                    hit = wave_hit[lane] != 0;
-                    if (__all(hit || !active)) {
-                        qn = 0;
-                        break;
+                    if (qn >= 64) {
+                        qn -= 64;
+                        obstruct_drain(sc, segs, s_base, p_begin, wq + qn, 64, lane, wave_hit, out);
+                        __builtin_amdgcn_wave_barrier();
+                        hit = wave_hit[lane] != 0;
+                        if (__all(hit || !active)) {
+                            qn = 0;
+                            wave_done = true;
+                            break;
+                        }
                     }
                 }
             }
         }
         if (qn > 0) obstruct_drain(sc, segs, s_base, p_begin, wq, qn, lane, wave_hit, out);
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();  // the staging buffer is free again
     }
 }
 
@@ -117,19 +136,6 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
 // and the parked exact tests are the every-polygon kernel's.  The polygons too large for the grid (the ground) are
 // tested first by every segment.  Every polygon the exact test could flag has its crossing point inside its own
 // padded box, hence inside a cell it is registered in, and that cell is on the segment's walk.
-__device__ __forceinline__ bool occ_pretest(const OccRec *__restrict__ r, const SceneView &sc, d3 A, d3 V, double pad) {
-    const double nx = r->nx, ny = r->ny, nz = r->nz, d = r->d;
-    const double den = V.x * nx + V.y * ny + V.z * nz;
-    const double num = d + (A.x * nx + A.y * ny + A.z * nz);
-    const double ad = fabs(den);
-    const double sn = den < 0.0 ? num : -num;
-    bool cand = sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
-    const double t = sn * fast_rcp(ad);
-    const double hx = A.x + t * V.x - sc.gx0, hy = A.y + t * V.y - sc.gy0, hz = A.z + t * V.z - sc.gz0;
-    return cand && hx >= (double)r->lo[0] - pad && hx <= (double)r->hi[0] + pad && hy >= (double)r->lo[1] - pad &&
-           hy <= (double)r->hi[1] + pad && hz >= (double)r->lo[2] - pad && hz <= (double)r->hi[2] + pad;
-}
-
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, const double *__restrict__ segs, int64_t n_cap,
                                                         const unsigned long long *__restrict__ n_dev,
@@ -271,7 +277,10 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, con
                            d_out, n_seg, d_count);
     else
         RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_seg, scene->stream));
-    if (scene->occlusion_mode == 0) {
+    // small launches on small scenes are latency-bound: there the every-polygon walk, split over grid.y, is quicker
+    const bool walk_grid = scene->occlusion_mode == 2 ||
+                           (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
+    if (walk_grid) {
         if (d_mask)
             hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view,
                                d_segs, n_seg, d_count, d_mask, d_out);

@@ -83,6 +83,7 @@ struct SceneView {
     int32_t gnx, gny;
     const OccCell *cells;    // [gnx*gny + 1]
     const OccRec *cell_recs;
+    const OccRec *poly_recs; // [n] the same records in polygon order (every-polygon walk)
 };
 
 #define RT_GRID_PAD 1e-5
@@ -105,7 +106,7 @@ struct rt_scene {
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     int64_t hint_paths = 0, hint_segments = 0;
-    int occlusion_mode = 0;  // 0 = grid walk, 1 = every polygon (kept for cross-checking the grid)
+    int occlusion_mode = 0;  // 0 = by scene size, 1 = every-polygon walk, 2 = grid walk
     // timing of the last solve
     double last_ms[4] = {0, 0, 0, 0};
     int64_t last_launches[4] = {0, 0, 0, 0};

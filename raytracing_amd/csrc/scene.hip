@@ -106,6 +106,21 @@ static int build_grid(rt_scene *s, int n_poly, const int32_t *vert_off, const do
             for (int32_t c : mine) cells[c].push_back(i);
         }
     }
+    std::vector<OccRec> poly_recs((size_t)n_poly);
+    for (int i = 0; i < n_poly; ++i) {
+        OccRec &r = poly_recs[i];
+        const double *pl = planes + 4 * (size_t)i, *b = bb + 6 * (size_t)i;
+        r.nx = pl[0];
+        r.ny = pl[1];
+        r.nz = pl[2];
+        r.d = pl[3];
+        for (int a = 0; a < 3; ++a) {
+            r.lo[a] = round_down(b[a] - lo[a]);
+            r.hi[a] = round_up(b[3 + a] - lo[a]);
+        }
+        r.poly = i;
+        r.pad_ = 0;
+    }
     std::vector<OccCell> cell_table((size_t)n_cells + 1);
     std::vector<OccRec> recs;
     for (int c = 0; c <= n_cells; ++c) {
@@ -114,20 +129,8 @@ static int build_grid(rt_scene *s, int n_poly, const int32_t *vert_off, const do
         cell.zmax = -INFINITY;
         cell.pad_ = 0;
         for (int32_t i : cells[c]) {
-            OccRec r;
-            const double *pl = planes + 4 * (size_t)i, *b = bb + 6 * (size_t)i;
-            r.nx = pl[0];
-            r.ny = pl[1];
-            r.nz = pl[2];
-            r.d = pl[3];
-            for (int a = 0; a < 3; ++a) {
-                r.lo[a] = round_down(b[a] - lo[a]);
-                r.hi[a] = round_up(b[3 + a] - lo[a]);
-            }
-            r.poly = i;
-            r.pad_ = 0;
-            cell.zmax = std::fmax(cell.zmax, r.hi[2]);
-            recs.push_back(r);
+            cell.zmax = std::fmax(cell.zmax, poly_recs[i].hi[2]);
+            recs.push_back(poly_recs[i]);
         }
         cell.end = (int32_t)recs.size();
     }
@@ -140,11 +143,12 @@ static int build_grid(rt_scene *s, int n_poly, const int32_t *vert_off, const do
     s->view.gny = gny;
     if (upload(s, cell_table, &s->view.cells)) return -1;
     if (upload(s, recs, &s->view.cell_recs)) return -1;
+    if (upload(s, poly_recs, &s->view.poly_recs)) return -1;
     return 0;
 }
 
 extern "C" int rt_debug_set_occlusion_mode(rt_scene *s, int mode) {
-    if (!s || mode < 0 || mode > 1) RT_FAIL("rt_debug_set_occlusion_mode: bad argument");
+    if (!s || mode < 0 || mode > 2) RT_FAIL("rt_debug_set_occlusion_mode: bad argument");
     s->occlusion_mode = mode;
     return 0;
 }

@@ -33,7 +33,7 @@ lib = _lib.load()
 for label, order in (("edge-major", np.arange(len(seg))), ("shuffled", rng.permutation(len(seg)))):
     d_seg = torch.tensor(seg[order], dtype=torch.float64, device="cuda")
     d_out = torch.zeros(len(seg), dtype=torch.uint8, device="cuda")
-    for mode in (1, 0):
+    for mode in (1, 2):
         scene.set_occlusion_mode(mode)
         for rep in range(3):
             torch.cuda.synchronize()

@@ -3,6 +3,9 @@ import sys
 import time
 
 import numpy as np
+import torch
+
+torch.cuda.init()
 
 sys.path.insert(0, ".")
 from raytracing_amd import _lib, geometry as geom, scenarios  # noqa: E402
@@ -42,3 +45,13 @@ t = time.time(); res = scene.solve_paths(cand, tx, rx); dt = time.time() - t
 print("solve", f"{dt:.3f}s", "paths", len(res["rx"]), "attempted", res["n_attempted"], f"{res['n_attempted']/dt:.3e} solves/s", scene.last_timing(), flush=True)
 t = time.time(); res = scene.solve_paths(cand, tx, rx); dt = time.time() - t
 print("solve again", f"{dt:.3f}s", f"{res['n_attempted']/dt:.3e} solves/s", flush=True)
+
+d_rx = torch.tensor(rx, dtype=torch.float64, device="cuda")
+cap = max(1 << 20, 4 * len(res["rx"]))
+o_rx = torch.empty(cap, dtype=torch.int32, device="cuda"); o_group = torch.empty_like(o_rx); o_cand = torch.empty_like(o_rx)
+o_pts = torch.empty((cap, _lib.RT_MAX_ORDER, 3), dtype=torch.float64, device="cuda")
+for rep in range(3):
+    torch.cuda.synchronize(); t = time.time()
+    found, attempted = scene.solve_paths_device(cand, tx, d_rx.data_ptr(), len(rx), o_rx.data_ptr(), o_group.data_ptr(), o_cand.data_ptr(), o_pts.data_ptr(), cap)
+    dt = time.time() - t
+    print("device-resident solve", f"{dt*1e3:.3f} ms", found, f"{attempted/dt:.3e} solves/s", scene.last_timing()["ms"], flush=True)

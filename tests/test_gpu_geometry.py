@@ -83,9 +83,10 @@ def test_obstruction_grid_walk_equals_every_polygon_walk(places, name, n):
     try:
         scene.set_occlusion_mode(1)
         want, want_masked = scene.obstructed(segs), scene.obstructed(segs, mask=mask)
+        scene.set_occlusion_mode(2)
+        got, got_masked = scene.obstructed(segs), scene.obstructed(segs, mask=mask)
     finally:
         scene.set_occlusion_mode(0)
-    got, got_masked = scene.obstructed(segs), scene.obstructed(segs, mask=mask)
     assert want.sum() > n // 10 and (~want).sum() > n // 10
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(got_masked, want_masked)
