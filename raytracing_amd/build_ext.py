@@ -14,8 +14,21 @@ HEADERS = ["rt_common.h", "rt_candidates.h", "rt_fresnel.h", os.path.join("..", 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
+FLAGS_STAMP = LIB + ".flags"
+
+
+def _flags_line():
+    return " ".join(FLAGS + os.environ.get("RT_EXTRA_HIPCC_FLAGS", "").split())
+
+
 def _stale():
     if not os.path.exists(LIB):
+        return True
+    try:
+        with open(FLAGS_STAMP) as f:
+            if f.read() != _flags_line():
+                return True  # built with other flags (e.g. an instrumented build)
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -26,10 +39,13 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("RT_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DRT_OCC_STATS for the obstruction work counters
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(_flags_line())
     return LIB
 
 

@@ -7,6 +7,8 @@
 // test of the reference (projection along the segment, extent overlap, boundary-inclusive point-in-polygon,
 // 1e-8 < t < 1-1e-8), so the expensive test always runs with full waves.  The padded pre-test can only let too many
 // pairs through, never too few, so the result is the exact test's.
+#include <algorithm>
+
 #include "rt_common.h"
 
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -14,18 +16,39 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r * (2.0 - x * r);  // one Newton step: plenty for a pre-test with a 1e-6 pad
 }
 
-// Runs the exact test for up to 64 parked (segment lane, polygon) pairs of a wave, one pair per lane.
-__device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double *__restrict__ segs, int64_t s_base,
-                                               int p_begin, const uint32_t *entries, int n_entries, int lane,
+// What a launch works on: item i is segment i of the queue, or (paths given) the segment `round` places from the end
+// of path i, skipped when the path is already known to be blocked; out[i] is set when the item's segment is cut.
+// Testing a path's segments last to first, one launch per place, stops at the first cut segment: most paths of a
+// coverage map are blocked on the stretch that reaches the receiver, and their other segments are never walked.
+struct ObstructItems {
+    const double *segs;
+    const PathRec *paths;
+    int round;
+};
+
+__device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t i, const uint8_t *__restrict__ out,
+                                             int64_t &seg) {
+    seg = i;
+    if (!it.paths) return true;
+    const PathRec &p = it.paths[i];
+    if (it.round >= p.nseg || out[i]) return false;
+    seg = p.seg0 + (int64_t)(p.nseg - 1 - it.round) * p.seg_stride;
+    return true;
+}
+
+// Runs the exact test for up to 64 parked (item lane, polygon) pairs of a wave, one pair per lane.
+__device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double *__restrict__ segs,
+                                               const int64_t *wave_seg, int64_t s_base, int p_begin,
+                                               const uint32_t *entries, int n_entries, int lane,
                                                volatile uint8_t *wave_hit, uint8_t *__restrict__ out) {
     if (lane < n_entries) {
         const uint32_t e = entries[lane];
         const int L = (int)(e & 63u);
         if (!wave_hit[L]) {
-            const int64_t s = s_base + L;
+            const int64_t s = wave_seg[L];
             if (polygon_cuts_segment(sc, p_begin + (int)(e >> 6), ld3(segs + 6 * s), ld3(segs + 6 * s + 3))) {
                 wave_hit[L] = 1;
-                out[s] = 1;  // out starts at zero; several polygon chunks may set the same byte
+                out[s_base + L] = 1;  // out starts at zero; several polygon chunks may set the same byte
             }
         }
     }
@@ -50,10 +73,11 @@ __device__ __forceinline__ bool occ_pretest(const OccRec *__restrict__ r, const 
 #define OBS_STAGE 128
 #define RT_GRID_MIN_POLYGONS 512
 template <bool MASKED>
-__global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__restrict__ segs, int64_t n_cap,
+__global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems items, int64_t n_cap,
                                                    const unsigned long long *__restrict__ n_dev,
-                                                   const uint8_t *__restrict__ mask, int poly_chunk,
-                                                   uint8_t *__restrict__ out) {
+                                                   const uint8_t *__restrict__ mask, int poly_chunk, uint8_t *out) {
+    __shared__ int64_t wave_segs[4][64];
+    const double *__restrict__ segs = items.segs;
     __shared__ OccRec s_rec[OBS_STAGE];
     __shared__ uint8_t s_mask[OBS_STAGE];
     __shared__ uint32_t wave_queue[4][128];
@@ -72,12 +96,14 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
     for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
-        const bool active = s < n_seg;
+        int64_t seg = 0;
+        const bool active = s < n_seg && item_segment(items, s, out, seg);
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
         if (active) {
-            A = ld3(segs + 6 * s);
-            B = ld3(segs + 6 * s + 3);
+            A = ld3(segs + 6 * seg);
+            B = ld3(segs + 6 * seg + 3);
         }
+        wave_segs[wave][lane] = seg;
         const d3 V = B - A;
         const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
         bool hit = false;
@@ -110,7 +136,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
                     __builtin_amdgcn_wave_barrier();
                     if (qn >= 64) {
                         qn -= 64;
-                        obstruct_drain(sc, segs, s_base, p_begin, wq + qn, 64, lane, wave_hit, out);
+                        obstruct_drain(sc, segs, wave_segs[wave], s_base, p_begin, wq + qn, 64, lane, wave_hit, out);
                         __builtin_amdgcn_wave_barrier();
                         hit = wave_hit[lane] != 0;
                         if (__all(hit || !active)) {
@@ -122,7 +148,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
                 }
             }
         }
-        if (qn > 0) obstruct_drain(sc, segs, s_base, p_begin, wq, qn, lane, wave_hit, out);
+        if (qn > 0) obstruct_drain(sc, segs, wave_segs[wave], s_base, p_begin, wq, qn, lane, wave_hit, out);
         __syncthreads();  // the staging buffer is free again
     }
 }
@@ -136,10 +162,25 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, const double *__
 // and the parked exact tests are the every-polygon kernel's.  The polygons too large for the grid (the ground) are
 // tested first by every segment.  Every polygon the exact test could flag has its crossing point inside its own
 // padded box, hence inside a cell it is registered in, and that cell is on the segment's walk.
+#ifdef RT_OCC_STATS
+__device__ unsigned long long g_occ_stats[8];
+extern "C" int rt_debug_occlusion_stats(unsigned long long *out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_occ_stats), sizeof(g_occ_stats)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_occ_stats), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+__device__ inline unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+#endif
+
 template <bool MASKED>
-__global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, const double *__restrict__ segs, int64_t n_cap,
+__global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructItems items, int64_t n_cap,
                                                         const unsigned long long *__restrict__ n_dev,
-                                                        const uint8_t *__restrict__ mask, uint8_t *__restrict__ out) {
+                                                        const uint8_t *__restrict__ mask, uint8_t *out) {
+    __shared__ int64_t wave_segs[4][64];
+    const double *__restrict__ segs = items.segs;
     __shared__ uint32_t wave_queue[4][128];
     __shared__ uint8_t wave_hits[4][64];
     int64_t n_seg = n_cap;
@@ -155,12 +196,14 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, const doubl
     for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
-        const bool active = s < n_seg;
+        int64_t seg = 0;
+        const bool active = s < n_seg && item_segment(items, s, out, seg);
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
         if (active) {
-            A = ld3(segs + 6 * s);
-            B = ld3(segs + 6 * s + 3);
+            A = ld3(segs + 6 * seg);
+            B = ld3(segs + 6 * seg + 3);
         }
+        wave_segs[wave][lane] = seg;
         const d3 V = B - A;
         const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
         // walk set-up: u = major horizontal axis, w = minor, both relative to the grid origin; the columns are visited
@@ -179,6 +222,9 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, const doubl
         int i = (step > 0 ? i_first : i_last) - step;  // current column
         int j = 1, j_hi = 0;
         int k = active ? global_cell.begin : 0, k_end = active ? global_cell.end : 0;
+#ifdef RT_OCC_STATS
+        unsigned long long st_cells = 0, st_recs = 0, st_iters = 0, st_exact = 0;
+#endif
         double z_low = 0.0;  // lowest point of the segment over the current column, relative to the grid origin
         // moves to the next cell that has records and is not entirely below the segment; false when the walk is over
         auto next_cell = [&]() -> bool {
@@ -207,6 +253,9 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, const doubl
                     z_low = fmin(A.z + ta * V.z, A.z + tb * V.z) - sc.gz0 - pad;
                 }
                 const OccCell cell = sc.cells[major_x ? j * sc.gnx + i : i * sc.gnx + j];
+#ifdef RT_OCC_STATS
+                ++st_cells;
+#endif
                 if (cell.end > cell.begin && !(z_low > (double)cell.zmax)) {
                     k = cell.begin;
                     k_end = cell.end;
@@ -230,7 +279,14 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, const doubl
                 if (wanted) cand = occ_pretest(r, sc, A, V, pad);
                 ++k;
                 if (k >= k_end) finished = !next_cell();
+#ifdef RT_OCC_STATS
+                ++st_recs;
+                if (cand) ++st_exact;
+#endif
             }
+#ifdef RT_OCC_STATS
+            if (lane == 0) ++st_iters;
+#endif
             const unsigned long long m = __ballot(cand);
             if (m != 0) {
                 if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)poly << 6) | (uint32_t)lane;
@@ -238,14 +294,29 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, const doubl
                 __builtin_amdgcn_wave_barrier();
                 if (qn >= 64) {
                     qn -= 64;
-                    obstruct_drain(sc, segs, s_base, 0, wq + qn, 64, lane, wave_hit, out);
+                    obstruct_drain(sc, segs, wave_segs[wave], s_base, 0, wq + qn, 64, lane, wave_hit, out);
                     __builtin_amdgcn_wave_barrier();
                     if (wave_hit[lane]) finished = true;
                 }
             }
         }
-        if (qn > 0) obstruct_drain(sc, segs, s_base, 0, wq, qn, lane, wave_hit, out);
+        if (qn > 0) obstruct_drain(sc, segs, wave_segs[wave], s_base, 0, wq, qn, lane, wave_hit, out);
         __builtin_amdgcn_wave_barrier();
+#ifdef RT_OCC_STATS
+        {
+            const unsigned long long a = wave_sum(active ? 1 : 0), c = wave_sum(st_cells), r = wave_sum(st_recs),
+                                     e = wave_sum(st_exact), it = wave_sum(st_iters), h = wave_sum(wave_hit[lane] ? 1 : 0);
+            if (lane == 0 && a > 0) {
+                atomicAdd(&g_occ_stats[0], a);
+                atomicAdd(&g_occ_stats[1], c);
+                atomicAdd(&g_occ_stats[2], r);
+                atomicAdd(&g_occ_stats[3], e);
+                atomicAdd(&g_occ_stats[4], it);
+                atomicAdd(&g_occ_stats[5], 1ull);
+                atomicAdd(&g_occ_stats[6], h);
+            }
+        }
+#endif
     }
 }
 
@@ -255,16 +326,17 @@ __global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const uns
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0;
 }
 
-// Obstruction flags of n_seg segments (or, with d_count, of the *d_count <= n_seg segments the device holds, the grid
-// being sized for n_hint of them).
-int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out,
-                       const unsigned long long *d_count, int64_t n_hint) {
-    if (n_seg == 0) return 0;
+// Obstruction flags of n_item items: segments of the queue, or with d_paths one segment per path (see ObstructItems;
+// then the flags are not cleared here: they accumulate over the rounds).  With d_count the device holds the item
+// count (<= n_item) and the grid is sized for n_hint of them.
+int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, const uint8_t *d_mask, uint8_t *d_out,
+                       const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths, int round) {
+    if (n_item == 0) return 0;
     const int block = 256;
-    const int64_t n_grid = d_count ? (n_hint < 1 ? 1 : (n_hint > n_seg ? n_seg : n_hint)) : n_seg;
+    const int64_t n_grid = d_count ? (n_hint < 1 ? 1 : (n_hint > n_item ? n_item : n_hint)) : n_item;
     int64_t grid = (n_grid + block - 1) / block;
     if (grid > (1 << 20)) grid = 1 << 20;  // the kernel strides over the rest
-    // few segments: split the polygon list over grid.y so the launch still fills the chip (target >= ~2048 waves)
+    // few items: split the polygon list over grid.y so the launch still fills the chip (target >= ~2048 waves)
     const int64_t waves = grid * (block / RT_WAVE);
     int64_t ny = waves >= 2048 ? 1 : (2048 + waves - 1) / waves;
     const int64_t max_ny = (scene->view.n + 31) / 32;
@@ -272,27 +344,39 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, con
     ny = ny < 1 ? 1 : ny;
     int poly_chunk = (int)((scene->view.n + ny - 1) / ny);
     ny = (scene->view.n + poly_chunk - 1) / poly_chunk;
-    if (d_count)
-        hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)(grid < 1024 ? grid : 1024)), dim3(block), 0, scene->stream,
-                           d_out, n_seg, d_count);
-    else
-        RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_seg, scene->stream));
+    if (!d_paths) {
+        if (d_count)
+            hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)(grid < 1024 ? grid : 1024)), dim3(block), 0, scene->stream,
+                               d_out, n_item, d_count);
+        else
+            RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_item, scene->stream));
+    }
+    const ObstructItems items{d_segs, d_paths, round};
     // small launches on small scenes are latency-bound: there the every-polygon walk, split over grid.y, is quicker
     const bool walk_grid = scene->occlusion_mode == 2 ||
                            (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
     if (walk_grid) {
         if (d_mask)
             hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view,
-                               d_segs, n_seg, d_count, d_mask, d_out);
+                               items, n_item, d_count, d_mask, d_out);
         else
             hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view,
-                               d_segs, n_seg, d_count, d_mask, d_out);
+                               items, n_item, d_count, d_mask, d_out);
     } else if (d_mask)
         hipLaunchKernelGGL(k_obstruct<true>, dim3((unsigned)grid, (unsigned)ny), dim3(block), 0, scene->stream,
-                           scene->view, d_segs, n_seg, d_count, d_mask, poly_chunk, d_out);
+                           scene->view, items, n_item, d_count, d_mask, poly_chunk, d_out);
     else
         hipLaunchKernelGGL(k_obstruct<false>, dim3((unsigned)grid, (unsigned)ny), dim3(block), 0, scene->stream,
-                           scene->view, d_segs, n_seg, d_count, d_mask, poly_chunk, d_out);
+                           scene->view, items, n_item, d_count, d_mask, poly_chunk, d_out);
+    RT_HIP(hipGetLastError());
+    return 0;
+}
+
+// clears the first *n_dev (<= n_cap) bytes
+int rt_launch_zero_bytes(rt_scene *scene, uint8_t *d_out, int64_t n_cap, const unsigned long long *d_count, int64_t n_hint) {
+    int64_t grid = (std::max<int64_t>(n_hint, 1) + 255) / 256;
+    grid = grid > 1024 ? 1024 : grid;
+    hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)grid), dim3(256), 0, scene->stream, d_out, n_cap, d_count);
     RT_HIP(hipGetLastError());
     return 0;
 }
@@ -305,7 +389,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
     if (!segs || !out) RT_FAIL("rt_obstruct_segments: null array");
     RT_HIP(hipSetDevice(scene->device));
     if (on_device) {
-        if (rt_launch_obstruct(scene, segs, n_seg, mask, out, nullptr, 0)) return -1;
+        if (rt_launch_obstruct(scene, segs, n_seg, mask, out, nullptr, 0, nullptr, 0)) return -1;
         RT_HIP(hipStreamSynchronize(scene->stream));
         return 0;
     }
@@ -319,7 +403,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
         if (hipMemcpyAsync(d_segs, segs, sizeof(double) * 6 * n_seg, hipMemcpyHostToDevice, scene->stream) != hipSuccess)
             break;
         if (mask && hipMemcpyAsync(d_mask, mask, scene->view.n, hipMemcpyHostToDevice, scene->stream) != hipSuccess) break;
-        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, d_out, nullptr, 0)) break;
+        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, d_out, nullptr, 0, nullptr, 0)) break;
         if (hipMemcpyAsync(out, d_out, n_seg, hipMemcpyDeviceToHost, scene->stream) != hipSuccess) break;
         if (hipStreamSynchronize(scene->stream) != hipSuccess) break;
         rc = 0;

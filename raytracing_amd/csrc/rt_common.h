@@ -115,6 +115,13 @@ struct rt_scene {
 
 int rt_scene_workspace(rt_scene *scene, size_t bytes, void **out);
 
+// A path waiting for its obstruction test: its interaction points and where its segments are in the segment queue.
+struct PathRec {
+    int32_t rx, group, cand, nseg;
+    int64_t seg0, seg_stride;  // segment k of the path is segs[seg0 + k * seg_stride]
+    double pts[RT_MAX_ORDER * 3];
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // fp64 3-vectors
 // ---------------------------------------------------------------------------------------------------------------

@@ -25,15 +25,10 @@
 #include "rt_common.h"
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out,
-                       const unsigned long long *d_count, int64_t n_hint);
+                       const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths, int round);
+int rt_launch_zero_bytes(rt_scene *scene, uint8_t *d_out, int64_t n_cap, const unsigned long long *d_count, int64_t n_hint);
 
 #define MIN_DISTANCE_TOL 0.005 /* ray_tracing.py:252 */
-
-struct PathRec {
-    int32_t rx, group, cand, nseg;
-    int64_t seg0, seg_stride;  // segment k of the path is segs[seg0 + k * seg_stride]
-    double pts[RT_MAX_ORDER * 3];
-};
 
 struct Queues {
     PathRec *paths;
@@ -838,11 +833,12 @@ __global__ void k_los_finalize(const uint8_t *__restrict__ hit, int64_t rx0, int
 
 // Keeps the queued paths none of whose segments is obstructed.  counters[0], counters[1] = paths and segments the
 // producers asked for; when either exceeds its queue the records are incomplete and nothing is done (the host redoes
-// the chunk with larger queues).  A wave looks at 512 paths and reserves the room of its survivors with one atomic.
+// the chunk with larger queues).  hit holds one flag per segment, or (per_path) one per path.  A wave looks at 512
+// paths and reserves the room of its survivors with one atomic.
 #define FINALIZE_ITEMS 8
 __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ paths, const uint8_t *__restrict__ hit,
                                                    const unsigned long long *__restrict__ counters, int64_t path_cap,
-                                                   int64_t seg_cap, OutArrays out) {
+                                                   int64_t seg_cap, int per_path, OutArrays out) {
     const unsigned long long np = counters[0], ns = counters[1];
     if (np > (unsigned long long)path_cap || ns > (unsigned long long)seg_cap) return;
     const int64_t n = (int64_t)np;
@@ -858,8 +854,12 @@ __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ pa
             const int64_t i = base + j * 64 + lane;
             bool ok = i < n;
             if (ok) {
-                const PathRec &p = paths[i];
-                for (int k = 0; k < p.nseg; ++k) ok = ok && !hit[p.seg0 + k * p.seg_stride];
+                if (per_path) {
+                    ok = !hit[i];
+                } else {
+                    const PathRec &p = paths[i];
+                    for (int k = 0; k < p.nseg; ++k) ok = ok && !hit[p.seg0 + k * p.seg_stride];
+                }
             }
             keep[j] = ok;
             const unsigned long long m = __ballot(ok);
@@ -1063,7 +1063,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_HIP(hipStreamSynchronize(st));
         if (n0 == 0) continue;
         timer.begin(2);
-        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, hit, nullptr, 0)) {
+        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, hit, nullptr, 0, nullptr, 0)) {
             free_temps();
             return -1;
         }
@@ -1149,7 +1149,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         hipLaunchKernelGGL(k_los_segments, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, d_lsegs);
         timer.end(3);
         timer.begin(2);
-        if (rt_launch_obstruct(scene, d_lsegs, nr, cand->d_ev, d_lhits, nullptr, 0)) {
+        if (rt_launch_obstruct(scene, d_lsegs, nr, cand->d_ev, d_lhits, nullptr, 0, nullptr, 0)) {
             free_temps();
             return -1;
         }
@@ -1189,15 +1189,32 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         // obstruction of the queued segments and the final filter, sized on the device
         const int64_t seg_hint = scene->hint_segments > 0 ? scene->hint_segments : std::min<int64_t>(seg_cap, 1 << 22);
         const int64_t path_hint = scene->hint_paths > 0 ? scene->hint_paths : std::min<int64_t>(path_cap, 1 << 21);
+        // Large batches: one launch per segment place, last segment first, each skipping the paths already blocked
+        // (flags per path).  Small batches are launch-bound: one launch over all segments (flags per segment).
+        const bool by_rounds = path_hint >= (1 << 15);
         timer.begin(2);
-        if (rt_launch_obstruct(scene, q.segs, seg_cap, nullptr, d_hits, d_counters + 1, seg_hint)) {
+        if (by_rounds) {
+            int max_nseg = 0;
+            for (int k = 1; k <= mo; ++k)
+                if (cand->groups[k - 1].count > 0) max_nseg = std::max(max_nseg, k + 1);
+            if (any_diffraction) max_nseg = std::max(max_nseg, 2);
+            if (rt_launch_zero_bytes(scene, d_hits, path_cap, d_counters, path_hint)) {
+                free_temps();
+                return -1;
+            }
+            for (int round = 0; round < max_nseg; ++round)
+                if (rt_launch_obstruct(scene, q.segs, path_cap, nullptr, d_hits, d_counters, path_hint, q.paths, round)) {
+                    free_temps();
+                    return -1;
+                }
+        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, nullptr, d_hits, d_counters + 1, seg_hint, nullptr, 0)) {
             free_temps();
             return -1;
         }
         timer.end(2);
         timer.begin(3);
         hipLaunchKernelGGL(k_finalize, dim3(std::min<unsigned>(blocks_for(path_hint, 256 * FINALIZE_ITEMS), 1u << 16)), dim3(256), 0, st, q.paths,
-                           d_hits, d_counters, path_cap, seg_cap, out);
+                           d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out);
         timer.end(3);
         SOLVE_HIP(hipMemcpyAsync(h_counters, d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         SOLVE_HIP(hipStreamSynchronize(st));

@@ -1,4 +1,5 @@
 """Timing probe on larger scenes (not a test): precompute phases and one solve, with progress lines."""
+import os
 import sys
 import time
 
@@ -14,7 +15,6 @@ name = sys.argv[1]
 order = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 n_side = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 diff = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-import os
 path = f"data/{name}.geojson"
 if not os.path.exists(path):
     path = f"data/{name}/{name}.geojson"
@@ -22,6 +22,12 @@ place = geom.load_place(path)
 lo, hi = place.get_domain()
 tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
 rx = scenarios.lattice_receivers(place, n_side, 1.5)
+if os.environ.get("RT_TILE_RX"):
+    # receivers in 8x8 tiles instead of rows: a wave's 64 receivers are then neighbours in both directions
+    idx = np.arange(n_side * n_side).reshape(n_side, n_side)
+    t = int(os.environ["RT_TILE_RX"])
+    order_ = np.concatenate([idx[a:a + t, b:b + t].ravel() for a in range(0, n_side, t) for b in range(0, n_side, t)])
+    rx = rx[order_]
 polygons = place.get_polygons_list()
 print(name, "polygons", len(polygons), "rx", len(rx), flush=True)
 scene = _lib.Scene(geom.scene_arrays_of(polygons))
@@ -54,4 +60,4 @@ for rep in range(3):
     torch.cuda.synchronize(); t = time.time()
     found, attempted = scene.solve_paths_device(cand, tx, d_rx.data_ptr(), len(rx), o_rx.data_ptr(), o_group.data_ptr(), o_cand.data_ptr(), o_pts.data_ptr(), cap)
     dt = time.time() - t
-    print("device-resident solve", f"{dt*1e3:.3f} ms", found, f"{attempted/dt:.3e} solves/s", scene.last_timing()["ms"], flush=True)
+    print("device-resident solve", f"{dt*1e3:.3f} ms", found, f"{attempted/dt:.3e} solves/s", scene.last_timing()["ms"], scene.last_timing()["segments"], flush=True)

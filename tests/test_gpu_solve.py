@@ -140,3 +140,46 @@ def test_multithread_solve_place_single_gpu(tmp_path, monkeypatch):
     direct = RayTracingProblem(tx.reshape(1, 3), place)
     direct.solve(max_order=2)
     assert back.path_set() == direct.path_set()
+
+
+def test_repeated_solves_and_obstruction_routes_agree(places):
+    """A scene remembers the sizes its last solve needed and sizes the next call's launches from them, and it tests
+    the queued segments either in one launch or path by path, last segment first, depending on the batch size.  Every
+    route and every kernel choice must give the same paths."""
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import scenarios
+
+    place, tx, rx = scenarios.levant_grid(16)
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+
+    def used_points(g):
+        if g < 0:
+            return 0
+        n_refl, has_edge = cand.group_kind(int(g))
+        return n_refl + (1 if has_edge else 0)
+
+    def as_set(res):  # only the first n points of a row are meaningful
+        return {(int(r), int(g), int(c)) + tuple(np.round(p[:used_points(g)].ravel(), 9)) for r, g, c, p in
+                zip(res["rx"], res["group"], res["cand"], res["points"])}
+
+    first = scene.solve_paths(cand, tx, rx)            # sizes unknown: path-by-path rounds
+    second = scene.solve_paths(cand, tx, rx)           # sizes known and small: one launch over all segments
+    assert len(first["rx"]) > 500
+    assert as_set(first) == as_set(second)
+    for mode in (1, 2):
+        scene.set_occlusion_mode(mode)
+        assert as_set(scene.solve_paths(cand, tx, rx)) == as_set(first)
+    scene.set_occlusion_mode(0)
+    # a subset of the receivers gives the subset of the paths
+    sub = scene.solve_paths(cand, tx, rx[40:90])
+    want = {(t[0] - 40,) + t[1:] for t in as_set(first) if 40 <= t[0] < 90}
+    assert as_set(sub) == want
+    cand.close()
+    scene.close()
