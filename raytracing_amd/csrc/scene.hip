@@ -17,14 +17,51 @@ extern "C" int rt_device_count(void) {
     return n;
 }
 
+// The scene's arrays live in ONE device allocation: a kernel of a small solve step touches most of them, and every
+// separate allocation is another page the cold TLBs of 256 CUs have to walk for.  upload() only notes what has to go
+// where; commit_uploads() allocates the arena, copies everything and sets the device pointers.
+struct PendingUpload {
+    const void *host;
+    size_t bytes;
+    const void **device_field;
+    size_t offset;
+};
+static thread_local std::vector<PendingUpload> g_pending;
+static thread_local std::vector<std::vector<unsigned char>> g_pending_copies;
+
 template <typename T>
-static int upload(rt_scene *s, const std::vector<T> &h, const T **dptr) {
-    void *d = nullptr;
-    size_t bytes = sizeof(T) * (h.empty() ? 1 : h.size());
-    RT_HIP(hipMalloc(&d, bytes));
-    s->allocations.push_back(d);
-    if (!h.empty()) RT_HIP(hipMemcpy(d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
-    *dptr = (const T *)d;
+static int upload(rt_scene *, const std::vector<T> &h, const T **dptr) {
+    // the caller's vector may be a local: keep a copy until the commit
+    g_pending_copies.emplace_back((const unsigned char *)h.data(), (const unsigned char *)h.data() + sizeof(T) * h.size());
+    g_pending.push_back({nullptr, sizeof(T) * h.size(), (const void **)dptr, 0});
+    return 0;
+}
+
+static int commit_uploads(rt_scene *s) {
+    size_t total = 0;
+    for (PendingUpload &u : g_pending) {
+        u.offset = total;
+        total += (u.bytes + 255) & ~(size_t)255;
+    }
+    total += 256;  // the solve's counters, below
+    void *arena = nullptr;
+    hipError_t e = hipMalloc(&arena, total);
+    if (e != hipSuccess) {
+        g_pending.clear();
+        g_pending_copies.clear();
+        rt_set_error(std::string("rt_scene_create: hipMalloc: ") + hipGetErrorString(e));
+        return -1;
+    }
+    s->allocations.push_back(arena);
+    std::vector<unsigned char> staging(total, 0);
+    for (size_t i = 0; i < g_pending.size(); ++i) {
+        if (g_pending[i].bytes) memcpy(staging.data() + g_pending[i].offset, g_pending_copies[i].data(), g_pending[i].bytes);
+        *g_pending[i].device_field = (const char *)arena + g_pending[i].offset;
+    }
+    s->d_counters = (unsigned long long *)((char *)arena + total - 256);
+    g_pending.clear();
+    g_pending_copies.clear();
+    RT_HIP(hipMemcpy(arena, staging.data(), total, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -172,6 +209,8 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
         }
     }
     RT_HIP_NULL(hipSetDevice(device));
+    g_pending.clear();
+    g_pending_copies.clear();
     rt_scene *s = new rt_scene();
     s->device = device;
     const int vtot = vert_off[n_poly];
@@ -217,21 +256,11 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
               upload(s, s->h_planes, &s->view.planes) == 0 && upload(s, frames, &s->view.frames) == 0 &&
               upload(s, s->h_bbox, &s->view.bbox) == 0 && upload(s, uv, &s->view.uv) == 0 &&
               upload(s, mat, &s->view.material) == 0 && upload(s, bld, &s->view.building) == 0 &&
-              build_grid(s, n_poly, vert_off, verts, planes) == 0;
-    if (ok) {
-        void *d = nullptr;
-        if (hipMalloc(&d, 16 * sizeof(unsigned long long)) == hipSuccess) {
-            s->allocations.push_back(d);
-            s->d_counters = (unsigned long long *)d;
-        } else {
-            rt_set_error("rt_scene_create: out of device memory");
-            ok = false;
-        }
-        if (ok && hipHostMalloc((void **)&s->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
-            rt_set_error("rt_scene_create: pinned host allocation failed");
-            s->h_counters = nullptr;
-            ok = false;
-        }
+              build_grid(s, n_poly, vert_off, verts, planes) == 0 && commit_uploads(s) == 0;
+    if (ok && hipHostMalloc((void **)&s->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        rt_set_error("rt_scene_create: pinned host allocation failed");
+        s->h_counters = nullptr;
+        ok = false;
     }
     if (ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         rt_set_error("rt_scene_create: hipStreamCreate failed");

@@ -43,11 +43,11 @@ for label, order in (("edge-major", np.arange(len(seg))), ("shuffled", rng.permu
             dt = time.perf_counter() - t
             assert rc == 0
         hits = int(d_out.sum().item())
-        if hasattr(lib, "rt_debug_occlusion_stats") and mode == 2:
+        if hasattr(lib, "rt_debug_occlusion_stamps") and mode == 1:
             st = (ctypes.c_ulonglong * 8)()
-            lib.rt_debug_occlusion_stats(st)
-            a = max(1, st[0])
-            print("    stats (3 reps): items", st[0], "cells/item", st[1] / a, "records/item", st[2] / a, "exact/item", st[3] / a,
-                  "loop trips/wave", st[4] / max(1, st[5]), "waves", st[5], "hit", st[6] / a, flush=True)
+            lib.rt_debug_occlusion_stamps(st)
+            w = max(1, st[4])
+            print("    per wave, us: loads", st[0] / w / 100, "staging", st[1] / w / 100, "record loop", st[2] / w / 100,
+                  "drains", st[3] / w / 100, "total", st[6] / w / 100, "drains per wave", st[5] / w, "waves", st[4], "core clock MHz", 100.0 * st[7] / max(1, st[6]), flush=True)
         print(f"  {label:10s} mode={mode} {dt*1e3:8.3f} ms  hit fraction {hits/len(seg):.3f}  "
               f"{len(seg)*len(polygons)/dt:.3e} seg*poly/s", flush=True)

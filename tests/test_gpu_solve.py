@@ -173,6 +173,7 @@ def test_repeated_solves_and_obstruction_routes_agree(places):
     second = scene.solve_paths(cand, tx, rx)           # sizes known and small: one launch over all segments
     assert len(first["rx"]) > 500
     assert as_set(first) == as_set(second)
+    assert scene.last_timing()["ms"]["reflect"] > 0 and scene.last_timing()["ms"]["obstruct"] > 0
     for mode in (1, 2):
         scene.set_occlusion_mode(mode)
         assert as_set(scene.solve_paths(cand, tx, rx)) == as_set(first)
