@@ -350,8 +350,11 @@ __device__ inline double los_tree_factor(const SceneView &sc, d3 A, d3 B, double
             if (status == ST_OK) status = ST_CONCAVE;
         }
     };
+    const d3 V = B - A;
+    const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
     for (int p = 0; p < sc.n; ++p) {
-        if (!polygon_cuts_segment(sc, p, A, B)) continue;
+        // the cheap conservative test first; the exact one only for the few polygons it lets through
+        if (!occ_pretest(sc.poly_recs + p, sc, A, V, pad) || !polygon_cuts_segment(sc, p, A, B)) continue;
         if (count == 0) {
             first = p;
             count = 1;
@@ -379,8 +382,11 @@ struct FieldOut {
 __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, FreqTable ft, rt_antenna_params ap, d3 tx,
                                                  const double *__restrict__ rx,
                                                  const unsigned long long *__restrict__ best_idx, FieldOut out) {
+    // one thread per (path, frequency): blockIdx.y is the frequency.  The frequency-independent set-up (antenna frames,
+    // angles) is cheap beside the coefficients and is simply redone per frequency; what it writes, frequency 0 writes.
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pa.n) return;
+    const int f = blockIdx.y;
     const int r = pa.rx[i];
     const int kind = pa.kind[i];
     d3 P[RT_MAX_ORDER + 2];
@@ -403,21 +409,23 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
     int status = ST_OK;
     double len = 0;
     for (int k = 0; k + 1 < np; ++k) len += norm3(P[k + 1] - P[k]);
-    out.time[i] = len / 299792458.0;
     double rr, tx_el = 0, tx_az = 0, rx_el = 0, rx_az = 0;
     if (!to_spherical(w2a(txa, P[1] - tx), rr, tx_el, tx_az)) status = ST_ORIGIN;
     if (!to_spherical(w2a(rxa, P[np - 2] - R), rr, rx_el, rx_az)) status = ST_ORIGIN;
-    const double deg = 180.0 / M_PI;
-    out.angles[4 * i + 0] = tx_el * deg;
-    out.angles[4 * i + 1] = tx_az * deg;
-    out.angles[4 * i + 2] = rx_el * deg;
-    out.angles[4 * i + 3] = rx_az * deg;
+    if (f == 0) {
+        const double deg = 180.0 / M_PI;
+        out.time[i] = len / 299792458.0;
+        out.angles[4 * i + 0] = tx_el * deg;
+        out.angles[4 * i + 1] = tx_az * deg;
+        out.angles[4 * i + 2] = rx_el * deg;
+        out.angles[4 * i + 3] = rx_az * deg;
+    }
 
     const int n_refl = kind & 255;
     const bool has_edge = (kind >> 8) != 0;
     const int32_t *chain = pa.chain + (size_t)i * RT_MAX_ORDER;
 
-    for (int f = 0; f < ft.n_freq; ++f) {
+    {
         const double K = ft.K[f];
         int st = status;
         c3 E;
@@ -460,9 +468,18 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
         fo[0] = E.x.re; fo[1] = E.x.im; fo[2] = E.y.re; fo[3] = E.y.im; fo[4] = E.z.re; fo[5] = E.z.im;
         out.power[(size_t)i * ft.n_freq + f] = power;
         atomicAdd(&out.power_sum[(size_t)r * ft.n_freq + f], power);
-        if (f == 0 || (status == ST_OK && st != ST_OK)) status = st;
+        // the status of a path is that of the lowest frequency at which something went wrong (the order in which a
+        // loop over the frequencies would have met it): keep the smallest (frequency, status) key
+        if (st != ST_OK) atomicMin(&out.status[i], (f << 8) | st);
     }
-    out.status[i] = status;
+}
+
+#define STATUS_UNSET 0x7f7f7f7f /* what hipMemset(0x7f) leaves: larger than any (frequency, status) key */
+__global__ void k_status_final(int32_t *__restrict__ status, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t key = status[i];
+    status[i] = key == STATUS_UNSET ? ST_OK : (key & 255);
 }
 
 __global__ void k_power_db(const double *__restrict__ sum, int64_t n, double p_in, double *__restrict__ db) {
@@ -730,8 +747,10 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         const unsigned grid = (unsigned)((n_paths + 255) / 256);
         hipLaunchKernelGGL(k_best_length, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len);
         hipLaunchKernelGGL(k_best_index, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len, best_idx);
-        hipLaunchKernelGGL(k_fields, dim3((unsigned)((n_paths + 127) / 128)), dim3(128), 0, st, scene->view, pa, ft, *antenna,
-                           TX, d_rx, best_idx, fo);
+        F_HIP(hipMemsetAsync(fo.status, 0x7f, sizeof(int32_t) * np_, st));
+        hipLaunchKernelGGL(k_fields, dim3((unsigned)((n_paths + 127) / 128), (unsigned)n_freq), dim3(128), 0, st, scene->view,
+                           pa, ft, *antenna, TX, d_rx, best_idx, fo);
+        hipLaunchKernelGGL(k_status_final, dim3(grid), dim3(256), 0, st, fo.status, (int64_t)n_paths);
     }
     hipLaunchKernelGGL(k_power_db, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, fo.power_sum,
                        (int64_t)(n_rx * nf), antenna->p_in, d_db);

@@ -11,11 +11,6 @@
 
 #include "rt_common.h"
 
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    return r * (2.0 - x * r);  // one Newton step: plenty for a pre-test with a 1e-6 pad
-}
-
 // What a launch works on: item i is segment i of the queue, or (paths given) the segment `round` places from the end
 // of path i, skipped when the path is already known to be blocked; out[i] is set when the item's segment is cut.
 // Testing a path's segments last to first, one launch per place, stops at the first cut segment: most paths of a
@@ -52,19 +47,6 @@ __device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double
             }
         }
     }
-}
-
-__device__ __forceinline__ bool occ_pretest(const OccRec *__restrict__ r, const SceneView &sc, d3 A, d3 V, double pad) {
-    const double nx = r->nx, ny = r->ny, nz = r->nz, d = r->d;
-    const double den = V.x * nx + V.y * ny + V.z * nz;
-    const double num = d + (A.x * nx + A.y * ny + A.z * nz);
-    const double ad = fabs(den);
-    const double sn = den < 0.0 ? num : -num;
-    bool cand = sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
-    const double t = sn * fast_rcp(ad);
-    const double hx = A.x + t * V.x - sc.gx0, hy = A.y + t * V.y - sc.gy0, hz = A.z + t * V.z - sc.gz0;
-    return cand && hx >= (double)r->lo[0] - pad && hx <= (double)r->hi[0] + pad && hy >= (double)r->lo[1] - pad &&
-           hy <= (double)r->hi[1] + pad && hz >= (double)r->lo[2] - pad && hz <= (double)r->hi[2] + pad;
 }
 
 // Every-polygon walk.  n_dev, when given, holds the segment count on the device (clamped to n_cap; a count above n_cap

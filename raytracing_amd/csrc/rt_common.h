@@ -210,6 +210,26 @@ __device__ inline bool polygon_cuts_segment(const SceneView &sc, int p, d3 A, d3
     return tol < t && t < 1 - tol;
 }
 
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    return r * (2.0 - x * r);  // one Newton step: plenty for a pre-test with a 1e-6 pad
+}
+
+// Padded, division-free form of the obstruction test for one pre-test record: false only when the exact test
+// (polygon_cuts_segment) is certainly false.  pad = 1e-5 max|V| + 1e-6.
+__device__ __forceinline__ bool occ_pretest(const OccRec *__restrict__ r, const SceneView &sc, d3 A, d3 V, double pad) {
+    const double nx = r->nx, ny = r->ny, nz = r->nz, d = r->d;
+    const double den = V.x * nx + V.y * ny + V.z * nz;
+    const double num = d + (A.x * nx + A.y * ny + A.z * nz);
+    const double ad = fabs(den);
+    const double sn = den < 0.0 ? num : -num;
+    bool cand = sn > 1e-8 * ad - 1e-11 && sn < (1.0 - 1e-8) * ad + 1e-11;
+    const double t = sn * fast_rcp(ad);
+    const double hx = A.x + t * V.x - sc.gx0, hy = A.y + t * V.y - sc.gy0, hz = A.z + t * V.z - sc.gz0;
+    return cand && hx >= (double)r->lo[0] - pad && hx <= (double)r->hi[0] + pad && hy >= (double)r->lo[1] - pad &&
+           hy <= (double)r->hi[1] + pad && hz >= (double)r->lo[2] - pad && hz <= (double)r->hi[2] + pad;
+}
+
 // OrientedPolygon.contains_point with check_in_plane (reference geometry.py:1792-1803): |n·p + d| within
 // atol + 1e-5|d| (numpy.allclose), then point-in-polygon in the polygon's own frame.
 __device__ inline bool polygon_contains_point(const SceneView &sc, int p, d3 X, bool check_in_plane, double plane_tol) {
