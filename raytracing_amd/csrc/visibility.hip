@@ -8,8 +8,8 @@
 // it.  Last, B must face A: some vertex p of A has normalize(p - centre(B))·n_B > 1e-4.
 //
 // The canvas a polygon is tested against holds the polygons that passed before it; a polygon hidden by the canvas
-// lies inside it, so leaving it out changes nothing and keeps the canvas small.  Faces are independent: one wave
-// paints one face, walking its candidates in sorted order.
+// lies inside it, so leaving it out changes nothing and keeps the canvas small.  Faces are independent: one workgroup
+// (four waves) paints one face, walking its candidates in sorted order.
 //
 // Coverage is decided exactly with witness points.  If part of B is uncovered, the uncovered region is bounded by
 // pieces of B's edges (region on B's inner side) and pieces of the C's edges (region on that C's outer side).  Every
@@ -18,9 +18,10 @@
 // decides it: B is visible iff some such point is inside B and outside every C.
 //
 // Kernels: k_vis_prepare (one thread per (face, polygon): mapping, keys, ring validity), k_vis_sort (one workgroup per
-// face: bitonic sort of its candidates by the painter's key) and k_vis_paint (persistent waves pulling faces from a
-// counter; inside a face, lanes work on different canvas polygons / edge pieces while the polygon being tested against
-// is wave-uniform).
+// face: bitonic sort of its candidates by the painter's key) and k_vis_paint (persistent workgroups pulling faces from
+// a counter; inside a face the candidate and the canvas polygons whose boxes meet its box are staged in LDS, the
+// candidate's edges and the canvas edges are dealt to the four waves, and inside a wave the lanes work on different
+// canvas polygons / edge pieces while the polygon being tested against is wave-uniform).
 #include <algorithm>
 #include <cstring>
 
