@@ -138,7 +138,7 @@ def test_contains_point_matches_oracle(places):
             assert got[interior].sum() > 5
 
 
-@pytest.mark.parametrize("name", ["small", "ny", "place_levant"])
+@pytest.mark.parametrize("name", ["small", "ny", "place_levant", "place_saint_jean/place_saint_jean"])
 def test_visibility_matrix_matches_oracle(places, name):
     from oracle import visibility_oracle as vo
     from raytracing_amd import geometry as geom
@@ -172,7 +172,29 @@ def test_emitter_visibility_matches_oracle(places):
             np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("name", ["small", "ny", "place_levant"])
+def test_visibility_rows_of_lln_match_oracle(places):
+    """lln.geojson (7 615 polygons) is too large for the oracle's full matrix in a test; rows of faces spread over
+    the scene (ground, roofs, walls) are compared instead, through the same entry point the matrix is built from."""
+    from oracle import visibility_oracle as vo
+    from raytracing_amd import geometry as geom
+
+    place = places("lln")
+    polygons = place.get_polygons_list()
+    polys = oracle_polys(place)
+    scene = geom.scene_arrays_of(polygons).device_scene()
+    faces = [0, 1, 2, 3] + list(range(17, len(polygons), len(polygons) // 36))
+    got = scene.faces_visibility([(polygons[i].points, polygons[i].get_parametric(), i) for i in faces], False)
+    n_visible = 0
+    packed = vo.PackedScene(polys)
+    for row, i in zip(got, faces):
+        want = vo.polygon_visibility_vector(polys[i], polys, self_index=i, packed=packed)
+        bad = np.flatnonzero(row != want)
+        assert len(bad) == 0, f"face {i}: {len(bad)} entries differ, first {bad[:10].tolist()}"
+        n_visible += int(row.sum())
+    assert n_visible > 1000
+
+
+@pytest.mark.parametrize("name", ["small", "ny", "place_levant", "place_saint_jean/place_saint_jean"])
 def test_sharp_edges_match_oracle(places, name):
     from oracle import geometry_oracle as go
     from raytracing_amd import geometry as geom
