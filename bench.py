@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the coverage-map-sized extra measurement")
     ap.add_argument("--n-side", type=int, default=32)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo to rehearse N > 1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 (rehearsal on a one-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -153,11 +155,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
 
     from raytracing_amd import _lib, scenarios
     from raytracing_amd import geometry as geom
@@ -212,14 +220,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(attempted)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(attempted)], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         attempted_all = float(tot.item())
         # per-receiver path counts of every rank on every rank: the one collective of the path (outside the timing)
-        counts = torch.bincount(o_rx[:found].long(), minlength=n_rx).to(torch.int32)
+        counts = torch.bincount(o_rx[:found].long(), minlength=n_rx).to(torch.int32).to(cdev)
         gathered = [torch.empty_like(counts) for _ in range(world)]
         dist.all_gather(gathered, counts)
         paths_all = int(sum(int(g.sum().item()) for g in gathered))
