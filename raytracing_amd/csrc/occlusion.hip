@@ -15,17 +15,23 @@
 // of path i, skipped when the path is already known to be blocked; out[i] is set when the item's segment is cut.
 // Testing a path's segments last to first, one launch per place, stops at the first cut segment: most paths of a
 // coverage map are blocked on the stretch that reaches the receiver, and their other segments are never walked.
+// With a polygon mask, the mask applies to the first n_masked segments of the queue, or (paths given) to the paths of
+// group -1: the lines of sight, which the reference tests against the polygons the emitter sees only
+// (ray_tracing.py:232-237); every other segment is tested against the whole scene.
 struct ObstructItems {
     const double *segs;
     const PathRec *paths;
     int round;
+    int64_t n_masked;
 };
 
 __device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t i, const uint8_t *__restrict__ out,
-                                             int64_t &seg) {
+                                             int64_t &seg, bool &masked) {
     seg = i;
+    masked = i < it.n_masked;
     if (!it.paths) return true;
     const PathRec &p = it.paths[i];
+    masked = p.group < 0;
     if (it.round >= p.nseg || out[i]) return false;
     seg = p.seg0 + (int64_t)(p.nseg - 1 - it.round) * p.seg_stride;
     return true;
@@ -79,7 +85,8 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
         int64_t seg = 0;
-        const bool active = s < n_seg && item_segment(items, s, out, seg);
+        bool use_mask = false;
+        const bool active = s < n_seg && item_segment(items, s, out, seg, use_mask);
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
         if (active) {
             A = ld3(segs + 6 * seg);
@@ -106,10 +113,9 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
             __syncthreads();
             if (wave_done) continue;
             for (int r = 0; r < cnt; ++r) {
-                if (MASKED) {
-                    if (!s_mask[r]) continue;  // wave-uniform
-                }
-                const bool cand = active && !hit && occ_pretest(&s_rec[r], sc, A, V, pad);
+                bool wanted = active && !hit;
+                if (MASKED) wanted = wanted && (!use_mask || s_mask[r]);
+                const bool cand = wanted && occ_pretest(&s_rec[r], sc, A, V, pad);
                 // pairs that pass the padded pre-test are parked and examined exactly 64 at a time, all lanes busy
                 const unsigned long long m = __ballot(cand);
                 if (m != 0) {
@@ -179,7 +185,8 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
         int64_t seg = 0;
-        const bool active = s < n_seg && item_segment(items, s, out, seg);
+        bool use_mask = false;
+        const bool active = s < n_seg && item_segment(items, s, out, seg, use_mask);
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
         if (active) {
             A = ld3(segs + 6 * seg);
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
                 const OccRec *r = sc.cell_recs + k;
                 poly = r->poly;
                 bool wanted = true;
-                if (MASKED) wanted = mask[poly] != 0;
+                if (MASKED) wanted = !use_mask || mask[poly] != 0;
                 if (wanted) cand = occ_pretest(r, sc, A, V, pad);
                 ++k;
                 if (k >= k_end) finished = !next_cell();
@@ -309,10 +316,12 @@ __global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const uns
 }
 
 // Obstruction flags of n_item items: segments of the queue, or with d_paths one segment per path (see ObstructItems;
-// then the flags are not cleared here: they accumulate over the rounds).  With d_count the device holds the item
+// then the flags are not cleared here: they accumulate over the rounds).  d_mask, when given, restricts the polygons
+// for the first n_masked segments / the line-of-sight paths.  With d_count the device holds the item
 // count (<= n_item) and the grid is sized for n_hint of them.
-int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, const uint8_t *d_mask, uint8_t *d_out,
-                       const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths, int round) {
+int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, const uint8_t *d_mask, int64_t n_masked,
+                       uint8_t *d_out, const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths,
+                       int round) {
     if (n_item == 0) return 0;
     const int block = 256;
     const int64_t n_grid = d_count ? (n_hint < 1 ? 1 : (n_hint > n_item ? n_item : n_hint)) : n_item;
@@ -333,7 +342,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
         else
             RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_item, scene->stream));
     }
-    const ObstructItems items{d_segs, d_paths, round};
+    const ObstructItems items{d_segs, d_paths, round, d_mask ? n_masked : 0};
     // small launches on small scenes are latency-bound: there the every-polygon walk, split over grid.y, is quicker
     const bool walk_grid = scene->occlusion_mode == 2 ||
                            (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
@@ -371,7 +380,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
     if (!segs || !out) RT_FAIL("rt_obstruct_segments: null array");
     RT_HIP(hipSetDevice(scene->device));
     if (on_device) {
-        if (rt_launch_obstruct(scene, segs, n_seg, mask, out, nullptr, 0, nullptr, 0)) return -1;
+        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, nullptr, 0)) return -1;
         RT_HIP(hipStreamSynchronize(scene->stream));
         return 0;
     }
@@ -385,7 +394,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
         if (hipMemcpyAsync(d_segs, segs, sizeof(double) * 6 * n_seg, hipMemcpyHostToDevice, scene->stream) != hipSuccess)
             break;
         if (mask && hipMemcpyAsync(d_mask, mask, scene->view.n, hipMemcpyHostToDevice, scene->stream) != hipSuccess) break;
-        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, d_out, nullptr, 0, nullptr, 0)) break;
+        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, nullptr, 0)) break;
         if (hipMemcpyAsync(out, d_out, n_seg, hipMemcpyDeviceToHost, scene->stream) != hipSuccess) break;
         if (hipStreamSynchronize(scene->stream) != hipSuccess) break;
         rc = 0;

@@ -24,8 +24,9 @@
 #include "rt_candidates.h"
 #include "rt_common.h"
 
-int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, uint8_t *d_out,
-                       const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths, int round);
+int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, int64_t n_masked,
+                       uint8_t *d_out, const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths,
+                       int round);
 int rt_launch_zero_bytes(rt_scene *scene, uint8_t *d_out, int64_t n_cap, const unsigned long long *d_count, int64_t n_hint);
 
 #define MIN_DISTANCE_TOL 0.005 /* ray_tracing.py:252 */
@@ -806,11 +807,25 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
     }
 }
 
-__global__ void k_los_segments(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t n, double *segs) {
+// The line of sight of every receiver of the chunk as the first records of the path queue (group -1, one segment),
+// and the queue counters started at that many records: the candidate kernels append behind them.
+__global__ void k_los_emit(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t n, Queues q) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        q.counters[0] = (unsigned long long)n;
+        q.counters[1] = (unsigned long long)n;
+    }
     if (i >= n) return;
-    st3(segs + 6 * i, tx);
-    st3(segs + 6 * i + 3, ld3(rx + 3 * (rx0 + i)));
+    PathRec &rec = q.paths[i];
+    rec.rx = (int32_t)(rx0 + i);
+    rec.group = -1;
+    rec.cand = 0;
+    rec.nseg = 1;
+    rec.seg0 = i;
+    rec.seg_stride = 1;
+    for (int k = 0; k < RT_MAX_ORDER * 3; ++k) rec.pts[k] = 0.0;
+    st3(q.segs + 6 * i, tx);
+    st3(q.segs + 6 * i + 3, ld3(rx + 3 * (rx0 + i)));
 }
 
 struct OutArrays {
@@ -819,17 +834,6 @@ struct OutArrays {
     int64_t cap;
     unsigned long long *count;
 };
-
-__global__ void k_los_finalize(const uint8_t *__restrict__ hit, int64_t rx0, int64_t n, OutArrays out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || hit[i]) return;
-    const int64_t slot = (int64_t)wave_reserve(out.count, 1u);
-    if (slot >= out.cap) return;
-    out.rx[slot] = (int32_t)(rx0 + i);
-    out.group[slot] = -1;
-    out.cand[slot] = 0;
-    for (int k = 0; k < RT_MAX_ORDER * 3; ++k) out.pts[slot * RT_MAX_ORDER * 3 + k] = 0.0;
-}
 
 // Keeps the queued paths none of whose segments is obstructed.  counters[0], counters[1] = paths and segments the
 // producers asked for; when either exceeds its queue the records are incomplete and nothing is done (the host redoes
@@ -885,8 +889,6 @@ __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ pa
         }
     }
 }
-
-__global__ void k_set_counter(unsigned long long *c, unsigned long long v) { *c = v; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // solve host side
@@ -1063,7 +1065,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_HIP(hipStreamSynchronize(st));
         if (n0 == 0) continue;
         timer.begin(2);
-        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, hit, nullptr, 0, nullptr, 0)) {
+        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, nullptr, 0)) {
             free_temps();
             return -1;
         }
@@ -1124,14 +1126,13 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     for (int64_t r0 = 0; r0 < n_rx;) {
         const int64_t r1 = std::min(n_rx, r0 + chunk);
         const int64_t nr = r1 - r0;
+        // workspace layout: paths | segs | hits.  The first nr records of both queues are the chunk's lines of sight.
+        if (path_cap < nr + 1024) path_cap = nr + 1024;
         const int64_t seg_cap = path_cap * 3;
-        // workspace layout: paths | segs | hits | los segs | los hits
         size_t off_paths = 0;
         size_t off_segs = align_up(off_paths + sizeof(PathRec) * path_cap);
         size_t off_hits = align_up(off_segs + sizeof(double) * 6 * seg_cap);
-        size_t off_lsegs = align_up(off_hits + (size_t)seg_cap);
-        size_t off_lhits = align_up(off_lsegs + sizeof(double) * 6 * nr);
-        size_t total = align_up(off_lhits + (size_t)nr);
+        size_t total = align_up(off_hits + (size_t)seg_cap);
         void *ws = nullptr;
         if (rt_scene_workspace(scene, total, &ws)) {
             free_temps();
@@ -1140,22 +1141,11 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         char *w = (char *)ws;
         Queues q{(PathRec *)(w + off_paths), (double *)(w + off_segs), path_cap, seg_cap, d_counters};
         uint8_t *d_hits = (uint8_t *)(w + off_hits);
-        double *d_lsegs = (double *)(w + off_lsegs);
-        uint8_t *d_lhits = (uint8_t *)(w + off_lhits);
-        SOLVE_HIP(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
-        // line of sight against the polygons the emitter sees (ray_tracing.py:232-237)
+        // lines of sight: queued like every other path, tested against the polygons the emitter sees only
+        // (ray_tracing.py:232-237); this launch also starts the queue counters
         timer.begin(3);
-        hipLaunchKernelGGL(k_los_segments, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, d_lsegs);
-        timer.end(3);
-        timer.begin(2);
-        if (rt_launch_obstruct(scene, d_lsegs, nr, cand->d_ev, d_lhits, nullptr, 0, nullptr, 0)) {
-            free_temps();
-            return -1;
-        }
-        timer.end(2);
-        timer.begin(3);
-        hipLaunchKernelGGL(k_los_finalize, dim3(blocks_for(nr, 256)), dim3(256), 0, st, d_lhits, r0, nr, out);
+        hipLaunchKernelGGL(k_los_emit, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, q);
         timer.end(3);
 
         // reflections
@@ -1203,11 +1193,11 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
                 return -1;
             }
             for (int round = 0; round < max_nseg; ++round)
-                if (rt_launch_obstruct(scene, q.segs, path_cap, nullptr, d_hits, d_counters, path_hint, q.paths, round)) {
+                if (rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters, path_hint, q.paths, round)) {
                     free_temps();
                     return -1;
                 }
-        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, nullptr, d_hits, d_counters + 1, seg_hint, nullptr, 0)) {
+        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, seg_hint, nullptr, 0)) {
             free_temps();
             return -1;
         }
@@ -1221,17 +1211,15 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_HIP(hipGetLastError());
         const int64_t n_paths = (int64_t)h_counters[0], n_segs = (int64_t)h_counters[1];
         if (n_paths > path_cap || n_segs > seg_cap) {
-            // survivors did not fit: nothing of this chunk but its lines of sight reached the outputs; take those
-            // back, grow the queues and redo the chunk
+            // survivors did not fit: nothing of this chunk reached the outputs; grow the queues and redo the chunk
             const int64_t need = std::max<int64_t>(n_paths, (n_segs + 2) / 3);
             path_cap = need + need / 8 + 1024;
-            hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, out.count, found_before);
             continue;
         }
         found_before = h_counters[2];
         scene->hint_paths = std::max<int64_t>(n_paths, 1);
         scene->hint_segments = std::max<int64_t>(n_segs, 1);
-        scene->last_segments += nr + n_segs;
+        scene->last_segments += n_segs;
         r0 = r1;
     }
     const unsigned long long found = found_before;
