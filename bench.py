@@ -250,7 +250,7 @@ def main():
         scene_bytes = 64.0 * n_poly + 24.0 * int(arrays.verts.shape[0])
         obstruct_bytes = 49.0 * seg_per_step + scene_bytes * launches["obstruct"]
         by_kernel = {
-            "reflect": {"kernel": "k_reflect<1>+k_reflect<2>", "bound": "valu_fp64",
+            "reflect": {"kernel": "k_reflect<2> (reflection orders 1 and 2 in one launch)", "bound": "valu_fp64",
                         "achieved": reflect_flop / (ms["reflect"] * 1e-3) / 1e12 if ms["reflect"] > 0 else 0.0,
                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "ms_per_step": ms["reflect"],
                         "launches_per_step": launches["reflect"], "algorithmic_flop_per_step": reflect_flop},

@@ -539,12 +539,12 @@ __device__ inline void reflect_exact(const SceneView &sc, const int32_t *__restr
 // parked in a per-wave LDS queue and solved exactly 64 at a time, so the expensive part runs with all lanes busy
 // instead of once per receiver with one or two lanes.
 template <int K>
-__global__ __launch_bounds__(256) void k_reflect(SceneView sc, const int32_t *__restrict__ chains, int64_t count,
-                                                  int group, d3 tx, const double *__restrict__ rx, int64_t rx0,
-                                                  int64_t rx1, int rx_tile, Queues q) {
-    __shared__ uint32_t wave_queue[4][128];
+__device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t *__restrict__ chains, int64_t count,
+                                              int group, d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t rx1,
+                                              int rx_tile, const Queues &q, unsigned block_x,
+                                              uint32_t (*wave_queue)[128]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t c_base = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+    const int64_t c_base = (int64_t)block_x * blockDim.x + wave * 64;
     const int64_t c = c_base + lane;
     const bool active = c < count;
     d3 prev = tx, nk = mk3(0, 0, 1);
@@ -602,6 +602,33 @@ __global__ __launch_bounds__(256) void k_reflect(SceneView sc, const int32_t *__
         const uint32_t e = wq[lane];
         const int64_t rr = r_begin + (e & 0xffffu);
         reflect_exact<K>(sc, chains, c_base + (e >> 16), group, tx, ld3(rx + 3 * rr), rr, q);
+    }
+}
+
+// All reflection orders of a solve in ONE launch (a small step is bound by the number of dependent launches): the
+// blocks [first_block[k-1], first_block[k]) of grid.x work on the k-reflection group.
+struct ReflectGroups {
+    const int32_t *chains[RT_MAX_ORDER];
+    int64_t count[RT_MAX_ORDER];
+    unsigned first_block[RT_MAX_ORDER + 1];
+};
+
+template <int MO>
+__global__ __launch_bounds__(256) void k_reflect(SceneView sc, ReflectGroups g, d3 tx, const double *__restrict__ rx,
+                                                  int64_t rx0, int64_t rx1, int rx_tile, Queues q) {
+    __shared__ uint32_t wave_queue[4][128];
+    const unsigned b = blockIdx.x;
+    if (b < g.first_block[1]) {
+        reflect_block<1>(sc, g.chains[0], g.count[0], 0, tx, rx, rx0, rx1, rx_tile, q, b, wave_queue);
+    } else if (MO >= 2 && b < g.first_block[2]) {
+        reflect_block<(MO >= 2 ? 2 : 1)>(sc, g.chains[1], g.count[1], 1, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[1],
+                                         wave_queue);
+    } else if (MO >= 3 && b < g.first_block[3]) {
+        reflect_block<(MO >= 3 ? 3 : 1)>(sc, g.chains[2], g.count[2], 2, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[2],
+                                         wave_queue);
+    } else if (MO >= 4) {
+        reflect_block<(MO >= 4 ? 4 : 1)>(sc, g.chains[3], g.count[3], 3, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[3],
+                                         wave_queue);
     }
 }
 
@@ -928,12 +955,30 @@ struct EventTimer {
     }
 };
 
-template <int K>
-static void launch_reflect(rt_scene *s, const CandGroup &g, int group, d3 tx, const double *rx, int64_t rx0, int64_t rx1,
+static void launch_reflect(rt_scene *s, const rt_candidates *cand, d3 tx, const double *rx, int64_t rx0, int64_t rx1,
                            int rx_tile, const Queues &q) {
-    dim3 grid(blocks_for(g.count, 256), blocks_for(rx1 - rx0, rx_tile));
-    hipLaunchKernelGGL(k_reflect<K>, grid, dim3(256), 0, s->stream, s->view, g.chains, g.count, group, tx, rx, rx0, rx1,
-                       rx_tile, q);
+    const int mo = cand->max_order;
+    ReflectGroups g{};
+    unsigned blocks = 0;
+    int top = 0;  // highest order that has candidates
+    for (int k = 1; k <= RT_MAX_ORDER; ++k) {
+        g.first_block[k - 1] = blocks;
+        if (k <= mo && cand->groups[k - 1].count > 0) {
+            g.chains[k - 1] = cand->groups[k - 1].chains;
+            g.count[k - 1] = cand->groups[k - 1].count;
+            blocks += blocks_for(g.count[k - 1], 256);
+            top = k;
+        }
+    }
+    g.first_block[RT_MAX_ORDER] = blocks;
+    if (blocks == 0) return;
+    dim3 grid(blocks, blocks_for(rx1 - rx0, rx_tile));
+    switch (top) {
+        case 1: hipLaunchKernelGGL(k_reflect<1>, grid, dim3(256), 0, s->stream, s->view, g, tx, rx, rx0, rx1, rx_tile, q); break;
+        case 2: hipLaunchKernelGGL(k_reflect<2>, grid, dim3(256), 0, s->stream, s->view, g, tx, rx, rx0, rx1, rx_tile, q); break;
+        case 3: hipLaunchKernelGGL(k_reflect<3>, grid, dim3(256), 0, s->stream, s->view, g, tx, rx, rx0, rx1, rx_tile, q); break;
+        default: hipLaunchKernelGGL(k_reflect<4>, grid, dim3(256), 0, s->stream, s->view, g, tx, rx, rx0, rx1, rx_tile, q); break;
+    }
 }
 
 template <int M>
@@ -1148,18 +1193,9 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         hipLaunchKernelGGL(k_los_emit, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, q);
         timer.end(3);
 
-        // reflections
+        // reflections of every order, one launch
         timer.begin(0);
-        for (int k = 1; k <= mo; ++k) {
-            const CandGroup &g = cand->groups[k - 1];
-            if (g.count == 0) continue;
-            switch (k) {
-                case 1: launch_reflect<1>(scene, g, k - 1, TX, d_rx, r0, r1, rx_tile, q); break;
-                case 2: launch_reflect<2>(scene, g, k - 1, TX, d_rx, r0, r1, rx_tile, q); break;
-                case 3: launch_reflect<3>(scene, g, k - 1, TX, d_rx, r0, r1, rx_tile, q); break;
-                default: launch_reflect<4>(scene, g, k - 1, TX, d_rx, r0, r1, rx_tile, q); break;
-            }
-        }
+        launch_reflect(scene, cand, TX, d_rx, r0, r1, rx_tile, q);
         timer.end(0);
         // diffractions
         if (any_diffraction) {
