@@ -81,24 +81,61 @@ def results_dir():
     return d
 
 
+def _float_strings(values):
+    """Strings NumPy's array printer gives the elements of a 1-D float array (default print options, spaces
+    removed), or None when the array holds a non-finite value (the caller then asks NumPy itself)."""
+    vals = [float(v) for v in values]
+    if not all(np.isfinite(vals)):
+        return None
+    nonzero = [abs(v) for v in vals if v != 0.0]
+    exp_format = bool(nonzero) and (max(nonzero) >= 1e8 or min(nonzero) < 1e-4 or max(nonzero) / min(nonzero) > 1e3)
+    if not exp_format:
+        return [np.format_float_positional(v, precision=8, unique=True, fractional=True, trim=".") for v in vals]
+    first = [np.format_float_scientific(v, precision=8, unique=True, trim=".") for v in vals]
+    mantissas, exponents = zip(*(t.split("e") for t in first))
+    digits = max(len(m.split(".")[1]) for m in mantissas)
+    exp_digits = max(len(e) for e in exponents) - 1
+    return [np.format_float_scientific(v, precision=digits, unique=True, min_digits=digits, trim="k", exp_digits=exp_digits)
+            for v in vals]
+
+
+def array_to_string(a):
+    """``np.array2string(a, separator=",").replace(" ", "")`` of a short 1-D real or complex array — the encoding of
+    the array columns of the reference's CSV (electromagnetism_utils.py:104-117) — without the array printer's set-up
+    cost per call; anything else goes through NumPy."""
+    a = np.asarray(a)
+    if a.ndim == 1 and 0 < a.size <= 16:
+        if a.dtype.kind == "f":
+            parts = _float_strings(a)
+            if parts is not None:
+                return "[" + ",".join(parts) + "]"
+        elif a.dtype.kind == "c":
+            re, im = _float_strings(a.real), _float_strings(a.imag)
+            if re is not None and im is not None:
+                return "[" + ",".join(r + (i if i[0] == "-" else "+" + i) + "j" for r, i in zip(re, im)) + "]"
+    return np.array2string(a, separator=",", max_line_width=999).replace(" ", "")
+
+
 def save_df(df, save_name):
     """CSV with the reference's column encoding (arrays as bracketed, comma-separated strings without spaces)."""
     if not save_name.endswith(".csv"):
         save_name += ".csv"
-    df = df.copy(deep=True)
-    df = df.astype(object)
+    out = df.copy(deep=False).astype(object)
+    possible = [t != "Impossible" for t in df["path_type"]]
+    out["field_strength"] = [array_to_string(v) for v in df["field_strength"]]
+    seen = {}  # a receiver has many rows: its position is formatted once
 
-    def enc(a):
-        return np.array2string(np.asarray(a), separator=",", max_line_width=999).replace(" ", "")
+    def receiver_string(v):
+        key = np.asarray(v, dtype=float).tobytes()
+        if key not in seen:
+            seen[key] = array_to_string(v)
+        return seen[key]
 
-    for i in range(len(df)):
-        df.at[i, "field_strength"] = enc(df.at[i, "field_strength"])
-        df.at[i, "receiver"] = enc(df.at[i, "receiver"])
-        if df.at[i, "path_type"] != "Impossible":
-            df.at[i, "tx_angles"] = enc(df.at[i, "tx_angles"])
-            df.at[i, "rx_angles"] = enc(df.at[i, "rx_angles"])
+    out["receiver"] = [receiver_string(v) for v in df["receiver"]]
+    for col in ("tx_angles", "rx_angles"):
+        out[col] = [array_to_string(v) if ok else v for v, ok in zip(df[col], possible)]
     path = save_name if os.path.isabs(save_name) else os.path.join(results_dir(), save_name)
-    df.to_csv(path, index=False)
+    out.to_csv(path, index=False)
     return path
 
 
@@ -106,10 +143,9 @@ def load_df(df_path):
     import pandas as pd
 
     df = pd.read_csv(df_path).astype(object)
-    for i in range(len(df)):
-        df.at[i, "receiver"] = string_arr_to_ndarray(df.at[i, "receiver"])
-        df.at[i, "field_strength"] = string_complex_arr_to_ndarray(df.at[i, "field_strength"])
-        if df.at[i, "path_type"] != "Impossible":
-            df.at[i, "tx_angles"] = string_arr_to_ndarray(df.at[i, "tx_angles"])
-            df.at[i, "rx_angles"] = string_arr_to_ndarray(df.at[i, "rx_angles"])
+    possible = [t != "Impossible" for t in df["path_type"]]
+    df["receiver"] = [string_arr_to_ndarray(v) for v in df["receiver"]]
+    df["field_strength"] = [string_complex_arr_to_ndarray(v) for v in df["field_strength"]]
+    for col in ("tx_angles", "rx_angles"):
+        df[col] = [string_arr_to_ndarray(v) if ok else v for v, ok in zip(df[col], possible)]
     return df

@@ -171,28 +171,33 @@ class RayTracingProblem:
 
     # ---- on-disk format of the reference (:66-132) -------------------------------------------------------
     def to_json(self, filename):
-        def enc(obj):
+        def plain(obj):
+            """Nested containers of arrays as nested lists (one C-level tolist() per array)."""
             if isinstance(obj, np.ndarray):
                 return obj.tolist()
-            if isinstance(obj, (np.integer,)):
+            if isinstance(obj, dict):
+                return {k: plain(v) for k, v in obj.items()}
+            if isinstance(obj, (list, tuple)):
+                return [plain(v) for v in obj]
+            if isinstance(obj, np.integer):
                 return int(obj)
-            if isinstance(obj, (np.floating,)):
+            if isinstance(obj, np.floating):
                 return float(obj)
-            raise TypeError(type(obj))
+            return obj
 
         data = {
             "place": self.place.to_json(),
-            "receivers": self.receivers,
-            "solved_receivers": self.solved_receivers,
-            "emitter": self.emitter,
+            "receivers": plain(self.receivers),
+            "solved_receivers": plain(self.solved_receivers),
+            "emitter": plain(self.emitter),
             "n_screens": self.n_screens,
-            "los": self.los,
-            "reflections": self.reflections,
-            "diffractions": self.diffractions,
+            "los": plain(self.los),
+            "reflections": plain(self.reflections),
+            "diffractions": plain(self.diffractions),
         }
         filename = filename if ".json" in filename else f"{filename}.json"
         with open(filename, "w") as f:
-            json.dump(data, f, default=enc)
+            f.write(json.dumps(data))  # one pass of the C encoder (json.dump would iterate in Python)
 
     @staticmethod
     def from_json(filename):

@@ -1,0 +1,37 @@
+"""End-to-end coverage map through the reference-named entry point (not a test): scene, receivers, solve, fields, files.
+python scripts/coverage_map.py lln 100 2"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+torch.cuda.init()
+sys.path.insert(0, ".")
+from raytracing_amd import electromagnetism_utils as emu, geometry as geom, scenarios  # noqa: E402
+from raytracing_amd.multithread_solve import multithread_solve_place  # noqa: E402
+
+name = sys.argv[1]
+n_side = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+order = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+path = f"data/{name}.geojson"
+if not os.path.exists(path):
+    path = f"data/{name}/{name}.geojson"
+os.environ.setdefault("RAYTRACING_AMD_RESULTS", tempfile.mkdtemp(prefix="coverage_"))
+t0 = time.perf_counter()
+place = geom.load_place(path)
+lo, hi = place.get_domain()
+tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
+rx = scenarios.lattice_receivers(place, n_side, 1.5)
+place.add_set_of_points(rx)
+print(name, "polygons", len(place.get_polygons_list()), "receivers", len(rx), f"scene {time.perf_counter()-t0:.2f}s", flush=True)
+t = time.perf_counter()
+em_path, rays_path = multithread_solve_place(place, tx.reshape(1, 3), name, order=order)
+print(f"multithread_solve_place {time.perf_counter()-t:.2f}s", flush=True)
+df = emu.load_df(em_path)
+db = emu.get_power_db_each_receiver(df)
+print("rows", len(df), "receivers with power", int(np.isfinite(db).sum()), "median dB", float(np.nanmedian(db[np.isfinite(db)])),
+      "files", os.path.getsize(em_path) >> 20, "MiB", os.path.getsize(rays_path) >> 20, "MiB", flush=True)
+print(f"total {time.perf_counter()-t0:.2f}s", flush=True)

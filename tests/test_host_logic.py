@@ -184,3 +184,32 @@ def test_scenarios_are_deterministic_and_outside_buildings():
     assert not scenarios._inside_any(fps, boxes, tx[0], tx[1])
     place, tx, rx = scenarios.small_place(16)
     np.testing.assert_array_equal(rx[3], [5.0, 3.0, 1.5])
+
+
+def test_array_to_string_is_numpys_encoding():
+    """The CSV's array columns are NumPy's own array2string with the spaces removed (the reference's save_df); the fast
+    encoder has to give the same text, whatever notation NumPy picks for the array."""
+    from raytracing_amd.electromagnetism_utils import array_to_string
+
+    def numpy_way(a):
+        return np.array2string(np.asarray(a), separator=",", max_line_width=999).replace(" ", "")
+
+    rng = np.random.default_rng(0)
+    cases = [np.array([1.0, 2.5, -3.25]), np.array([1e-5, 2.0, 3.0]), np.array([0.0, 0.0, 0.0]), np.array([-0.0, 1.5]),
+             np.array([1e8, 1.0, 2.0]), np.array([1e-4, 1.0, 999.0]), np.array([1e-4, 1.0, 1000.1]),
+             np.array([1 + 2j, 3.5e-6 - 1e-7j, 0j]), np.array([np.nan, 1.0]), np.array([np.inf, 1.0 + 0j]),
+             np.zeros((2, 2)), np.array([3])]
+    for trial in range(4000):
+        k = rng.integers(1, 5)
+        a = 10.0 ** rng.uniform(-12, 10, size=k) * rng.choice([-1, 1], size=k)
+        if trial % 3 == 0:
+            a = 10.0 ** rng.uniform(-2, 3, size=k)
+        if trial % 7 == 0:
+            a[rng.integers(0, k)] = 0.0
+        if trial % 11 == 0:
+            a = np.round(a, rng.integers(0, 5))
+        if trial % 2:
+            a = a + 1j * 10.0 ** rng.uniform(-12, 2, size=k) * rng.choice([-1, 1], size=k)
+        cases.append(a)
+    for a in cases:
+        assert array_to_string(a) == numpy_way(a), repr(a)
