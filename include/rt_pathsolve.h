@@ -3,7 +3,7 @@
  *
  * The reference (MaximeLeu/RayTracing) has no FFI layer: its path-solve path is plain Python
  * (raytracing/geometry.py, raytracing/ray_tracing.py, electromagnetism_fun/electromagnetism.py).  Each entry point
- * below names the reference function(s) it stands for; a Python binding only needs ctypes (see INTEGRATION.md).
+ * below names the reference function(s) it stands for; a Python binding only needs ctypes.
  *
  * Conventions
  *   - every function returns 0 on success and a negative code on failure; rt_last_error() gives the message of the
