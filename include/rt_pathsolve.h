@@ -69,6 +69,9 @@ int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_devic
  * default, picks by scene size.  Both give the same flags; the switch exists so that tests can check one against the
  * other (no reference counterpart). */
 int rt_debug_set_occlusion_mode(rt_scene *scene, int mode);
+/* First size of the solve's path queue in records (0 = chosen from the batch).  A queue that turns out too small is
+ * grown and the chunk redone; the switch exists so that tests can take that route (no reference counterpart). */
+int rt_debug_set_path_queue_capacity(rt_scene *scene, int64_t n_paths);
 /* Work counters of the visibility painter accumulated since the last call, then zeroed (profiling aid, no reference
  * counterpart): candidates, listed canvas polygons, canvas edges entering a candidate, edge cuts, candidates settled by
  * the interior-sample shortcut, polygons shown visible, canvas-edge examinations, edge examinations. out8[8]. */

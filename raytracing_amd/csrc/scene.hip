@@ -184,6 +184,12 @@ static int build_grid(rt_scene *s, int n_poly, const int32_t *vert_off, const do
     return 0;
 }
 
+extern "C" int rt_debug_set_path_queue_capacity(rt_scene *s, int64_t n_paths) {
+    if (!s || n_paths < 0) RT_FAIL("rt_debug_set_path_queue_capacity: bad argument");
+    s->queue_capacity_override = n_paths;
+    return 0;
+}
+
 extern "C" int rt_debug_set_occlusion_mode(rt_scene *s, int mode) {
     if (!s || mode < 0 || mode > 2) RT_FAIL("rt_debug_set_occlusion_mode: bad argument");
     s->occlusion_mode = mode;

@@ -1161,6 +1161,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     if (total_cand > 0 && chunk * total_cand > max_pairs_per_launch) chunk = std::max<int64_t>(1, max_pairs_per_launch / total_cand);
     int64_t path_cap = std::max<int64_t>(1 << 16, std::min<int64_t>(chunk * std::max<int64_t>(total_cand, 1) / 64 + 4096, 1ll << 26));
     path_cap = std::max<int64_t>(path_cap, scene->hint_paths + scene->hint_paths / 8);
+    if (scene->queue_capacity_override > 0) path_cap = scene->queue_capacity_override;
     // receivers per block of a candidate kernel: few enough that the launch has several waves per SIMD
     int64_t cand_blocks = 0;
     for (const CandGroup &g : cand->groups) cand_blocks += blocks_for(g.count, 256);

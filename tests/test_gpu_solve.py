@@ -178,6 +178,13 @@ def test_repeated_solves_and_obstruction_routes_agree(places):
         scene.set_occlusion_mode(mode)
         assert as_set(scene.solve_paths(cand, tx, rx)) == as_set(first)
     scene.set_occlusion_mode(0)
+    # a path queue that is too small at first: grown, chunk redone, same paths
+    scene.set_path_queue_capacity(300)
+    assert as_set(scene.solve_paths(cand, tx, rx)) == as_set(first)
+    scene.set_path_queue_capacity(0)
+    # no receivers, and an output capacity that is too small at first (the host wrapper asks again with room)
+    empty = scene.solve_paths(cand, tx, np.zeros((0, 3)))
+    assert len(empty["rx"]) == 0 and empty["n_attempted"] == 0
     # a subset of the receivers gives the subset of the paths
     sub = scene.solve_paths(cand, tx, rx[40:90])
     want = {(t[0] - 40,) + t[1:] for t in as_set(first) if 40 <= t[0] < 90}
