@@ -446,23 +446,24 @@ __device__ __forceinline__ double fast_rcp_s(double x) {
     return r * (2.0 - x * r);
 }
 
-// Adds `each` per calling lane to *counter with one atomic per wave (the calling lanes may be any subset of the wave)
-// and returns the calling lane's own base.
-__device__ __forceinline__ unsigned long long wave_reserve(unsigned long long *counter, unsigned each) {
+// Room for one path and its nseg segments per calling lane (nseg the same for every calling lane): one pair of
+// atomics per wave, both in flight together.
+__device__ inline bool reserve(const Queues &q, int nseg, int64_t &path_slot, int64_t &seg_slot) {
     const unsigned long long m = __ballot(1);
     const int lane = (int)(threadIdx.x & 63);
     const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1));
-    unsigned long long base = 0;
-    if (rank == 0) base = atomicAdd(counter, (unsigned long long)each * (unsigned)__popcll(m));
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
-    return (((unsigned long long)hi << 32) | lo) + (unsigned long long)each * rank;
-}
-
-// nseg must be the same for every calling lane
-__device__ inline bool reserve(const Queues &q, int nseg, int64_t &path_slot, int64_t &seg_slot) {
-    path_slot = (int64_t)wave_reserve(&q.counters[0], 1u);
-    seg_slot = (int64_t)wave_reserve(&q.counters[1], (unsigned)nseg);
+    const unsigned cnt = (unsigned)__popcll(m);
+    unsigned long long bp = 0, bs = 0;
+    if (rank == 0) {
+        bp = atomicAdd(&q.counters[0], (unsigned long long)cnt);
+        bs = atomicAdd(&q.counters[1], (unsigned long long)cnt * (unsigned)nseg);
+    }
+    const unsigned plo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bp);
+    const unsigned phi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bp >> 32));
+    const unsigned slo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bs);
+    const unsigned shi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bs >> 32));
+    path_slot = (int64_t)((((unsigned long long)phi << 32) | plo) + rank);
+    seg_slot = (int64_t)((((unsigned long long)shi << 32) | slo) + (unsigned long long)rank * (unsigned)nseg);
     return path_slot < q.path_cap && seg_slot + nseg <= q.seg_cap;
 }
 
@@ -502,9 +503,11 @@ __device__ inline void reflect_exact(const SceneView &sc, const int32_t *__restr
         prev = img[i];
     }
     if (!unfold_exact<K>(nrm, g, img, R, X)) return;
+    // ray_tracing.py:253-255; all K tests are made before looking at any of them, so that their loads overlap
+    bool inside = true;
 #pragma unroll
-    for (int i = 0; i < K; ++i)
-        if (!polygon_contains_point(sc, poly[i], X[i], true, 1e-8)) return;  // ray_tracing.py:253-255
+    for (int i = 0; i < K; ++i) inside = polygon_contains_point(sc, poly[i], X[i], true, 1e-8) && inside;
+    if (!inside) return;
     // ray_tracing.py:268-272
     d3 a = tx;
 #pragma unroll
