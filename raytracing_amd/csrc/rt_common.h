@@ -187,13 +187,26 @@ __device__ inline bool polygon_cuts_segment(const SceneView &sc, int p, d3 A, d3
     frame_from_vector(V, fx, fy, fz);
     const double z_min = dot(A, fz), z_max = dot(B, fz);
     const int v0 = sc.vert_off[p], nv = sc.vert_off[p + 1] - v0;
-    double zlo = INFINITY, zhi = -INFINITY;
-    for (int v = 0; v < nv; ++v) {
-        double z = dot(ld3(sc.verts + 3 * (size_t)(v0 + v)), fz);
-        zlo = fmin(zlo, z);
-        zhi = fmax(zhi, z);
+    // extent of the polygon along the segment (geometry.py:866-871): some vertex beyond the start and some before the
+    // end.  The polygon's box bounds every vertex, so where the box settles the matter (with a margin far above the
+    // rounding of the sums) the loop over the vertices is not needed; a roof can have tens of them.
+    {
+        const double *bb = sc.bbox + 6 * (size_t)p;
+        const double cx = 0.5 * (bb[0] + bb[3]), cy = 0.5 * (bb[1] + bb[4]), cz = 0.5 * (bb[2] + bb[5]);
+        const double zc = cx * fz.x + cy * fz.y + cz * fz.z;
+        const double r = 0.5 * ((bb[3] - bb[0]) * fabs(fz.x) + (bb[4] - bb[1]) * fabs(fz.y) + (bb[5] - bb[2]) * fabs(fz.z));
+        const double eps = 1e-9 * (fabs(zc) + r + fabs(z_min) + fabs(z_max) + 1.0);
+        if (zc + r + eps <= z_min || zc - r - eps >= z_max) return false;
+        if (!(zc - r - eps > z_min && zc + r + eps < z_max)) {
+            double zlo = INFINITY, zhi = -INFINITY;
+            for (int v = 0; v < nv; ++v) {
+                double z = dot(ld3(sc.verts + 3 * (size_t)(v0 + v)), fz);
+                zlo = fmin(zlo, z);
+                zhi = fmax(zhi, z);
+            }
+            if (!(zhi > z_min && zlo < z_max)) return false;
+        }
     }
-    if (!(zhi > z_min && zlo < z_max)) return false;
     const double px = dot(A, fx), py = dot(A, fy);
     const double *vb = sc.verts + 3 * (size_t)v0;
     bool in = pip_inclusive(

@@ -869,7 +869,8 @@ struct OutArrays {
 // producers asked for; when either exceeds its queue the records are incomplete and nothing is done (the host redoes
 // the chunk with larger queues).  hit holds one flag per segment, or (per_path) one per path.  A wave looks at 512
 // paths and reserves the room of its survivors with one atomic.
-#define FINALIZE_ITEMS 8
+// FINALIZE_ITEMS = 8 paths per lane for large batches (few atomics), 1 for small ones (more waves, shorter chains).
+template <int FINALIZE_ITEMS>
 __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ paths, const uint8_t *__restrict__ hit,
                                                    const unsigned long long *__restrict__ counters, int64_t path_cap,
                                                    int64_t seg_cap, int per_path, OutArrays out) {
@@ -1243,8 +1244,12 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         }
         timer.end(2);
         timer.begin(3);
-        hipLaunchKernelGGL(k_finalize, dim3(std::min<unsigned>(blocks_for(path_hint, 256 * FINALIZE_ITEMS), 1u << 16)), dim3(256), 0, st, q.paths,
-                           d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out);
+        if (path_hint >= (1 << 16))
+            hipLaunchKernelGGL(k_finalize<8>, dim3(std::min<unsigned>(blocks_for(path_hint, 256 * 8), 1u << 16)), dim3(256), 0, st,
+                               q.paths, d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out);
+        else
+            hipLaunchKernelGGL(k_finalize<1>, dim3(blocks_for(path_hint + path_hint / 4 + 256, 256)), dim3(256), 0, st, q.paths,
+                               d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out);
         timer.end(3);
         SOLVE_HIP(hipMemcpyAsync(h_counters, d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         SOLVE_HIP(hipStreamSynchronize(st));
