@@ -330,7 +330,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     // few items: split the polygon list over grid.y so the launch still fills the chip (target >= ~2048 waves)
     const int64_t waves = grid * (block / RT_WAVE);
     int64_t ny = waves >= 2048 ? 1 : (2048 + waves - 1) / waves;
-    const int64_t max_ny = (scene->view.n + 31) / 32;
+    const int64_t max_ny = (scene->view.n + 7) / 8;
     ny = ny > max_ny ? max_ny : ny;
     ny = ny < 1 ? 1 : ny;
     int poly_chunk = (int)((scene->view.n + ny - 1) / ny);
