@@ -65,6 +65,9 @@ int rt_face_visibility(rt_scene *scene, const double *face_verts, int32_t n_face
 int rt_faces_visibility(rt_scene *scene, int32_t n_faces, const int32_t *face_off, const double *face_verts,
                         const double *face_normals, const int32_t *self_index, int strict, uint8_t *out);
 int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_device);
+/* rows of that matrix before it is symmetrised (geometry.py:1036-1046 for the listed i only): out[n_rows*N], row k =
+ * what polygon row_ids[k] sees.  matrix = rows | rows^T once every row is there; a node deals the rows to its GPUs. */
+int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *out);
 /* Obstruction tests either walk every polygon (mode 1) or a uniform grid over the scene (mode 2); mode 0, the
  * default, picks by scene size.  Both give the same flags; the switch exists so that tests can check one against the
  * other (no reference counterpart). */

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "rt_segment_hits": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rt_contains_points": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int, c_double, c_void_p, c_int]),
     "rt_face_visibility": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_void_p]),
+    "rt_visibility_rows": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p]),
     "rt_faces_visibility": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_debug_visibility_stats": (c_int, [c_void_p]),
     "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
@@ -252,6 +253,14 @@ class Scene:
         out = np.zeros((len(faces), self.n), dtype=np.uint8)
         _check(load().rt_faces_visibility(self.handle, len(faces), _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs),
                                           int(bool(strict)), _ptr(out)), "rt_faces_visibility")
+        return out.astype(bool)
+
+    def visibility_rows(self, row_ids, strict=False):
+        """Rows of the visibility matrix before symmetrisation: bool [len(row_ids), N]."""
+        rows = np.ascontiguousarray(row_ids, dtype=np.int32)
+        out = np.zeros((len(rows), self.n), dtype=np.uint8)
+        _check(load().rt_visibility_rows(self.handle, len(rows), _ptr(rows), int(bool(strict)), _ptr(out)),
+               "rt_visibility_rows")
         return out.astype(bool)
 
     def visibility_matrix(self, strict=False):

@@ -833,6 +833,41 @@ extern "C" int rt_face_visibility(rt_scene *scene, const double *face_verts, int
     return rt_faces_visibility(scene, 1, off, face_verts, face_normal, &self_index, strict, out);
 }
 
+// Rows of the visibility matrix before symmetrisation: row k of `out` = what polygon row_ids[k] sees
+// (geometry.py:1036-1046 restricted to some i).  The full matrix is the OR of all rows with their transpose; a node
+// shares the rows out over its GPUs and all-gathers them.
+extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *out) {
+    if (!scene || (n_rows > 0 && (!row_ids || !out))) RT_FAIL("rt_visibility_rows: null argument");
+    if (n_rows < 0) RT_FAIL("rt_visibility_rows: negative count");
+    if (n_rows == 0) return 0;
+    const int n = scene->view.n;
+    RT_HIP(hipSetDevice(scene->device));
+    for (int k = 0; k < n_rows; ++k)
+        if (row_ids[k] < 0 || row_ids[k] >= n) RT_FAIL("rt_visibility_rows: row index out of range");
+    DevBuf d_out;
+    if (d_out.alloc((size_t)n * n_rows)) RT_FAIL("rt_visibility_rows: out of device memory");
+    const size_t per_face = sizeof(double) * 2 * (size_t)scene->view.vtot + (sizeof(PolyMeta) + 8) * (size_t)n;
+    int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_rows, ((size_t)24 << 30) / per_face));
+    batch = std::min(batch, 65535);
+    for (int k0 = 0; k0 < n_rows; k0 += batch) {
+        const int k1 = std::min(n_rows, k0 + batch);
+        std::vector<int32_t> a_off(1, 0), a_self;
+        std::vector<double> a_verts, a_normal;
+        for (int k = k0; k < k1; ++k) {
+            const int i = row_ids[k];
+            const int v0 = scene->h_vert_off[i], v1 = scene->h_vert_off[i + 1];
+            a_verts.insert(a_verts.end(), scene->h_verts.begin() + 3 * (size_t)v0, scene->h_verts.begin() + 3 * (size_t)v1);
+            a_off.push_back(a_off.back() + (v1 - v0));
+            a_normal.insert(a_normal.end(), scene->h_planes.begin() + 4 * (size_t)i, scene->h_planes.begin() + 4 * (size_t)i + 3);
+            a_self.push_back(i);
+        }
+        if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_out.p + (size_t)k0 * n)) return -1;
+    }
+    RT_HIP(hipStreamSynchronize(scene->stream));
+    RT_HIP(hipMemcpy(out, d_out.p, (size_t)n * n_rows, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_device) {
     if (!scene || !out) RT_FAIL("rt_visibility_matrix: null argument");
     RT_HIP(hipSetDevice(scene->device));

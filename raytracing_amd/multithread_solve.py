@@ -101,6 +101,45 @@ def _decode_paths(problem, rows):
             problem.diffractions[r][order].append((lines, chain, (int(row[26]), int(row[27])), row[28:34].reshape(2, 3).copy()))
 
 
+def gather_visibility_rows(rows_of, n, dist=None):
+    """Visibility matrix of an n-polygon scene from rows computed rank by rank: rank r computes rows r, r + W, r + 2W ...
+    (``rows_of(ids)`` -> bool [len(ids), n], unsymmetrised; interleaved because neighbouring rows cost alike), one
+    all-gather of the byte rows, then matrix = rows | rows^T (geometry.py:1036-1048)."""
+    import torch
+
+    dist = dist or _dist()
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    mine = np.arange(rank, n, world, dtype=np.int32)
+    local = np.ascontiguousarray(rows_of(mine), dtype=np.uint8).reshape(len(mine), n)
+    matrix = np.zeros((n, n), dtype=bool)
+    if dist is None:
+        matrix[mine] = local.astype(bool)
+    else:
+        dev = _device_for_collectives(dist)
+        pad = (n + world - 1) // world
+        buf = torch.zeros((pad, n), dtype=torch.uint8, device=dev)
+        buf[:len(mine)] = torch.from_numpy(local).to(dev)
+        bufs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(bufs, buf)
+        for r, b in enumerate(bufs):
+            ids = np.arange(r, n, world)
+            matrix[ids] = b[:len(ids)].cpu().numpy().astype(bool)
+    return matrix | matrix.T
+
+
+def sharded_visibility_matrix(place, strict=False):
+    """``place.get_visibility_matrix()`` with the rows dealt to the ranks of the process group; the result is cached on
+    the place like the reference's (geometry.py:1467-1483), on every rank."""
+    from . import geometry as geom
+
+    if place.visibility_matrix is None:
+        polygons = place.get_polygons_list()
+        scene = geom.scene_arrays_of(polygons).device_scene()
+        place.visibility_matrix = gather_visibility_rows(lambda ids: scene.visibility_rows(ids, strict), len(polygons))
+    return place.visibility_matrix
+
+
 def solve_sharded(problem, order):
     """Solves this rank's block of receivers, then gives every rank every receiver's paths."""
     dist = _dist()
@@ -131,6 +170,8 @@ def multithread_solve_place(place, tx, geometry, N_CPU=16, order=3, save_name=No
     dist = _dist()
     rank = dist.get_rank() if dist else 0
     t0 = time.time()
+    if dist is not None and dist.get_world_size() > 1:
+        sharded_visibility_matrix(place)  # the one precompute step worth sharing out: every rank needs the whole matrix
     problem = RayTracingProblem(tx, place)
     solve_sharded(problem, order)
     out_dir = electromagnetism_utils.results_dir()

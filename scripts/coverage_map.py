@@ -20,6 +20,13 @@ path = f"data/{name}.geojson"
 if not os.path.exists(path):
     path = f"data/{name}/{name}.geojson"
 os.environ.setdefault("RAYTRACING_AMD_RESULTS", tempfile.mkdtemp(prefix="coverage_"))
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+if world > 1:  # torchrun: one process per GPU (RT_BACKEND=gloo rehearses several ranks on one GPU)
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("RT_BACKEND", "nccl"))
 t0 = time.perf_counter()
 place = geom.load_place(path)
 lo, hi = place.get_domain()
@@ -30,6 +37,8 @@ print(name, "polygons", len(place.get_polygons_list()), "receivers", len(rx), f"
 t = time.perf_counter()
 em_path, rays_path = multithread_solve_place(place, tx.reshape(1, 3), name, order=order)
 print(f"multithread_solve_place {time.perf_counter()-t:.2f}s", flush=True)
+if rank != 0:
+    sys.exit(0)
 df = emu.load_df(em_path)
 db = emu.get_power_db_each_receiver(df)
 print("rows", len(df), "receivers with power", int(np.isfinite(db).sum()), "median dB", float(np.nanmedian(db[np.isfinite(db)])),

@@ -1,0 +1,28 @@
+"""Time of single rows of the visibility matrix (not a test): python scripts/painter_probe.py lln"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from raytracing_amd import _lib, geometry as geom  # noqa: E402
+
+name = sys.argv[1]
+path = f"data/{name}.geojson"
+if not os.path.exists(path):
+    path = f"data/{name}/{name}.geojson"
+place = geom.load_place(path)
+polygons = place.get_polygons_list()
+scene = _lib.Scene(geom.scene_arrays_of(polygons))
+scene.faces_visibility([(polygons[1].points, polygons[1].get_parametric(), 1)], False)  # warm-up
+n = len(polygons)
+for i in [0, 1, 2, 3, n // 3, n // 2, n - 1]:
+    t = time.perf_counter()
+    v = scene.faces_visibility([(polygons[i].points, polygons[i].get_parametric(), i)], False)
+    print(f"row {i}: {1e3*(time.perf_counter()-t):8.2f} ms, sees {int(v.sum())}, vertices {len(polygons[i].points)}", flush=True)
+for lo_, hi_ in [(0, 1), (1, n), (0, n)]:
+    faces = [(polygons[i].points, polygons[i].get_parametric(), i) for i in range(lo_, hi_)]
+    t = time.perf_counter()
+    v = scene.faces_visibility(faces[:65535], False)
+    print(f"rows [{lo_},{min(hi_, lo_ + 65535)}): {1e3*(time.perf_counter()-t):8.2f} ms", flush=True)

@@ -85,3 +85,53 @@ def test_single_process_gather_is_identity():
 
     a = np.arange(12.0).reshape(4, 3)
     np.testing.assert_array_equal(all_gather_rows(a), a)
+
+
+def _stub_rows(n):
+    """A deterministic unsymmetrised 'sees' relation standing in for the GPU rows."""
+    rng = np.random.default_rng(42)
+    full = rng.random((n, n)) < 0.2
+    np.fill_diagonal(full, False)
+    return full
+
+
+def _vis_worker(rank, world, port, n, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracing_amd import multithread_solve as mts
+
+    full = _stub_rows(n)
+    asked = []
+
+    def rows_of(ids):
+        asked.extend(int(i) for i in ids)
+        return full[ids]
+
+    matrix = mts.gather_visibility_rows(rows_of, n)
+    np.save(os.path.join(out_dir, f"vis_{rank}.npy"), matrix)
+    np.save(os.path.join(out_dir, f"asked_{rank}.npy"), np.array(asked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 7, 64])
+def test_two_rank_visibility_rows(tmp_path, n):
+    """Rows dealt to two ranks (interleaved), all-gathered and symmetrised: every rank ends with rows | rows^T and each
+    row was computed by exactly one rank."""
+    import torch.multiprocessing as mp
+
+    from raytracing_amd import multithread_solve as mts
+
+    port = 31500 + (os.getpid() % 2000) + n
+    mp.spawn(_vis_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    full = _stub_rows(n)
+    want = full | full.T
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / f"vis_{r}.npy"), want)
+    asked = np.concatenate([np.load(tmp_path / f"asked_{r}.npy") for r in range(2)])
+    assert sorted(asked.tolist()) == list(range(n))
+    # without a process group: one rank does every row
+    np.testing.assert_array_equal(mts.gather_visibility_rows(lambda ids: full[ids], n), want)

@@ -172,6 +172,26 @@ def test_emitter_visibility_matches_oracle(places):
             np.testing.assert_array_equal(got, want)
 
 
+def test_visibility_rows_reassemble_the_matrix(places):
+    """The matrix is rows | rows^T whatever the split of the rows (what a node does over its GPUs)."""
+    from raytracing_amd import geometry as geom
+    from raytracing_amd.multithread_solve import gather_visibility_rows
+
+    place = places("place_levant")
+    polygons = place.get_polygons_list()
+    scene = geom.scene_arrays_of(polygons).device_scene()
+    full = scene.visibility_matrix(False)
+    n = len(polygons)
+    assert scene.visibility_rows(np.zeros(0, dtype=np.int32)).shape == (0, n)
+    rows = np.zeros((n, n), dtype=bool)
+    for part in (np.arange(0, n, 3), np.arange(1, n, 3), np.arange(2, n, 3)[::-1]):
+        rows[part] = scene.visibility_rows(part, False)
+    np.testing.assert_array_equal(rows | rows.T, full)
+    np.testing.assert_array_equal(gather_visibility_rows(lambda ids: scene.visibility_rows(ids, False), n), full)
+    with pytest.raises(Exception):
+        scene.visibility_rows([n], False)
+
+
 def test_visibility_rows_of_lln_match_oracle(places):
     """lln.geojson (7 615 polygons) is too large for the oracle's full matrix in a test; rows of faces spread over
     the scene (ground, roofs, walls) are compared instead, through the same entry point the matrix is built from."""
