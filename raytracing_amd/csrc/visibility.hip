@@ -36,6 +36,12 @@
 // Work counters of the painter (candidates, listed polygons, edges examined, pieces examined, shortcut hits, polygons
 // shown visible, edge_has_witness calls from canvas edges, cut gathers), summed over a launch; read by the profiling scripts.
 __device__ unsigned long long g_vis_stats[8];
+__device__ unsigned long long g_vis_phase[16];
+extern "C" int rt_debug_visibility_phases(unsigned long long *out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_vis_phase), sizeof(g_vis_phase)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_vis_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
 // Compiled in only for profiling builds (-DRT_VIS_STATS, ~170 M updates on a 7 615-polygon scene); otherwise
 // rt_debug_visibility_stats reads zeros.
 #ifdef RT_VIS_STATS
@@ -267,6 +273,36 @@ struct LocalSet {
     __device__ int sgn(int i) const { return st->sgns[i]; }
 };
 
+// The canvas of the face being painted, resident in LDS: every polygon found visible so far with its box and mapped
+// vertices, so that a candidate only brings its own vertices in from global memory (the listed polygons of every
+// candidate used to be gathered again and again).  The candidate is staged in the next free slot; when it turns out
+// visible the slot is simply kept.  A face whose canvas outgrows the store continues on the staged / global views.
+#define CS_MAX_POLY 320
+#define CS_MAX_COORD 3072 /* doubles: 1536 vertices */
+struct CanvasStore {
+    int nvs[CS_MAX_POLY], offs[CS_MAX_POLY], sgns[CS_MAX_POLY];
+    int list[CS_MAX_POLY];  // slots listed for the current candidate
+    double boxes[CS_MAX_POLY * 4];
+    double xy[CS_MAX_COORD];
+};
+struct CanvasSet {
+    const CanvasStore *st;
+    int b_slot, n;
+    __device__ int slot(int i) const { return i == 0 ? b_slot : st->list[i - 1]; }
+    __device__ int count() const { return n; }
+    __device__ int nv(int i) const { return st->nvs[slot(i)]; }
+    __device__ const double *x(int i) const { return st->xy + st->offs[slot(i)]; }
+    __device__ const double *y(int i) const {
+        const int k = slot(i);
+        return st->xy + st->offs[k] + st->nvs[k];
+    }
+    __device__ void box(int i, double &x0, double &x1, double &y0, double &y1) const {
+        const int k = slot(i);
+        x0 = st->boxes[4 * k]; x1 = st->boxes[4 * k + 1]; y0 = st->boxes[4 * k + 2]; y1 = st->boxes[4 * k + 3];
+    }
+    __device__ int sgn(int i) const { return st->sgns[slot(i)]; }
+};
+
 // Is the witness next to the middle of piece (t0, t1) of edge a->b, on side `side` (+1 = left of a->b), inside B and
 // outside every listed polygon?
 template <typename Set>
@@ -318,10 +354,13 @@ __device__ inline int edge_cuts(double ax, double ay, double bx, double by, doub
 
 // Cut parameters of the edge being examined: the first SPLIT_LDS live in LDS, the rare overflow in global memory.
 #define SPLIT_LDS 192
+#define PIECE_LDS 64 /* pieces (or sample points) whose witnesses are tested with lanes = (piece, entry) pairs */
 struct SplitBuf {
     double *lds;     // [SPLIT_LDS]
     double *glob;    // [cap]
     int64_t cap;
+    double *px, *py; // [PIECE_LDS] witness points of the pieces of the edge being examined
+    int *pstate;     // [PIECE_LDS] 1 while the witness is still a proof of visibility
     __device__ void put(int i, double t) const {
         if (i < SPLIT_LDS) lds[i] = t;
         else if (i < cap) glob[i] = t;
@@ -381,6 +420,46 @@ __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay,
         VIS_STAT(7, 1);
     }
     // ---- every piece (t_j, next larger cut or 1)
+    if (n_splits <= PIECE_LDS) {
+        // lanes = pieces: the witness point of each; then lanes = (piece, entry) pairs: a witness outside B (when it has
+        // to be inside) or inside another entry proves nothing.  Same tests as witness_uncovered, spread over the lanes
+        // instead of one lane walking every entry.
+        if (lane < n_splits) {
+            const double t0 = splits.get(lane);
+            double t1 = 1.0;
+            for (int i = 0; i < n_splits; ++i) {
+                const double ti = splits.get(i);
+                if (ti > t0 && ti < t1) t1 = ti;
+            }
+            const double tm = 0.5 * (t0 + t1);
+            splits.px[lane] = ax + tm * ex - side * VIS_DELTA * (ey / len);
+            splits.py[lane] = ay + tm * ey + side * VIS_DELTA * (ex / len);
+            splits.pstate[lane] = (t1 - t0) * len > VIS_MIN_PIECE ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int first = need_in_b ? 0 : 1;
+        const int per_piece = n - first;
+        const int n_pairs = n_splits * per_piece;
+        for (int base = 0; base < n_pairs; base += 64) {
+            const int pair = base + lane;
+            if (pair < n_pairs) {
+                const int j = pair / per_piece, i = first + pair % per_piece;
+                if (splits.pstate[j]) {
+                    const double wx = splits.px[j], wy = splits.py[j];
+                    if (i == 0) {
+                        if (!pip_ring(ps.x(0), ps.y(0), ps.nv(0), wx, wy)) splits.pstate[j] = 0;
+                    } else {
+                        double x0, x1, y0, y1;
+                        ps.box(i, x0, x1, y0, y1);
+                        if (!(wx < x0 || wx > x1 || wy < y0 || wy > y1) && pip_ring(ps.x(i), ps.y(i), ps.nv(i), wx, wy))
+                            splits.pstate[j] = 0;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        return __any(lane < n_splits && splits.pstate[lane] != 0);
+    }
     bool found = false;
     for (int base = 0; base < n_splits && !found; base += 64) {
         const int j = base + lane;
@@ -410,6 +489,20 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
     const double *x = ps.x(0), *y = ps.y(0);
     double bx0, bx1, by0, by1;
     ps.box(0, bx0, bx1, by0, by1);
+#ifdef RT_VIS_STAMPS
+    unsigned long long t_prev = wall_clock64();
+#define PHASE(i)                                                                                 \
+    do {                                                                                         \
+        const unsigned long long now_ = wall_clock64();                                          \
+        if (threadIdx.x == 0) {                                                                  \
+            atomicAdd(&g_vis_phase[2 * (i)], now_ - t_prev);                                     \
+            atomicAdd(&g_vis_phase[2 * (i) + 1], 1ull);                                          \
+        }                                                                                        \
+        t_prev = now_;                                                                           \
+    } while (0)
+#else
+#define PHASE(i)
+#endif
     bool visible = false;
     // ---- shortcut: a few points inside B (vertex average and the points halfway to some vertices); one of them
     // outside every other entry proves B visible.  Lanes = entries.
@@ -422,63 +515,84 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
         gx /= nv;
         gy /= nv;
         const int n_samples = nv < 8 ? nv + 1 : 9;
-        for (int sidx = 0; sidx < n_samples && !visible; ++sidx) {
-            const double px = sidx == 0 ? gx : 0.5 * (gx + x[(sidx - 1) * nv / (n_samples - 1)]);
-            const double py = sidx == 0 ? gy : 0.5 * (gy + y[(sidx - 1) * nv / (n_samples - 1)]);
-            if (!pip_ring(x, y, nv, px, py)) continue;  // wave-uniform
-            bool covered = false;
-            for (int base = 1; base < n && !covered; base += 64) {
-                const int li = base + lane;
-                bool in = false;
-                if (li < n) {
+        // lanes = samples: the point, and whether it is inside B; then lanes = (sample, entry) pairs
+        if (lane < n_samples) {
+            const double px = lane == 0 ? gx : 0.5 * (gx + x[(lane - 1) * nv / (n_samples - 1)]);
+            const double py = lane == 0 ? gy : 0.5 * (gy + y[(lane - 1) * nv / (n_samples - 1)]);
+            splits.px[lane] = px;
+            splits.py[lane] = py;
+            splits.pstate[lane] = pip_ring(x, y, nv, px, py) ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int per_sample = n - 1;
+        const int n_pairs = n_samples * per_sample;
+        for (int base = 0; base < n_pairs; base += 64) {
+            const int pair = base + lane;
+            if (pair < n_pairs) {
+                const int sidx = pair / per_sample, li = 1 + pair % per_sample;
+                if (splits.pstate[sidx]) {
+                    const double px = splits.px[sidx], py = splits.py[sidx];
                     double x0, x1, y0, y1;
                     ps.box(li, x0, x1, y0, y1);
                     if (!(px < x0 || px > x1 || py < y0 || py > y1)) {
                         const int cn = ps.nv(li);
                         const double *cx = ps.x(li), *cy = ps.y(li);
                         // closed test: a point on another entry's boundary proves nothing
-                        in = pip_ring(cx, cy, cn, px, py) || pip_ring(cx, cy, cn, px + VIS_DELTA, py + VIS_DELTA) ||
-                             pip_ring(cx, cy, cn, px - VIS_DELTA, py - VIS_DELTA);
+                        if (pip_ring(cx, cy, cn, px, py) || pip_ring(cx, cy, cn, px + VIS_DELTA, py + VIS_DELTA) ||
+                            pip_ring(cx, cy, cn, px - VIS_DELTA, py - VIS_DELTA))
+                            splits.pstate[sidx] = 0;
                     }
                 }
-                covered = __any(in);
             }
-            visible = !covered;
         }
+        __builtin_amdgcn_wave_barrier();
+        visible = __any(lane < n_samples && splits.pstate[lane] != 0);
         if (visible && lane == 0) VIS_STAT(4, 1);
     }
+    PHASE(0);
     if (visible) return true;
     // ---- shortcut: B inside ONE other entry (all of B's vertices strictly inside it and no edge of it meets B's ring)
-    // is hidden.  Lanes = entries.
+    // is hidden.  Lanes = entries for the box test; then, for each entry whose box holds B's box, lanes = the single
+    // tests: (vertex of B, one of five points around it) inside the entry, and (edge of the entry, edge of B) apart.
     {
         bool hidden = false;
         for (int base = 1; base < n && !hidden; base += 64) {
             const int li = base + lane;
-            bool inside = false;
+            bool holds = false;
             if (li < n) {
                 double x0, x1, y0, y1;
                 ps.box(li, x0, x1, y0, y1);
-                if (x0 < bx0 && x1 > bx1 && y0 < by0 && y1 > by1) {
-                    const int cn = ps.nv(li);
-                    const double *cx = ps.x(li), *cy = ps.y(li);
-                    inside = true;
-                    for (int v = 0; v < nv && inside; ++v) {
-                        // the vertex and four points 2e-9 around it must all be inside: strictly inside with margin
-                        inside = pip_ring(cx, cy, cn, x[v], y[v]) && pip_ring(cx, cy, cn, x[v] + 8 * VIS_DELTA, y[v]) &&
-                                 pip_ring(cx, cy, cn, x[v] - 8 * VIS_DELTA, y[v]) && pip_ring(cx, cy, cn, x[v], y[v] + 8 * VIS_DELTA) &&
-                                 pip_ring(cx, cy, cn, x[v], y[v] - 8 * VIS_DELTA);
-                    }
-                    for (int q = 0; q < cn && inside; ++q) {
-                        const int p = q == 0 ? cn - 1 : q - 1;
-                        for (int v = 0; v < nv && inside; ++v) {
-                            const int u = v == 0 ? nv - 1 : v - 1;
-                            if (segments_meet(cx[p], cy[p], cx[q], cy[q], x[u], y[u], x[v], y[v])) inside = false;
-                        }
-                    }
-                }
+                holds = x0 < bx0 && x1 > bx1 && y0 < by0 && y1 > by1;
             }
-            hidden = __any(inside);
+            unsigned long long todo = __ballot(holds);
+            while (todo != 0 && !hidden) {
+                const int e = base + (__ffsll((long long)todo) - 1);  // wave-uniform
+                todo &= todo - 1;
+                const int cn = ps.nv(e);
+                const double *cx = ps.x(e), *cy = ps.y(e);
+                const int n_pips = nv * 5, n_meets = cn * nv;
+                bool ok = true;
+                for (int w0 = 0; w0 < n_pips + n_meets && ok; w0 += 64) {
+                    const int w = w0 + lane;
+                    bool mine = true;
+                    if (w < n_pips) {
+                        // the vertex and four points 2e-9 around it must all be inside: strictly inside with margin
+                        const int v = w / 5, k = w % 5;
+                        const double ox = k == 1 ? 8 * VIS_DELTA : (k == 2 ? -8 * VIS_DELTA : 0.0);
+                        const double oy = k == 3 ? 8 * VIS_DELTA : (k == 4 ? -8 * VIS_DELTA : 0.0);
+                        mine = pip_ring(cx, cy, cn, x[v] + ox, y[v] + oy);
+                    } else if (w < n_pips + n_meets) {
+                        const int m = w - n_pips;
+                        const int q = m / nv, v = m % nv;
+                        const int p = q == 0 ? cn - 1 : q - 1, u = v == 0 ? nv - 1 : v - 1;
+                        mine = !segments_meet(cx[p], cy[p], cx[q], cy[q], x[u], y[u], x[v], y[v]);
+                    }
+                    ok = __all(mine);
+                }
+                hidden = ok;
+            }
         }
+        PHASE(1);
         if (hidden) return false;
     }
     // ---- B's own edges, witness on B's inner side
@@ -489,6 +603,7 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
         if (edge_has_witness(ps, 0, x[u], y[u], x[v], y[v], sgn_b, false, splits, lds_count) && lane == 0) *flag = 1;
     }
     __syncthreads();
+    PHASE(2);
     if (*(volatile int *)flag) return true;
     // ---- edges of the other entries that enter B (an endpoint inside B or a crossing with B's ring): collected with
     // lanes = entries, then examined one by one, witness on their outer side
@@ -523,6 +638,7 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
+    PHASE(3);
     if (lane == 0 && wave == 0) VIS_STAT(2, n_work);
     for (int w = wave; w < n_work; w += n_waves) {
         if (*(volatile int *)flag) break;
@@ -535,6 +651,7 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
             *flag = 1;
     }
     __syncthreads();
+    PHASE(4);
     return *(volatile int *)flag != 0;
 }
 
@@ -603,16 +720,24 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
                                                     int strict, unsigned long long *work_counter,
                                                     uint8_t *__restrict__ out) {
     __shared__ int lds_counts[4];
-    __shared__ LocalStore store_;
+    __shared__ union {
+        LocalStore staged;   // used once the face's canvas no longer fits the resident store
+        CanvasStore canvas;  // used until then
+    } stores;
+    __shared__ int s_resident, s_ncs;
     __shared__ double lds_splits[4][SPLIT_LDS];
+    __shared__ double lds_px[4][PIECE_LDS], lds_py[4][PIECE_LDS];
+    __shared__ int lds_pstate[4][PIECE_LDS];
     __shared__ int s_face, s_nlist, s_fits, s_flag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    LocalStore *store = &store_;
+    LocalStore *store = &stores.staged;
+    CanvasStore *cs = &stores.canvas;
     int32_t *list = ps.list + (int64_t)blockIdx.x * sc.n;
     int32_t *canvas = ps.canvas + (int64_t)blockIdx.x * sc.n;
     double *cbox = ps.cbox + (int64_t)blockIdx.x * sc.n * 4;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
-    const SplitBuf splits{lds_splits[wave], ps.splits + wave_id * ps.split_cap, ps.split_cap};
+    const SplitBuf splits{lds_splits[wave], ps.splits + wave_id * ps.split_cap, ps.split_cap,
+                          lds_px[wave],     lds_py[wave],                        lds_pstate[wave]};
     int32_t *work = ps.work + wave_id * 2 * (int64_t)sc.vtot;
     int *lds_count = &lds_counts[wave];
     for (;;) {
@@ -636,10 +761,56 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
         const int32_t *ord = order + (size_t)f * m_stride;
         const int m = counts[f];
         int n_canvas = 0;
+        bool resident = true;  // wave 0's view; the others read s_resident after the barrier
+        int n_cs = 0, used = 0;
+#ifdef RT_VIS_STAMPS
+        unsigned long long acc_setup = 0, acc_decide = 0, acc_tail = 0;
+#endif
         for (int k = 0; k < m; ++k) {
+#ifdef RT_VIS_STAMPS
+            const unsigned long long t_a = wall_clock64();
+#endif
             const int B = ord[k];  // uniform over the workgroup
             const PolyMeta mb = meta_f[B];
-            if (wave == 0) {
+            if (wave == 0 && resident) {
+                const int v0 = sc.vert_off[B], nvb = sc.vert_off[B + 1] - v0;
+                if (n_cs >= CS_MAX_POLY - 1 || used + 2 * nvb > CS_MAX_COORD) resident = false;
+            }
+            if (wave == 0 && resident) {
+                // ---- resident canvas: list the slots whose box meets B's box, stage B in the free slot
+                int n_list = 0;
+                for (int base = 0; base < n_cs; base += 64) {
+                    const int ci = base + lane;
+                    bool take = false;
+                    if (ci < n_cs) {
+                        const double *cb = cs->boxes + 4 * ci;
+                        take = !(cb[1] < mb.xmin || cb[0] > mb.xmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                    }
+                    const unsigned long long mk = __ballot(take);
+                    if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = ci;
+                    n_list += __popcll(mk);
+                }
+                const int v0 = sc.vert_off[B], nvb = sc.vert_off[B + 1] - v0;
+                const double *src = sph_f + (size_t)v0 * 2;
+                for (int q = lane; q < 2 * nvb; q += 64) cs->xy[used + q] = src[q];
+                if (lane == 0) {
+                    cs->nvs[n_cs] = nvb;
+                    cs->offs[n_cs] = used;
+                    cs->sgns[n_cs] = mb.sgn;
+                    cs->boxes[4 * n_cs] = mb.xmin;
+                    cs->boxes[4 * n_cs + 1] = mb.xmax;
+                    cs->boxes[4 * n_cs + 2] = mb.ymin;
+                    cs->boxes[4 * n_cs + 3] = mb.ymax;
+                    s_nlist = n_list;
+                    s_fits = 1;
+                    s_flag = 0;
+                    s_resident = 1;
+                    s_ncs = n_cs;
+                    VIS_STAT(0, 1);
+                    VIS_STAT(1, n_list);
+                }
+            } else if (wave == 0) {
+                if (lane == 0) s_resident = 0;
                 // ---- canvas polygons whose box meets B's box
                 int n_list = 0;
                 for (int base = 0; base < n_canvas; base += 64) {
@@ -712,10 +883,17 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
                 }
             }
             __syncthreads();
+#ifdef RT_VIS_STAMPS
+            const unsigned long long t_b = wall_clock64();
+#endif
             const int n_list = s_nlist;
             bool visible = n_list == 0;
+            const bool res_now = s_resident != 0;
             if (!visible) {
-                if (s_fits) {
+                if (res_now) {
+                    CanvasSet cv{cs, s_ncs, n_list + 1};
+                    visible = polygon_uncovered(cv, splits, lds_count, work, &s_flag);
+                } else if (s_fits) {
                     LocalSet ls{store, n_list + 1};
                     visible = polygon_uncovered(ls, splits, lds_count, work, &s_flag);
                 } else {
@@ -723,6 +901,9 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
                     visible = polygon_uncovered(gs, splits, lds_count, work, &s_flag);
                 }
             }
+#ifdef RT_VIS_STAMPS
+            const unsigned long long t_c = wall_clock64();
+#endif
             if (visible) {
                 if (threadIdx.x == 0) {
                     VIS_STAT(5, 1);
@@ -733,9 +914,27 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
                     __threadfence_block();
                 }
                 ++n_canvas;
+                if (wave == 0 && resident) {  // the staged candidate keeps its slot
+                    used += 2 * (sc.vert_off[B + 1] - sc.vert_off[B]);
+                    ++n_cs;
+                }
             }
             __syncthreads();  // canvas / LDS store are rewritten for the next candidate
+#ifdef RT_VIS_STAMPS
+            acc_setup += t_b - t_a;
+            acc_decide += t_c - t_b;
+            acc_tail += wall_clock64() - t_c;
+#endif
         }
+#ifdef RT_VIS_STAMPS
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_vis_stats[0], acc_setup);
+            atomicAdd(&g_vis_stats[1], acc_decide);
+            atomicAdd(&g_vis_stats[2], acc_tail);
+            atomicAdd(&g_vis_stats[3], (unsigned long long)m);
+            atomicAdd(&g_vis_stats[4], (unsigned long long)n_canvas);
+        }
+#endif
     }
 }
 

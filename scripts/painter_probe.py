@@ -21,8 +21,21 @@ for i in [0, 1, 2, 3, n // 3, n // 2, n - 1]:
     t = time.perf_counter()
     v = scene.faces_visibility([(polygons[i].points, polygons[i].get_parametric(), i)], False)
     print(f"row {i}: {1e3*(time.perf_counter()-t):8.2f} ms, sees {int(v.sum())}, vertices {len(polygons[i].points)}", flush=True)
+import ctypes
+def stamps(label):
+    st = (ctypes.c_ulonglong * 8)()
+    _lib.load().rt_debug_visibility_stats(st)
+    c = max(1, st[3])
+    if hasattr(_lib.load(), "rt_debug_visibility_phases"):
+        ph = (ctypes.c_ulonglong * 16)()
+        _lib.load().rt_debug_visibility_phases(ph)
+        names = ["samples", "inside-one", "B edges", "collect", "canvas edges"]
+        print("   phases (us per visit, visits): " + ", ".join(f"{nm} {ph[2*i]/max(1,ph[2*i+1])/100:.1f} x{ph[2*i+1]}" for i, nm in enumerate(names)), flush=True)
+    print(f"   {label}: candidates {st[3]}, visible {st[4]}; per candidate us: setup {st[0]/c/100:.2f} decide {st[1]/c/100:.2f} tail {st[2]/c/100:.2f}", flush=True)
+stamps("single rows")
 for lo_, hi_ in [(0, 1), (1, n), (0, n)]:
     faces = [(polygons[i].points, polygons[i].get_parametric(), i) for i in range(lo_, hi_)]
     t = time.perf_counter()
     v = scene.faces_visibility(faces[:65535], False)
     print(f"rows [{lo_},{min(hi_, lo_ + 65535)}): {1e3*(time.perf_counter()-t):8.2f} ms", flush=True)
+stamps("batches")
