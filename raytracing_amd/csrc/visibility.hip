@@ -277,16 +277,21 @@ struct LocalSet {
 // vertices, so that a candidate only brings its own vertices in from global memory (the listed polygons of every
 // candidate used to be gathered again and again).  The candidate is staged in the next free slot; when it turns out
 // visible the slot is simply kept.  A face whose canvas outgrows the store continues on the staged / global views.
-#define CS_MAX_POLY 320
-#define CS_MAX_COORD 3072 /* doubles: 1536 vertices */
+// Two sizes: a small store when many faces are painted at once (three workgroups per CU), a large one for a handful
+// of faces that see a lot (the emitter's screens), one workgroup per CU.
+template <int CS_MAX_POLY, int CS_MAX_COORD>
 struct CanvasStore {
+    static constexpr int max_poly = CS_MAX_POLY, max_coord = CS_MAX_COORD;  // coordinates in doubles
     int nvs[CS_MAX_POLY], offs[CS_MAX_POLY], sgns[CS_MAX_POLY];
     int list[CS_MAX_POLY];  // slots listed for the current candidate
     double boxes[CS_MAX_POLY * 4];
     double xy[CS_MAX_COORD];
 };
+using SmallCanvasStore = CanvasStore<320, 3072>;
+using LargeCanvasStore = CanvasStore<1024, 8192>;
+template <typename Store>
 struct CanvasSet {
-    const CanvasStore *st;
+    const Store *st;
     int b_slot, n;
     __device__ int slot(int i) const { return i == 0 ? b_slot : st->list[i - 1]; }
     __device__ int count() const { return n; }
@@ -714,6 +719,7 @@ __device__ inline bool faces_viewer(const SceneView &sc, const FaceBatch &fb, in
 
 // One workgroup (4 waves) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
 // polygons whose box meets it and stages them in LDS; all waves then decide coverage together.
+template <typename Store>
 __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, const double *__restrict__ sph,
                                                     const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
                                                     int m_stride, const int32_t *__restrict__ counts, PaintScratch ps,
@@ -722,7 +728,7 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
     __shared__ int lds_counts[4];
     __shared__ union {
         LocalStore staged;   // used once the face's canvas no longer fits the resident store
-        CanvasStore canvas;  // used until then
+        Store canvas;        // used until then
     } stores;
     __shared__ int s_resident, s_ncs;
     __shared__ double lds_splits[4][SPLIT_LDS];
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
     __shared__ int s_face, s_nlist, s_fits, s_flag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LocalStore *store = &stores.staged;
-    CanvasStore *cs = &stores.canvas;
+    Store *cs = &stores.canvas;
     int32_t *list = ps.list + (int64_t)blockIdx.x * sc.n;
     int32_t *canvas = ps.canvas + (int64_t)blockIdx.x * sc.n;
     double *cbox = ps.cbox + (int64_t)blockIdx.x * sc.n * 4;
@@ -774,7 +780,7 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
             const PolyMeta mb = meta_f[B];
             if (wave == 0 && resident) {
                 const int v0 = sc.vert_off[B], nvb = sc.vert_off[B + 1] - v0;
-                if (n_cs >= CS_MAX_POLY - 1 || used + 2 * nvb > CS_MAX_COORD) resident = false;
+                if (n_cs >= Store::max_poly - 1 || used + 2 * nvb > Store::max_coord) resident = false;
             }
             if (wave == 0 && resident) {
                 // ---- resident canvas: list the slots whose box meets B's box, stage B in the free slot
@@ -891,7 +897,7 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
             const bool res_now = s_resident != 0;
             if (!visible) {
                 if (res_now) {
-                    CanvasSet cv{cs, s_ncs, n_list + 1};
+                    CanvasSet<Store> cv{cs, s_ncs, n_list + 1};
                     visible = polygon_uncovered(cv, splits, lds_count, work, &s_flag);
                 } else if (s_fits) {
                     LocalSet ls{store, n_list + 1};
@@ -994,9 +1000,15 @@ static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, c
                            (int32_t *)b_order.p, m_stride, (int32_t *)b_counts.p);
     PaintScratch ps{(int32_t *)b_list.p, (int32_t *)b_canvas.p, (double *)b_cbox.p, (double *)b_splits.p, split_cap,
                     (int32_t *)b_work.p};
-    hipLaunchKernelGGL(k_vis_paint, dim3(n_blocks), dim3(256), 0, st, sc, fb, (const double *)b_sph.p,
-                       (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride, (const int32_t *)b_counts.p, ps,
-                       strict, (unsigned long long *)b_counter.p, d_out);
+    // at most one face per CU: the large canvas store (one workgroup per CU) costs no parallelism
+    if (n_faces <= 256)
+        hipLaunchKernelGGL(k_vis_paint<LargeCanvasStore>, dim3(n_blocks), dim3(256), 0, st, sc, fb,
+                           (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
+                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, d_out);
+    else
+        hipLaunchKernelGGL(k_vis_paint<SmallCanvasStore>, dim3(n_blocks), dim3(256), 0, st, sc, fb,
+                           (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
+                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, d_out);
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(st));
     return 0;
