@@ -233,6 +233,9 @@ struct PaintScratch {
 // LDS (a single wave chasing list -> record -> offsets -> coordinates through global memory is latency-bound; staged,
 // the same loops run out of LDS).
 struct GlobalSet {
+    static constexpr bool flat = false;  // no running vertex count: loops go entry by entry
+    __device__ int total_vertices() const { return 0; }
+    __device__ void locate(int, int &i, int &v) const { i = v = 0; }
     const SceneView *sc;
     const double *sph_f;
     const PolyMeta *meta_f;
@@ -261,6 +264,9 @@ struct LocalStore {
     double xy[LS_MAX_COORD];
 };
 struct LocalSet {
+    static constexpr bool flat = false;
+    __device__ int total_vertices() const { return 0; }
+    __device__ void locate(int, int &i, int &v) const { i = v = 0; }
     LocalStore *st;
     int n;
     __device__ int count() const { return n; }
@@ -284,6 +290,7 @@ struct CanvasStore {
     static constexpr int max_poly = CS_MAX_POLY, max_coord = CS_MAX_COORD;  // coordinates in doubles
     int nvs[CS_MAX_POLY], offs[CS_MAX_POLY], sgns[CS_MAX_POLY];
     int list[CS_MAX_POLY];  // slots listed for the current candidate
+    int lpre[CS_MAX_POLY + 1];  // vertices before entry i of the current set (entry 0 = the candidate, then the listed)
     double boxes[CS_MAX_POLY * 4];
     double xy[CS_MAX_COORD];
 };
@@ -291,6 +298,19 @@ using SmallCanvasStore = CanvasStore<320, 3072>;
 using LargeCanvasStore = CanvasStore<1024, 8192>;
 template <typename Store>
 struct CanvasSet {
+    // the vertices of all entries are numbered through lpre, so that a loop over every ring edge of every entry can
+    // give each lane one edge (a roof has tens of vertices: one lane walking its ring is the slow way)
+    static constexpr bool flat = true;
+    __device__ int total_vertices() const { return st->lpre[n]; }
+    __device__ void locate(int e, int &i, int &v) const {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (st->lpre[mid] <= e) lo = mid; else hi = mid - 1;
+        }
+        i = lo;
+        v = e - st->lpre[lo];
+    }
     const Store *st;
     int b_slot, n;
     __device__ int slot(int i) const { return i == 0 ? b_slot : st->list[i - 1]; }
@@ -389,6 +409,31 @@ __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay,
     }
     __builtin_amdgcn_wave_barrier();
     const int n = ps.count();
+    if (Set::flat) {
+        // lanes = ring edges of all entries
+        const int tv = ps.total_vertices();
+        for (int base = 0; base < tv; base += 64) {
+            const int e = base + lane;
+            if (e >= tv) continue;
+            int li, v;
+            ps.locate(e, li, v);
+            if (li == owner) continue;
+            double x0, x1, y0, y1;
+            ps.box(li, x0, x1, y0, y1);
+            const bool near = !(x1 < fmin(ax, bx) - VIS_ON_LINE || x0 > fmax(ax, bx) + VIS_ON_LINE ||
+                                y1 < fmin(ay, by) - VIS_ON_LINE || y0 > fmax(ay, by) + VIS_ON_LINE);
+            if (!near) continue;
+            const int nv = ps.nv(li);
+            const double *x = ps.x(li), *y = ps.y(li);
+            const int u = v == 0 ? nv - 1 : v - 1;
+            double t[3];
+            const int k = edge_cuts(ax, ay, bx, by, x[u], y[u], x[v], y[v], t);
+            if (k > 0) {
+                const int slot = atomicAdd(lds_count, k);
+                for (int q = 0; q < k; ++q) splits.put(slot + q, t[q]);
+            }
+        }
+    } else
     for (int base = 0; base < n; base += 64) {
         const int li = base + lane;
         if (li < n && li != owner) {
@@ -613,6 +658,35 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
     // ---- edges of the other entries that enter B (an endpoint inside B or a crossing with B's ring): collected with
     // lanes = entries, then examined one by one, witness on their outer side
     int n_work = 0;
+    if (Set::flat) {
+        const int tv = ps.total_vertices();
+        for (int base = nv; base < tv; base += 64) {  // entry 0 (B itself) owns the first nv
+            const int e = base + lane;
+            bool rel = false;
+            int li = 0, v = 0;
+            if (e < tv) {
+                ps.locate(e, li, v);
+                const int cn = ps.nv(li);
+                const double *cx = ps.x(li), *cy = ps.y(li);
+                const int u = v == 0 ? cn - 1 : v - 1;
+                const double ax = cx[u], ay = cy[u], ex = cx[v], ey = cy[v];
+                if (!(fmax(ax, ex) < bx0 || fmin(ax, ex) > bx1 || fmax(ay, ey) < by0 || fmin(ay, ey) > by1)) {
+                    rel = pip_ring(x, y, nv, ax, ay) || pip_ring(x, y, nv, ex, ey);
+                    for (int q = 0; q < nv && !rel; ++q) {
+                        const int p = q == 0 ? nv - 1 : q - 1;
+                        rel = segments_meet(ax, ay, ex, ey, x[p], y[p], x[q], y[q]);
+                    }
+                }
+            }
+            const unsigned long long mk = __ballot(rel);
+            if (rel) {
+                const int slot = n_work + __popcll(mk & ((1ull << lane) - 1));
+                work[2 * slot] = li;
+                work[2 * slot + 1] = v;
+            }
+            n_work += __popcll(mk);
+        }
+    } else
     for (int base = 1; base < n; base += 64) {
         const int li = base + lane;
         const int cn = li < n ? ps.nv(li) : 0;
@@ -799,6 +873,26 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
                 const int v0 = sc.vert_off[B], nvb = sc.vert_off[B + 1] - v0;
                 const double *src = sph_f + (size_t)v0 * 2;
                 for (int q = lane; q < 2 * nvb; q += 64) cs->xy[used + q] = src[q];
+                // running vertex count over the set: the candidate first, then the listed slots
+                {
+                    int total = nvb;
+                    __builtin_amdgcn_wave_barrier();
+                    for (int base = 0; base < n_list; base += 64) {
+                        const int li = base + lane;
+                        const int cnt = li < n_list ? cs->nvs[cs->list[li]] : 0;
+                        int incl = cnt;
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int t = __shfl_up(incl, off);
+                            if (lane >= off) incl += t;
+                        }
+                        if (li < n_list) cs->lpre[li + 1] = total + incl - cnt;
+                        total += __shfl(incl, 63);
+                    }
+                    if (lane == 0) {
+                        cs->lpre[0] = 0;
+                        cs->lpre[n_list + 1] = total;
+                    }
+                }
                 if (lane == 0) {
                     cs->nvs[n_cs] = nvb;
                     cs->offs[n_cs] = used;

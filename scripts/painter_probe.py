@@ -39,3 +39,12 @@ for lo_, hi_ in [(0, 1), (1, n), (0, n)]:
     v = scene.faces_visibility(faces[:65535], False)
     print(f"rows [{lo_},{min(hi_, lo_ + 65535)}): {1e3*(time.perf_counter()-t):8.2f} ms", flush=True)
 stamps("batches")
+from raytracing_amd import scenarios  # noqa: E402
+lo, hi = place.get_domain()
+tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
+cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+for k, sface in enumerate(cube.polygons):
+    t = time.perf_counter()
+    v = scene.faces_visibility([(sface.points, sface.get_parametric(), -1)], False)
+    print(f"screen {k}: {1e3*(time.perf_counter()-t):8.2f} ms, sees {int(v.sum())}", flush=True)
+    stamps(f"screen {k}")
