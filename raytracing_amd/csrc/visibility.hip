@@ -9,7 +9,7 @@
 //
 // The canvas a polygon is tested against holds the polygons that passed before it; a polygon hidden by the canvas
 // lies inside it, so leaving it out changes nothing and keeps the canvas small.  Faces are independent: one workgroup
-// (four waves) paints one face, walking its candidates in sorted order.
+// (four or sixteen waves) paints one face, walking its candidates in sorted order.
 //
 // Coverage is decided exactly with witness points.  If part of B is uncovered, the uncovered region is bounded by
 // pieces of B's edges (region on B's inner side) and pieces of the C's edges (region on that C's outer side).  Every
@@ -19,9 +19,9 @@
 //
 // Kernels: k_vis_prepare (one thread per (face, polygon): mapping, keys, ring validity), k_vis_sort (one workgroup per
 // face: bitonic sort of its candidates by the painter's key) and k_vis_paint (persistent workgroups pulling faces from
-// a counter; inside a face the candidate and the canvas polygons whose boxes meet its box are staged in LDS, the
-// candidate's edges and the canvas edges are dealt to the four waves, and inside a wave the lanes work on different
-// canvas polygons / edge pieces while the polygon being tested against is wave-uniform).
+// a counter; the face's canvas lives in LDS, a candidate is staged next to it, the candidate's edges and the canvas
+// edges that enter it are dealt to the waves, and inside a wave the lanes take single tests: one ring edge against the
+// edge being cut, one witness point against one polygon).
 #include <algorithm>
 #include <cstring>
 
@@ -295,7 +295,7 @@ struct CanvasStore {
     double xy[CS_MAX_COORD];
 };
 using SmallCanvasStore = CanvasStore<320, 3072>;
-using LargeCanvasStore = CanvasStore<1024, 8192>;
+using LargeCanvasStore = CanvasStore<768, 6144>;
 template <typename Store>
 struct CanvasSet {
     // the vertices of all entries are numbered through lpre, so that a loop over every ring edge of every entry can
@@ -791,23 +791,23 @@ __device__ inline bool faces_viewer(const SceneView &sc, const FaceBatch &fb, in
     return false;
 }
 
-// One workgroup (4 waves) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
+// One workgroup (NW waves: four when many faces are painted at once, sixteen for a handful) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
 // polygons whose box meets it and stages them in LDS; all waves then decide coverage together.
-template <typename Store>
-__global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, const double *__restrict__ sph,
+template <typename Store, int NW>
+__global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch fb, const double *__restrict__ sph,
                                                     const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
                                                     int m_stride, const int32_t *__restrict__ counts, PaintScratch ps,
                                                     int strict, unsigned long long *work_counter,
                                                     uint8_t *__restrict__ out) {
-    __shared__ int lds_counts[4];
+    __shared__ int lds_counts[NW];
     __shared__ union {
         LocalStore staged;   // used once the face's canvas no longer fits the resident store
         Store canvas;        // used until then
     } stores;
     __shared__ int s_resident, s_ncs;
-    __shared__ double lds_splits[4][SPLIT_LDS];
-    __shared__ double lds_px[4][PIECE_LDS], lds_py[4][PIECE_LDS];
-    __shared__ int lds_pstate[4][PIECE_LDS];
+    __shared__ double lds_splits[NW][SPLIT_LDS];
+    __shared__ double lds_px[NW][PIECE_LDS], lds_py[NW][PIECE_LDS];
+    __shared__ int lds_pstate[NW][PIECE_LDS];
     __shared__ int s_face, s_nlist, s_fits, s_flag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LocalStore *store = &stores.staged;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void k_vis_paint(SceneView sc, FaceBatch fb, c
     int32_t *list = ps.list + (int64_t)blockIdx.x * sc.n;
     int32_t *canvas = ps.canvas + (int64_t)blockIdx.x * sc.n;
     double *cbox = ps.cbox + (int64_t)blockIdx.x * sc.n * 4;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wave_id = (int64_t)blockIdx.x * NW + wave;
     const SplitBuf splits{lds_splits[wave], ps.splits + wave_id * ps.split_cap, ps.split_cap,
                           lds_px[wave],     lds_py[wave],                        lds_pstate[wave]};
     int32_t *work = ps.work + wave_id * 2 * (int64_t)sc.vtot;
@@ -1070,7 +1070,9 @@ static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, c
     const int64_t split_cap = 3 * (int64_t)sc.vtot + 8;
     int m_stride = 1;
     while (m_stride < sc.n) m_stride <<= 1;
-    const size_t n_waves = (size_t)n_blocks * 4;
+    // few faces: sixteen waves per face (the canvas edges of a candidate are dealt to them), otherwise four
+    const int waves_per_face = n_faces <= 256 ? 16 : 4;
+    const size_t n_waves = (size_t)n_blocks * waves_per_face;
     if (b_off.alloc(sizeof(int32_t) * a_off.size()) || b_verts.alloc(sizeof(double) * a_verts.size()) ||
         b_normal.alloc(sizeof(double) * a_normal.size()) || b_self.alloc(sizeof(int32_t) * a_self.size()) ||
         b_sph.alloc(sizeof(double) * 2 * (size_t)sc.vtot * n_faces) || b_meta.alloc(sizeof(PolyMeta) * (size_t)sc.n * n_faces) ||
@@ -1096,11 +1098,11 @@ static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, c
                     (int32_t *)b_work.p};
     // at most one face per CU: the large canvas store (one workgroup per CU) costs no parallelism
     if (n_faces <= 256)
-        hipLaunchKernelGGL(k_vis_paint<LargeCanvasStore>, dim3(n_blocks), dim3(256), 0, st, sc, fb,
+        hipLaunchKernelGGL((k_vis_paint<LargeCanvasStore, 16>), dim3(n_blocks), dim3(1024), 0, st, sc, fb,
                            (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
                            (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, d_out);
     else
-        hipLaunchKernelGGL(k_vis_paint<SmallCanvasStore>, dim3(n_blocks), dim3(256), 0, st, sc, fb,
+        hipLaunchKernelGGL((k_vis_paint<SmallCanvasStore, 4>), dim3(n_blocks), dim3(256), 0, st, sc, fb,
                            (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
                            (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, d_out);
     RT_HIP(hipGetLastError());
