@@ -95,3 +95,54 @@ def lln_grid(n_side=100):
     lo, hi = place.get_domain()
     tx = emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
     return place, tx, lattice_receivers(place, n_side, 1.5)
+
+
+def ny_tiled(tiles=8, gap=10.0, n_rx=256, seed=0):
+    """Config 4: data/ny.geojson repeated ``tiles`` x ``tiles`` times with a ``gap`` m street between the copies
+    (92 polygons -> 5 825 for 8 x 8), TX above the centre at 20 m, ``n_rx`` receivers on a lattice at 1.5 m."""
+    footprints = geom.preprocess_geojson(os.path.join(DATA_DIR, "ny.geojson"), seed=seed)
+    all_xy = np.concatenate([f["ring"] for f in footprints])
+    lo, hi = all_xy.min(axis=0), all_xy.max(axis=0)
+    pitch = (hi - lo) + gap
+    tiled = []
+    for ty in range(tiles):
+        for tx_ in range(tiles):
+            for f in footprints:
+                g = dict(f)
+                g["ring"] = f["ring"] + np.array([tx_ * pitch[0], ty * pitch[1]])
+                g["id"] = f"{f['id']}-{ty}-{tx_}"
+                tiled.append(g)
+    place = geom.generate_place_from_rooftops_file(tiled)
+    lo3, hi3 = place.get_domain()
+    tx = emitter_outside(place, (lo3[0] + hi3[0]) / 2, (lo3[1] + hi3[1]) / 2, 20.0)
+    n_side = int(np.ceil(np.sqrt(n_rx)))
+    return place, tx, lattice_receivers(place, n_side, 1.5, count=n_rx)
+
+
+# emitter positions of the reference's measurement campaign on place_saint_jean (scenario_measures.py:157-167), lifted
+# to 3 m above the ground
+SAINT_JEAN_EMITTERS = np.array([[35.0, -6.0, 3.0], [69.0, -54.0, 3.0], [53.0, -93.0, 3.0], [70.0, 41.5, 3.0],
+                                [-96.0, 92.0, 3.0]])
+SWEEP_FREQUENCIES_HZ = np.array([3.5e9, 6e9, 12.5e9, 28e9, 30e9, 39e9, 60e9])
+
+
+def saint_jean_sweep(n_rx=5000, seed=0, min_spacing=1.0):
+    """Config 5: data/place_saint_jean, the five emitters above (moved out of any footprint), ``n_rx`` receivers drawn
+    uniformly in the ground box outside the footprints (seeded rejection sampling, at least ``min_spacing`` apart on a
+    grid of that pitch, z = 1.2 m), and the sweep frequencies."""
+    place = geom.load_place(os.path.join(DATA_DIR, "place_saint_jean", "place_saint_jean.geojson"))
+    lo, hi = place.get_domain()
+    fps = _footprints(place)
+    boxes = [(f.min(axis=0), f.max(axis=0)) for f in fps]
+    rng = np.random.default_rng(seed)
+    taken = set()
+    out = []
+    while len(out) < n_rx:
+        x, y = rng.uniform(lo[0], hi[0]), rng.uniform(lo[1], hi[1])
+        cell = (int(np.floor(x / min_spacing)), int(np.floor(y / min_spacing)))
+        if cell in taken or _inside_any(fps, boxes, x, y):
+            continue
+        taken.add(cell)
+        out.append((x, y, 1.2))
+    emitters = np.array([emitter_outside(place, *e) for e in SAINT_JEAN_EMITTERS])
+    return place, emitters, np.array(out), SWEEP_FREQUENCIES_HZ.copy()
