@@ -1172,6 +1172,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     for (const CandGroup &g : cand->groups) cand_blocks += blocks_for(g.count, 256);
     int rx_tile = (int)std::min<int64_t>(32, std::max<int64_t>(4, chunk * std::max<int64_t>(cand_blocks, 1) / 512));
     rx_tile &= ~3;
+    chunk = std::min<int64_t>(chunk, 65535ll * rx_tile);  // grid.y of the candidate kernels
     unsigned long long found_before = 0;
 
     for (int64_t r0 = 0; r0 < n_rx;) {

@@ -246,3 +246,34 @@ def test_saint_jean_order1_with_diffraction_matches_exact_oracle(places):
     assert not only_gpu and not only_ref, f"only GPU: {sorted(only_gpu)[:5]}, only oracle: {sorted(only_ref)[:5]}"
     assert worst <= 1e-6
     assert len(problem.path_set()) >= 8
+
+
+def test_many_receivers_in_one_call(places):
+    """300 000 receivers in one call (more than one launch can tile): the library cuts the batch into chunks; every
+    receiver's paths are those of the same receiver solved in a small batch."""
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+
+    place = places("small")
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    tx, _ = small_tx_rx(1)
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    cand = scene.enumerate(vis, ev, pairs, edges, 1, with_diffraction=True)
+    rng = np.random.default_rng(9)
+    lo, hi = place.get_domain()
+    n = 300_000
+    rx = np.column_stack([rng.uniform(lo[0], hi[0], n), rng.uniform(lo[1], hi[1], n), np.full(n, 1.5)])
+    res = scene.solve_paths(cand, tx, rx)
+    assert res["n_attempted"] == n * (1 + cand.total)
+    picks = np.concatenate([np.arange(0, 50), np.arange(262_100, 262_200), np.arange(n - 50, n)])
+    sub = scene.solve_paths(cand, tx, rx[picks])
+    want = {(int(picks[r]), int(g), int(c)) for r, g, c in zip(sub["rx"], sub["group"], sub["cand"])}
+    chosen = np.isin(res["rx"], picks)
+    got = {(int(r), int(g), int(c)) for r, g, c in zip(res["rx"][chosen], res["group"][chosen], res["cand"][chosen])}
+    assert got == want and len(want) > 100
+    cand.close()
+    scene.close()
