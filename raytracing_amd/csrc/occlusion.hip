@@ -23,10 +23,12 @@ struct ObstructItems {
     const PathRec *paths;
     int round;
     int64_t n_masked;
+    const int32_t *index;  // when given, work item k is item index[k] (second pass over the stragglers of a first)
 };
 
-__device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t i, const uint8_t *__restrict__ out,
+__device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t &i, const uint8_t *__restrict__ out,
                                              int64_t &seg, bool &masked) {
+    if (it.index) i = it.index[i];
     seg = i;
     masked = i < it.n_masked;
     if (!it.paths) return true;
@@ -39,7 +41,7 @@ __device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t i,
 
 // Runs the exact test for up to 64 parked (item lane, polygon) pairs of a wave, one pair per lane.
 __device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double *__restrict__ segs,
-                                               const int64_t *wave_seg, int64_t s_base, int p_begin,
+                                               const int64_t *wave_seg, const int64_t *wave_item, int p_begin,
                                                const uint32_t *entries, int n_entries, int lane,
                                                volatile uint8_t *wave_hit, uint8_t *__restrict__ out) {
     if (lane < n_entries) {
@@ -49,7 +51,7 @@ __device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double
             const int64_t s = wave_seg[L];
             if (polygon_cuts_segment(sc, p_begin + (int)(e >> 6), ld3(segs + 6 * s), ld3(segs + 6 * s + 3))) {
                 wave_hit[L] = 1;
-                out[s_base + L] = 1;  // out starts at zero; several polygon chunks may set the same byte
+                out[wave_item[L]] = 1;  // out starts at zero; several polygon chunks may set the same byte
             }
         }
     }
@@ -60,11 +62,13 @@ __device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double
 // polygon range through LDS, OBS_STAGE at a time, so the inner loop reads them at LDS latency.
 #define OBS_STAGE 128
 #define RT_GRID_MIN_POLYGONS 512
+#define OBS_PASSES 2
+#define OBS_FIRST_PASS_TRIPS 24
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems items, int64_t n_cap,
                                                    const unsigned long long *__restrict__ n_dev,
                                                    const uint8_t *__restrict__ mask, int poly_chunk, uint8_t *out) {
-    __shared__ int64_t wave_segs[4][64];
+    __shared__ int64_t wave_segs[4][64], wave_items[4][64];
     const double *__restrict__ segs = items.segs;
     __shared__ OccRec s_rec[OBS_STAGE];
     __shared__ uint8_t s_mask[OBS_STAGE];
@@ -84,9 +88,10 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
     for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
-        int64_t seg = 0;
+        int64_t seg = 0, item = s;
         bool use_mask = false;
-        const bool active = s < n_seg && item_segment(items, s, out, seg, use_mask);
+        const bool active = s < n_seg && item_segment(items, item, out, seg, use_mask);
+        wave_items[wave][lane] = item;
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
         if (active) {
             A = ld3(segs + 6 * seg);
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                     __builtin_amdgcn_wave_barrier();
                     if (qn >= 64) {
                         qn -= 64;
-                        obstruct_drain(sc, segs, wave_segs[wave], s_base, p_begin, wq + qn, 64, lane, wave_hit, out);
+                        obstruct_drain(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq + qn, 64, lane, wave_hit, out);
                         __builtin_amdgcn_wave_barrier();
                         hit = wave_hit[lane] != 0;
                         if (__all(hit || !active)) {
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                 }
             }
         }
-        if (qn > 0) obstruct_drain(sc, segs, wave_segs[wave], s_base, p_begin, wq, qn, lane, wave_hit, out);
+        if (qn > 0) obstruct_drain(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
         __syncthreads();  // the staging buffer is free again
     }
 }
@@ -166,8 +171,9 @@ __device__ inline unsigned long long wave_sum(unsigned long long v) {
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructItems items, int64_t n_cap,
                                                         const unsigned long long *__restrict__ n_dev,
-                                                        const uint8_t *__restrict__ mask, uint8_t *out) {
-    __shared__ int64_t wave_segs[4][64];
+                                                        const uint8_t *__restrict__ mask, uint8_t *out, int max_trips,
+                                                        unsigned long long *late_count, int32_t *late_items) {
+    __shared__ int64_t wave_segs[4][64], wave_items[4][64];
     const double *__restrict__ segs = items.segs;
     __shared__ uint32_t wave_queue[4][128];
     __shared__ uint8_t wave_hits[4][64];
@@ -184,9 +190,10 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
     for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
-        int64_t seg = 0;
+        int64_t seg = 0, item = s;
         bool use_mask = false;
-        const bool active = s < n_seg && item_segment(items, s, out, seg, use_mask);
+        const bool active = s < n_seg && item_segment(items, item, out, seg, use_mask);
+        wave_items[wave][lane] = item;
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
         if (active) {
             A = ld3(segs + 6 * seg);
@@ -257,7 +264,9 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
         int qn = 0;  // wave-uniform
         wave_hit[lane] = 0;
         __builtin_amdgcn_wave_barrier();
-        while (__any(!finished)) {
+        int trips = 0;  // wave-uniform
+        while (__any(!finished) && trips < max_trips) {
+            ++trips;
             bool cand = false;
             int poly = 0;
             if (!finished) {
@@ -283,14 +292,28 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
                 __builtin_amdgcn_wave_barrier();
                 if (qn >= 64) {
                     qn -= 64;
-                    obstruct_drain(sc, segs, wave_segs[wave], s_base, 0, wq + qn, 64, lane, wave_hit, out);
+                    obstruct_drain(sc, segs, wave_segs[wave], wave_items[wave], 0, wq + qn, 64, lane, wave_hit, out);
                     __builtin_amdgcn_wave_barrier();
                     if (wave_hit[lane]) finished = true;
                 }
             }
         }
-        if (qn > 0) obstruct_drain(sc, segs, wave_segs[wave], s_base, 0, wq, qn, lane, wave_hit, out);
+        if (qn > 0) obstruct_drain(sc, segs, wave_segs[wave], wave_items[wave], 0, wq, qn, lane, wave_hit, out);
         __builtin_amdgcn_wave_barrier();
+        if (late_items) {
+            // a lane whose walk is not over when the wave's trips are used up hands its item to the second pass, where
+            // the stragglers of many waves walk side by side instead of each holding 63 idle lanes
+            const bool late = !finished && !wave_hit[lane];
+            const unsigned long long lm = __ballot(late);
+            if (lm != 0) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(late_count, (unsigned long long)__popcll(lm));
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+                base = ((unsigned long long)hi << 32) | lo;
+                if (late) late_items[base + __popcll(lm & ((1ull << lane) - 1))] = (int32_t)item;
+            }
+        }
 #ifdef RT_OCC_STATS
         {
             const unsigned long long a = wave_sum(active ? 1 : 0), c = wave_sum(st_cells), r = wave_sum(st_recs),
@@ -323,6 +346,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
                        uint8_t *d_out, const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths,
                        int round) {
     if (n_item == 0) return 0;
+    hipStream_t stream = scene->stream;
     const int block = 256;
     const int64_t n_grid = d_count ? (n_hint < 1 ? 1 : (n_hint > n_item ? n_item : n_hint)) : n_item;
     int64_t grid = (n_grid + block - 1) / block;
@@ -342,17 +366,60 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
         else
             RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_item, scene->stream));
     }
-    const ObstructItems items{d_segs, d_paths, round, d_mask ? n_masked : 0};
+    const ObstructItems items{d_segs, d_paths, round, d_mask ? n_masked : 0, nullptr};
     // small launches on small scenes are latency-bound: there the every-polygon walk, split over grid.y, is quicker
     const bool walk_grid = scene->occlusion_mode == 2 ||
                            (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
     if (walk_grid) {
-        if (d_mask)
-            hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view,
-                               items, n_item, d_count, d_mask, d_out);
-        else
-            hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, scene->stream, scene->view,
-                               items, n_item, d_count, d_mask, d_out);
+        // Large launches go in passes: every wave of the first stops after OBS_FIRST_PASS_TRIPS records per lane and
+        // hands the items still walking to a second launch over just those, which walks them to the end (a wave lasts
+        // as long as its longest walk, and most walks are short). Measured on 25 M segments of lln: one pass 17.2 ms,
+        // two passes 12.6 ms with 24 trips (worse with 8, 12, 16 or 40), three passes (24, 96, rest) 12.9 ms: a handed
+        // over item starts its walk again.
+        const bool passes = n_grid >= (1 << 20) && n_item <= 0x7fffffffLL;
+        if (!passes) {
+            if (d_mask)
+                hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, stream, scene->view, items,
+                                   n_item, d_count, d_mask, d_out, 0x7fffffff, (unsigned long long *)nullptr,
+                                   (int32_t *)nullptr);
+            else
+                hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, stream, scene->view, items,
+                                   n_item, d_count, d_mask, d_out, 0x7fffffff, (unsigned long long *)nullptr,
+                                   (int32_t *)nullptr);
+        } else {
+            // two hand-over lists (a pass reads one and fills the other) and their counters
+            if (scene->late_cap < 2 * (size_t)n_item) {
+                RT_HIP(hipStreamSynchronize(stream));
+                if (scene->late_items) (void)hipFree(scene->late_items);
+                scene->late_items = nullptr;
+                scene->late_cap = 0;
+                RT_HIP(hipMalloc((void **)&scene->late_items, sizeof(int32_t) * 2 * (size_t)n_item));
+                scene->late_cap = 2 * (size_t)n_item;
+            }
+            unsigned long long *counts = scene->d_counters + 6;  // [6], [7]
+            RT_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), stream));
+            const int trip_limits[OBS_PASSES] = {OBS_FIRST_PASS_TRIPS, 0x7fffffff};
+            for (int pass = 0; pass < OBS_PASSES; ++pass) {
+                ObstructItems it = items;
+                const unsigned long long *n_in = d_count;
+                unsigned g = (unsigned)grid;
+                if (pass > 0) {
+                    it.index = scene->late_items + (size_t)((pass - 1) & 1) * n_item;
+                    n_in = counts + ((pass - 1) & 1);
+                    g = (unsigned)std::max<int64_t>(1024, grid >> (2 * pass));
+                }
+                const bool last = pass == OBS_PASSES - 1;
+                int32_t *late_out = last ? nullptr : scene->late_items + (size_t)(pass & 1) * n_item;
+                unsigned long long *count_out = last ? nullptr : counts + (pass & 1);
+                if (pass >= 2 && !last) RT_HIP(hipMemsetAsync(count_out, 0, sizeof(unsigned long long), stream));
+                if (d_mask)
+                    hipLaunchKernelGGL(k_obstruct_grid<true>, dim3(g), dim3(block), 0, stream, scene->view, it, n_item, n_in,
+                                       d_mask, d_out, trip_limits[pass], count_out, late_out);
+                else
+                    hipLaunchKernelGGL(k_obstruct_grid<false>, dim3(g), dim3(block), 0, stream, scene->view, it, n_item, n_in,
+                                       d_mask, d_out, trip_limits[pass], count_out, late_out);
+            }
+        }
     } else if (d_mask)
         hipLaunchKernelGGL(k_obstruct<true>, dim3((unsigned)grid, (unsigned)ny), dim3(block), 0, scene->stream,
                            scene->view, items, n_item, d_count, d_mask, poly_chunk, d_out);

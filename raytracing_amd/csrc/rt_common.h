@@ -106,6 +106,8 @@ struct rt_scene {
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     int64_t hint_paths = 0, hint_segments = 0;
+    int32_t *late_items = nullptr;  // items handed from the first to the second obstruction pass (grows on demand)
+    size_t late_cap = 0;
     int64_t queue_capacity_override = 0;  // > 0: first size of the path queue (tests of the grow-and-redo route)
     int occlusion_mode = 0;  // 0 = by scene size, 1 = every-polygon walk, 2 = grid walk
     // timing of the last solve

@@ -292,6 +292,7 @@ extern "C" void rt_scene_destroy(rt_scene *s) {
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->ws) (void)hipFree(s->ws);
+    if (s->late_items) (void)hipFree(s->late_items);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
     delete s;
 }
