@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the coverage-map-sized extra measurement")
     ap.add_argument("--n-side", type=int, default=32)
+    ap.add_argument("--events-in-timed-region", action="store_true",
+                    help="keep the per-launch timing events on during the timed steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 (rehearsal on a one-GPU box)")
     args = ap.parse_args()
@@ -221,22 +223,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timed region runs without the per-launch events (a pair of event records per launch costs a step of this
+    # size a measurable part of its time); the kernel times of the roofline come from the same number of steps run
+    # again right after it with the events on.
+    scene.set_timing(args.events_in_timed_region)
     for _ in range(args.warmup):
         found, attempted = step()
-    fam_ms = {"reflect": 0.0, "diffract": 0.0, "obstruct": 0.0, "finalize": 0.0}
-    fam_launches = dict.fromkeys(fam_ms, 0)
-    segments = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         found, attempted = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    fam_ms = {"reflect": 0.0, "diffract": 0.0, "obstruct": 0.0, "finalize": 0.0}
+    fam_launches = dict.fromkeys(fam_ms, 0)
+    segments = 0
+    scene.set_timing(True)
+    step()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
         tm = scene.last_timing()
         for k in fam_ms:
             fam_ms[k] += tm["ms"][k]
             fam_launches[k] += tm["launches"][k]
         segments += tm["segments"]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    elapsed_with_events = time.perf_counter() - t1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,7 +300,7 @@ def main():
         roof["traffic"] = detail["bytes_per_launch"] if detail else None
         roof["traffic_detail"] = detail
         roof["achieved_per_launch_basis"] = "algorithmic bytes (or flop) per step / launches per step / mean launch time"
-        roof["note"] = ("launch- and latency-bound at this size (a step is six dependent launches of 2-40 us over 3 M "
+        roof["note"] = ("launch- and latency-bound at this size (a step is four dependent launches of 2-40 us over 3 M "
                         "pairs); see large_workload for the same kernels on a coverage-map-sized batch")
         out = {
             "metric": "path-solves/sec (RX x candidate paths, whole node)",
@@ -310,6 +323,9 @@ def main():
             "roofline": roof,
             "roofline_by_kernel": by_kernel,
             "kernel_ms_per_step": ms,
+            "kernel_ms_source": "HIP events around every launch, over the same number of steps run again after the "
+                                "timed region (which runs without them)",
+            "ms_per_step_with_events": 1e3 * elapsed_with_events / steps,
             "segments_per_step": seg_per_step,
             "pairs_per_step": pairs,
         }

@@ -75,6 +75,10 @@ int rt_debug_set_occlusion_mode(rt_scene *scene, int mode);
 /* First size of the solve's path queue in records (0 = chosen from the batch).  A queue that turns out too small is
  * grown and the chunk redone; the switch exists so that tests can take that route (no reference counterpart). */
 int rt_debug_set_path_queue_capacity(rt_scene *scene, int64_t n_paths);
+/* Per-kernel-family timing of rt_solve_paths (rt_solve_last_timing) on (default) or off.  The timing is a pair of
+ * events around every launch; a small solve is bound by the latency of its few dependent launches and runs a little
+ * faster without them.  rt_solve_last_timing reports zeros while it is off (no reference counterpart). */
+int rt_scene_set_timing(rt_scene *scene, int on);
 /* Work counters of the visibility painter accumulated since the last call, then zeroed (profiling aid, no reference
  * counterpart): candidates, listed canvas polygons, canvas edges entering a candidate, edge cuts, candidates settled by
  * the interior-sample shortcut, polygons shown visible, canvas-edge examinations, edge examinations. out8[8]. */

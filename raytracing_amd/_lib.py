@@ -42,6 +42,7 @@ _SIGNATURES = {
     "rt_faces_visibility": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_debug_visibility_stats": (c_int, [c_void_p]),
     "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
+    "rt_scene_set_timing": (c_int, [c_void_p, c_int]),
     "rt_debug_set_path_queue_capacity": (c_int, [c_void_p, c_int64]),
     "rt_visibility_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "rt_sharp_edges": (c_int, [c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -237,6 +238,10 @@ class Scene:
     def set_occlusion_mode(self, mode):
         """0: obstruction kernel chosen by scene size (default); 1: every-polygon walk; 2: grid walk."""
         _check(load().rt_debug_set_occlusion_mode(self.handle, int(mode)), "rt_debug_set_occlusion_mode")
+
+    def set_timing(self, on):
+        """Per-kernel-family timing of the solves on (default) or off; ``last_timing`` reports zeros while off."""
+        _check(load().rt_scene_set_timing(self.handle, int(bool(on))), "rt_scene_set_timing")
 
     def set_path_queue_capacity(self, n_paths):
         """First size of the solve's path queue (0 = automatic); too small a queue is grown and the chunk redone."""

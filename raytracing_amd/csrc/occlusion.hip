@@ -39,7 +39,9 @@ __device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t &i
     return true;
 }
 
-// Runs the exact test for up to 64 parked (item lane, polygon) pairs of a wave, one pair per lane.
+// Runs the exact test for up to 64 parked (item lane, polygon) pairs of a wave, one pair per lane.  BATCHED picks the
+// arrangement of the exact test for latency-bound launches.
+template <bool BATCHED>
 __device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double *__restrict__ segs,
                                                const int64_t *wave_seg, const int64_t *wave_item, int p_begin,
                                                const uint32_t *entries, int n_entries, int lane,
@@ -49,7 +51,9 @@ __device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double
         const int L = (int)(e & 63u);
         if (!wave_hit[L]) {
             const int64_t s = wave_seg[L];
-            if (polygon_cuts_segment(sc, p_begin + (int)(e >> 6), ld3(segs + 6 * s), ld3(segs + 6 * s + 3))) {
+            const int p = p_begin + (int)(e >> 6);
+            const d3 A = ld3(segs + 6 * s), B = ld3(segs + 6 * s + 3);
+            if (BATCHED ? polygon_cuts_segment_batched(sc, p, A, B) : polygon_cuts_segment(sc, p, A, B)) {
                 wave_hit[L] = 1;
                 out[wave_item[L]] = 1;  // out starts at zero; several polygon chunks may set the same byte
             }
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                     __builtin_amdgcn_wave_barrier();
                     if (qn >= 64) {
                         qn -= 64;
-                        obstruct_drain(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq + qn, 64, lane, wave_hit, out);
+                        obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq + qn, 64, lane, wave_hit, out);
                         __builtin_amdgcn_wave_barrier();
                         hit = wave_hit[lane] != 0;
                         if (__all(hit || !active)) {
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                 }
             }
         }
-        if (qn > 0) obstruct_drain(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
+        if (qn > 0) obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
         __syncthreads();  // the staging buffer is free again
     }
 }
@@ -292,13 +296,13 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
                 __builtin_amdgcn_wave_barrier();
                 if (qn >= 64) {
                     qn -= 64;
-                    obstruct_drain(sc, segs, wave_segs[wave], wave_items[wave], 0, wq + qn, 64, lane, wave_hit, out);
+                    obstruct_drain<false>(sc, segs, wave_segs[wave], wave_items[wave], 0, wq + qn, 64, lane, wave_hit, out);
                     __builtin_amdgcn_wave_barrier();
                     if (wave_hit[lane]) finished = true;
                 }
             }
         }
-        if (qn > 0) obstruct_drain(sc, segs, wave_segs[wave], wave_items[wave], 0, wq, qn, lane, wave_hit, out);
+        if (qn > 0) obstruct_drain<false>(sc, segs, wave_segs[wave], wave_items[wave], 0, wq, qn, lane, wave_hit, out);
         __builtin_amdgcn_wave_barrier();
         if (late_items) {
             // a lane whose walk is not over when the wave's trips are used up hands its item to the second pass, where
@@ -339,12 +343,13 @@ __global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const uns
 }
 
 // Obstruction flags of n_item items: segments of the queue, or with d_paths one segment per path (see ObstructItems;
-// then the flags are not cleared here: they accumulate over the rounds).  d_mask, when given, restricts the polygons
+// the flags then accumulate over the rounds).  The flags are cleared first when clear_flags is set; otherwise whoever
+// queued the items has cleared them.  d_mask, when given, restricts the polygons
 // for the first n_masked segments / the line-of-sight paths.  With d_count the device holds the item
 // count (<= n_item) and the grid is sized for n_hint of them.
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, const uint8_t *d_mask, int64_t n_masked,
                        uint8_t *d_out, const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths,
-                       int round) {
+                       int round, bool clear_flags) {
     if (n_item == 0) return 0;
     hipStream_t stream = scene->stream;
     const int block = 256;
@@ -359,7 +364,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     ny = ny < 1 ? 1 : ny;
     int poly_chunk = (int)((scene->view.n + ny - 1) / ny);
     ny = (scene->view.n + poly_chunk - 1) / poly_chunk;
-    if (!d_paths) {
+    if (clear_flags) {
         if (d_count)
             hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)(grid < 1024 ? grid : 1024)), dim3(block), 0, scene->stream,
                                d_out, n_item, d_count);
@@ -430,15 +435,6 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     return 0;
 }
 
-// clears the first *n_dev (<= n_cap) bytes
-int rt_launch_zero_bytes(rt_scene *scene, uint8_t *d_out, int64_t n_cap, const unsigned long long *d_count, int64_t n_hint) {
-    int64_t grid = (std::max<int64_t>(n_hint, 1) + 255) / 256;
-    grid = grid > 1024 ? 1024 : grid;
-    hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)grid), dim3(256), 0, scene->stream, d_out, n_cap, d_count);
-    RT_HIP(hipGetLastError());
-    return 0;
-}
-
 extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t n_seg, const uint8_t *mask,
                                     uint8_t *out, int on_device) {
     if (!scene) RT_FAIL("rt_obstruct_segments: null scene");
@@ -447,7 +443,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
     if (!segs || !out) RT_FAIL("rt_obstruct_segments: null array");
     RT_HIP(hipSetDevice(scene->device));
     if (on_device) {
-        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, nullptr, 0)) return -1;
+        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, nullptr, 0, true)) return -1;
         RT_HIP(hipStreamSynchronize(scene->stream));
         return 0;
     }
@@ -461,7 +457,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
         if (hipMemcpyAsync(d_segs, segs, sizeof(double) * 6 * n_seg, hipMemcpyHostToDevice, scene->stream) != hipSuccess)
             break;
         if (mask && hipMemcpyAsync(d_mask, mask, scene->view.n, hipMemcpyHostToDevice, scene->stream) != hipSuccess) break;
-        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, nullptr, 0)) break;
+        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, nullptr, 0, true)) break;
         if (hipMemcpyAsync(out, d_out, n_seg, hipMemcpyDeviceToHost, scene->stream) != hipSuccess) break;
         if (hipStreamSynchronize(scene->stream) != hipSuccess) break;
         rc = 0;

@@ -105,6 +105,7 @@ struct rt_scene {
     unsigned long long *h_counters = nullptr;  // [16] pinned
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
+    bool timing = true;  // per-kernel-family events around the launches of a solve
     int64_t hint_paths = 0, hint_segments = 0;
     int32_t *late_items = nullptr;  // items handed from the first to the second obstruction pass (grows on demand)
     size_t late_cap = 0;
@@ -226,6 +227,70 @@ __device__ inline bool polygon_cuts_segment(const SceneView &sc, int p, d3 A, d3
     return tol < t && t < 1 - tol;
 }
 
+// The same test arranged for launches that are bound by latency rather than throughput: one pass over the ring with
+// the vertex loads issued four at a time and no early exit (more arithmetic, a quarter of the dependent loads).  Same
+// result as polygon_cuts_segment.
+__device__ inline bool polygon_cuts_segment_batched(const SceneView &sc, int p, d3 A, d3 B) {
+    const double tol = 1e-8;
+    d3 V = B - A;
+    d3 fx, fy, fz;
+    frame_from_vector(V, fx, fy, fz);
+    const double z_min = dot(A, fz), z_max = dot(B, fz);
+    const int v0 = sc.vert_off[p], nv = sc.vert_off[p + 1] - v0;
+    // extent of the polygon along the segment (geometry.py:866-871): some vertex beyond the start and some before the
+    // end.  The polygon's box bounds every vertex, so where the box says no (with a margin far above the rounding of
+    // the sums) the vertices need not be looked at.
+    {
+        const double *bb = sc.bbox + 6 * (size_t)p;
+        const double cx = 0.5 * (bb[0] + bb[3]), cy = 0.5 * (bb[1] + bb[4]), cz = 0.5 * (bb[2] + bb[5]);
+        const double zc = cx * fz.x + cy * fz.y + cz * fz.z;
+        const double r = 0.5 * ((bb[3] - bb[0]) * fabs(fz.x) + (bb[4] - bb[1]) * fabs(fz.y) + (bb[5] - bb[2]) * fabs(fz.z));
+        const double eps = 1e-9 * (fabs(zc) + r + fabs(z_min) + fabs(z_max) + 1.0);
+        if (zc + r + eps <= z_min || zc - r - eps >= z_max) return false;
+    }
+    // One pass over the ring for both the extent and the crossing-number test of the segment's start in the plane
+    // across the segment (pip_inclusive's arithmetic), four vertices at a time with their loads issued together: the
+    // test is a chain of dependent loads, and a roof has tens of vertices.
+    const double px = dot(A, fx), py = dot(A, fy);
+    const double *vb = sc.verts + 3 * (size_t)v0;
+    double zlo = INFINITY, zhi = -INFINITY;
+    bool inside = false, boundary = false;
+    double ax, ay;
+    {
+        const d3 P = ld3(vb + 3 * (nv - 1));
+        ax = dot(P, fx);
+        ay = dot(P, fy);
+    }
+    for (int k0 = 0; k0 < nv; k0 += 4) {
+        d3 P[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[j] = ld3(vb + 3 * (k0 + j < nv ? k0 + j : nv - 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k0 + j < nv) {
+                const double z = dot(P[j], fz);
+                zlo = fmin(zlo, z);
+                zhi = fmax(zhi, z);
+                const double bx = dot(P[j], fx), by = dot(P[j], fy);
+                const double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+                if (cr == 0.0 && fmin(ax, bx) <= px && px <= fmax(ax, bx) && fmin(ay, by) <= py && py <= fmax(ay, by))
+                    boundary = true;
+                if ((ay > py) != (by > py)) {
+                    if ((cr > 0.0) == (by > ay)) inside = !inside;
+                }
+                ax = bx;
+                ay = by;
+            }
+        }
+    }
+    if (!(zhi > z_min && zlo < z_max)) return false;
+    if (!(boundary || inside)) return false;
+    d3 n = ld3(sc.planes + 4 * (size_t)p);
+    double d = sc.planes[4 * (size_t)p + 3];
+    double t = -(d + dot(A, n)) / dot(V, n);
+    return tol < t && t < 1 - tol;
+}
+
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     return r * (2.0 - x * r);  // one Newton step: plenty for a pre-test with a 1e-6 pad
@@ -258,11 +323,31 @@ __device__ inline bool polygon_contains_point(const SceneView &sc, int p, d3 X, 
     double px = dot(X, ld3(f)), py = dot(X, ld3(f + 3));
     const int v0 = sc.vert_off[p], nv = sc.vert_off[p + 1] - v0;
     const double *uv = sc.uv + 2 * (size_t)v0;
-    return pip_inclusive(
-        nv,
-        [&](int k, double &x, double &y) {
-            x = uv[2 * k];
-            y = uv[2 * k + 1];
-        },
-        px, py);
+    // pip_inclusive's arithmetic, four ring vertices at a time with their loads issued together and no early exit
+    bool inside = false, boundary = false;
+    double ax = uv[2 * (nv - 1)], ay = uv[2 * (nv - 1) + 1];
+    for (int k0 = 0; k0 < nv; k0 += 4) {
+        double bxs[4], bys[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j < nv ? k0 + j : nv - 1;
+            bxs[j] = uv[2 * k];
+            bys[j] = uv[2 * k + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k0 + j < nv) {
+                const double bx = bxs[j], by = bys[j];
+                const double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+                if (cr == 0.0 && fmin(ax, bx) <= px && px <= fmax(ax, bx) && fmin(ay, by) <= py && py <= fmax(ay, by))
+                    boundary = true;
+                if ((ay > py) != (by > py)) {
+                    if ((cr > 0.0) == (by > ay)) inside = !inside;
+                }
+                ax = bx;
+                ay = by;
+            }
+        }
+    }
+    return boundary || inside;
 }

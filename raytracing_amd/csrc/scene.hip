@@ -196,6 +196,12 @@ extern "C" int rt_debug_set_occlusion_mode(rt_scene *s, int mode) {
     return 0;
 }
 
+extern "C" int rt_scene_set_timing(rt_scene *s, int on) {
+    if (!s) RT_FAIL("rt_scene_set_timing: null scene");
+    s->timing = on != 0;
+    return 0;
+}
+
 extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *vert_off, const double *verts,
                                      const double *planes, const int32_t *material_id, const int32_t *building_id) {
     if (n_poly <= 0 || !vert_off || !verts || !planes) {

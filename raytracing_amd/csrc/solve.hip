@@ -26,8 +26,7 @@
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, int64_t n_masked,
                        uint8_t *d_out, const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths,
-                       int round);
-int rt_launch_zero_bytes(rt_scene *scene, uint8_t *d_out, int64_t n_cap, const unsigned long long *d_count, int64_t n_hint);
+                       int round, bool clear_flags);
 
 #define MIN_DISTANCE_TOL 0.005 /* ray_tracing.py:252 */
 
@@ -36,7 +35,18 @@ struct Queues {
     double *segs;
     int64_t path_cap, seg_cap;
     unsigned long long *counters;  // [0] paths, [1] segments
+    uint8_t *hits;                 // obstruction flags, cleared by whoever queues a path
+    int hits_per_path;             // one flag per path (else one per segment)
 };
+
+// clears the obstruction flags of a path that was just queued
+__device__ __forceinline__ void clear_hits(const Queues &q, int64_t path_slot, int64_t seg0, int64_t stride, int nseg) {
+    if (q.hits_per_path) {
+        q.hits[path_slot] = 0;
+    } else {
+        for (int i = 0; i < nseg; ++i) q.hits[seg0 + i * stride] = 0;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // enumeration kernels
@@ -484,12 +494,13 @@ __device__ inline bool unfold_exact(const d3 *nrm, const double *g, const d3 *im
     return true;
 }
 
-// Exact solve and checks of one (candidate, receiver) pair of a K-reflection group; appends the path if it survives.
+// Exact solve and checks of one (candidate, receiver) pair of a K-reflection group: true when the path survives them;
+// X = its reflection points.
 template <int K>
-__device__ inline void reflect_exact(const SceneView &sc, const int32_t *__restrict__ chains, int64_t c, int group,
-                                     d3 tx, d3 R, int64_t r, const Queues &q) {
+__device__ inline bool reflect_exact(const SceneView &sc, const int32_t *__restrict__ chains, int64_t c, d3 tx, d3 R,
+                                     d3 *X) {
     int32_t poly[K];
-    d3 nrm[K], img[K], X[K];
+    d3 nrm[K], img[K];
     double g[K];
     d3 prev = tx;
 #pragma unroll
@@ -502,22 +513,26 @@ __device__ inline void reflect_exact(const SceneView &sc, const int32_t *__restr
         g[i] = -s;
         prev = img[i];
     }
-    if (!unfold_exact<K>(nrm, g, img, R, X)) return;
+    if (!unfold_exact<K>(nrm, g, img, R, X)) return false;
     // ray_tracing.py:253-255; all K tests are made before looking at any of them, so that their loads overlap
     bool inside = true;
 #pragma unroll
     for (int i = 0; i < K; ++i) inside = polygon_contains_point(sc, poly[i], X[i], true, 1e-8) && inside;
-    if (!inside) return;
+    if (!inside) return false;
     // ray_tracing.py:268-272
     d3 a = tx;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        if (!(norm3(a - X[i]) >= MIN_DISTANCE_TOL)) return;
+        if (!(norm3(a - X[i]) >= MIN_DISTANCE_TOL)) return false;
         a = X[i];
     }
-    if (!(norm3(a - R) >= MIN_DISTANCE_TOL)) return;
-    int64_t ps, ss;
-    if (!reserve(q, K + 1, ps, ss)) return;
+    return norm3(a - R) >= MIN_DISTANCE_TOL;
+}
+
+// Queue record and segments of a surviving reflection path.
+template <int K>
+__device__ inline void reflect_emit(const Queues &q, int64_t ps, int64_t ss, int group, int64_t c, int64_t r, d3 tx, d3 R,
+                                    const d3 *X) {
     PathRec &rec = q.paths[ps];
     rec.rx = (int32_t)r;
     rec.group = group;
@@ -525,7 +540,8 @@ __device__ inline void reflect_exact(const SceneView &sc, const int32_t *__restr
     rec.nseg = K + 1;
     rec.seg0 = ss;
     rec.seg_stride = 1;
-    a = tx;
+    clear_hits(q, ps, ss, 1, K + 1);
+    d3 a = tx;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         st3(rec.pts + 3 * i, X[i]);
@@ -540,12 +556,32 @@ __device__ inline void reflect_exact(const SceneView &sc, const int32_t *__restr
 // Reflection candidates: lane = candidate of a K-reflection group, loop = receivers of the block's tile.
 // The loop only runs the padded pre-test (is the last reflection point near its polygon's box?); pairs that pass are
 // parked in a per-wave LDS queue and solved exactly 64 at a time, so the expensive part runs with all lanes busy
-// instead of once per receiver with one or two lanes.
+// instead of once per receiver with one or two lanes.  Survivors are parked again (few per wave) and written out at
+// the end of the block with ONE reservation in the path and segment queues for the whole block: atomics on one
+// address serialise at about 10 ns each, which a reservation per wave and exact batch made the longest part of a
+// small launch.  A wave whose survivor list fills up before that writes 64 of them out on its own.
+struct ReflectShared {
+    uint32_t wave_queue[4][128];  // pairs waiting for the exact solve: lane << 16 | receiver within the tile
+    uint32_t survivors[4][128];   // same encoding
+    int n_survivors[4];
+    long long base[2];
+};
+
+template <int K>
+__device__ __forceinline__ void reflect_write(const SceneView &sc, const int32_t *__restrict__ chains, int group, d3 tx,
+                                              const double *__restrict__ rx, int64_t c_base, int64_t r_begin,
+                                              const Queues &q, uint32_t e, int64_t ps, int64_t ss) {
+    const int64_t rr = r_begin + (e & 0xffffu);
+    const d3 R = ld3(rx + 3 * rr);
+    d3 X[K];
+    (void)reflect_exact<K>(sc, chains, c_base + (e >> 16), tx, R, X);
+    reflect_emit<K>(q, ps, ss, group, c_base + (e >> 16), rr, tx, R, X);
+}
+
 template <int K>
 __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t *__restrict__ chains, int64_t count,
                                               int group, d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t rx1,
-                                              int rx_tile, const Queues &q, unsigned block_x,
-                                              uint32_t (*wave_queue)[128]) {
+                                              int rx_tile, const Queues &q, unsigned block_x, ReflectShared &sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c_base = (int64_t)block_x * blockDim.x + wave * 64;
     const int64_t c = c_base + lane;
@@ -568,8 +604,27 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
 
     const int64_t r_begin = rx0 + (int64_t)blockIdx.y * rx_tile;
     const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
-    int qn = 0;  // wave-uniform
-    uint32_t *wq = wave_queue[wave];
+    int qn = 0, sn = 0;  // wave-uniform
+    uint32_t *wq = sh.wave_queue[wave], *ws = sh.survivors[wave];
+    // exact solve of the queue entry e of every lane that has one; survivors go to the wave's list
+    auto solve_batch = [&](bool has, uint32_t e) {
+        bool ok = false;
+        if (has) {
+            d3 X[K];
+            ok = reflect_exact<K>(sc, chains, c_base + (e >> 16), tx, ld3(rx + 3 * (r_begin + (e & 0xffffu))), X);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m == 0) return;
+        if (ok) ws[sn + __popcll(m & ((1ull << lane) - 1))] = e;
+        sn += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (sn >= 64) {
+            sn -= 64;
+            int64_t ps, ss;
+            if (reserve(q, K + 1, ps, ss)) reflect_write<K>(sc, chains, group, tx, rx, c_base, r_begin, q, ws[sn + lane], ps, ss);
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
     // four receivers per trip: their pre-tests are independent, which hides the fp64 latency of one behind the others
     for (int64_t r4 = r_begin; r4 < r_end; r4 += 4) {
         bool pass[4];
@@ -593,19 +648,28 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
             qn += __popcll(m);
             __builtin_amdgcn_wave_barrier();
             if (qn >= 64) {
-                const uint32_t e = wq[qn - 64 + lane];
                 qn -= 64;
-                const int64_t rr = r_begin + (e & 0xffffu);
-                reflect_exact<K>(sc, chains, c_base + (e >> 16), group, tx, ld3(rx + 3 * rr), rr, q);
-                __builtin_amdgcn_wave_barrier();
+                solve_batch(true, wq[qn + lane]);
             }
         }
     }
-    if (lane < qn) {
-        const uint32_t e = wq[lane];
-        const int64_t rr = r_begin + (e & 0xffffu);
-        reflect_exact<K>(sc, chains, c_base + (e >> 16), group, tx, ld3(rx + 3 * rr), rr, q);
+    if (qn > 0) solve_batch(lane < qn, lane < qn ? wq[lane] : 0u);
+    // one reservation for what the four waves still hold
+    if (lane == 0) sh.n_survivors[wave] = sn;
+    __syncthreads();
+    const int total = sh.n_survivors[0] + sh.n_survivors[1] + sh.n_survivors[2] + sh.n_survivors[3];
+    if (total == 0) return;
+    if (threadIdx.x == 0) {
+        sh.base[0] = (long long)atomicAdd(&q.counters[0], (unsigned long long)total);
+        sh.base[1] = (long long)atomicAdd(&q.counters[1], (unsigned long long)total * (unsigned)(K + 1));
     }
+    __syncthreads();
+    if (sh.base[0] + total > q.path_cap || sh.base[1] + (long long)total * (K + 1) > q.seg_cap) return;  // chunk is redone
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += sh.n_survivors[w];
+    if (lane < sn)
+        reflect_write<K>(sc, chains, group, tx, rx, c_base, r_begin, q, ws[lane], sh.base[0] + before + lane,
+                         sh.base[1] + (int64_t)(before + lane) * (K + 1));
 }
 
 // All reflection orders of a solve in ONE launch (a small step is bound by the number of dependent launches): the
@@ -619,7 +683,7 @@ struct ReflectGroups {
 template <int MO>
 __global__ __launch_bounds__(256) void k_reflect(SceneView sc, ReflectGroups g, d3 tx, const double *__restrict__ rx,
                                                   int64_t rx0, int64_t rx1, int rx_tile, Queues q) {
-    __shared__ uint32_t wave_queue[4][128];
+    __shared__ ReflectShared wave_queue;
     const unsigned b = blockIdx.x;
     if (b < g.first_block[1]) {
         reflect_block<1>(sc, g.chains[0], g.count[0], 0, tx, rx, rx0, rx1, rx_tile, q, b, wave_queue);
@@ -825,6 +889,7 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
         rec.nseg = 2;
         rec.seg0 = s0 + j;
         rec.seg_stride = n;
+        clear_hits(q, p0 + j, s0 + j, n, 2);
         if (M > 0) {
             const AliveRec &al = alive[c_begin + (e >> 6)];
             for (int i = 0; i < M; ++i) st3(rec.pts + 3 * i, ld3(al.pts + 3 * i));
@@ -838,12 +903,17 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
 }
 
 // The line of sight of every receiver of the chunk as the first records of the path queue (group -1, one segment),
-// and the queue counters started at that many records: the candidate kernels append behind them.
-__global__ void k_los_emit(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t n, Queues q) {
+// and the queue counters started at that many records: the candidate kernels append behind them.  The first chunk of
+// a solve also starts the result counter ([2]) and the count of finished filter blocks ([3]).
+__global__ void k_los_emit(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t n, Queues q, int first_chunk) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         q.counters[0] = (unsigned long long)n;
         q.counters[1] = (unsigned long long)n;
+        if (first_chunk) {
+            q.counters[2] = 0;
+            q.counters[3] = 0;
+        }
     }
     if (i >= n) return;
     PathRec &rec = q.paths[i];
@@ -853,6 +923,7 @@ __global__ void k_los_emit(d3 tx, const double *__restrict__ rx, int64_t rx0, in
     rec.nseg = 1;
     rec.seg0 = i;
     rec.seg_stride = 1;
+    clear_hits(q, i, i, 1, 1);
     for (int k = 0; k < RT_MAX_ORDER * 3; ++k) rec.pts[k] = 0.0;
     st3(q.segs + 6 * i, tx);
     st3(q.segs + 6 * i + 3, ld3(rx + 3 * (rx0 + i)));
@@ -870,13 +941,15 @@ struct OutArrays {
 // the chunk with larger queues).  hit holds one flag per segment, or (per_path) one per path.  A wave looks at 512
 // paths and reserves the room of its survivors with one atomic.
 // FINALIZE_ITEMS = 8 paths per lane for large batches (few atomics), 1 for small ones (more waves, shorter chains).
+// The block that finishes last copies counters[0..2] to host_counters (host memory the device can write), so the host
+// needs no copy after the launch, and clears the count of finished blocks (counters[3]) for the next launch.
 template <int FINALIZE_ITEMS>
 __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ paths, const uint8_t *__restrict__ hit,
-                                                   const unsigned long long *__restrict__ counters, int64_t path_cap,
-                                                   int64_t seg_cap, int per_path, OutArrays out) {
+                                                   unsigned long long *counters, int64_t path_cap, int64_t seg_cap,
+                                                   int per_path, OutArrays out, unsigned long long *host_counters) {
     const unsigned long long np = counters[0], ns = counters[1];
-    if (np > (unsigned long long)path_cap || ns > (unsigned long long)seg_cap) return;
-    const int64_t n = (int64_t)np;
+    const bool fits = np <= (unsigned long long)path_cap && ns <= (unsigned long long)seg_cap;
+    const int64_t n = fits ? (int64_t)np : 0;
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -919,6 +992,19 @@ __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ pa
             for (int k = 0; k < RT_MAX_ORDER * 3; ++k) out.pts[slot * RT_MAX_ORDER * 3 + k] = p.pts[k];
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long done = atomicAdd(&counters[3], 1ull);
+        if (done == (unsigned long long)gridDim.x - 1) {
+            __threadfence();
+            host_counters[0] = np;
+            host_counters[1] = ns;
+            host_counters[2] = atomicAdd(&counters[2], 0ull);
+            counters[3] = 0;
+            __threadfence_system();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -938,12 +1024,15 @@ struct EventTimer {
         return sc->event_pool[sc->events_used++];
     }
     void begin(int fam) {
+        if (!sc->timing) return;
         hipEvent_t a = take(), b = take();
         (void)hipEventRecord(a, sc->stream);
         ev[fam].push_back(a);
         ev[fam].push_back(b);
     }
-    void end(int fam) { (void)hipEventRecord(ev[fam].back(), sc->stream); }
+    void end(int fam) {
+        if (sc->timing) (void)hipEventRecord(ev[fam].back(), sc->stream);
+    }
     // after the stream has been synchronised
     void collect(double *ms, int64_t *launches) {
         for (int f = 0; f < 4; ++f) {
@@ -1059,7 +1148,8 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
 
     unsigned long long *d_counters = scene->d_counters;  // 0 paths, 1 segments, 2 results, 4-5 pre-pass
     unsigned long long *h_counters = scene->h_counters;
-    SOLVE_HIP(hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 8, st));
+    unsigned long long *h_counters_dev = nullptr;  // the same words as the device addresses them
+    SOLVE_HIP(hipHostGetDevicePointer((void **)&h_counters_dev, h_counters, 0));
     if (on_device) {
         out.rx = out_rx;
         out.group = out_group;
@@ -1114,7 +1204,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_HIP(hipStreamSynchronize(st));
         if (n0 == 0) continue;
         timer.begin(2);
-        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, nullptr, 0)) {
+        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, nullptr, 0, true)) {
             free_temps();
             return -1;
         }
@@ -1191,13 +1281,19 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
             return -1;
         }
         char *w = (char *)ws;
-        Queues q{(PathRec *)(w + off_paths), (double *)(w + off_segs), path_cap, seg_cap, d_counters};
         uint8_t *d_hits = (uint8_t *)(w + off_hits);
+
+        const int64_t seg_hint = scene->hint_segments > 0 ? scene->hint_segments : std::min<int64_t>(seg_cap, 1 << 22);
+        const int64_t path_hint = scene->hint_paths > 0 ? scene->hint_paths : std::min<int64_t>(path_cap, 1 << 21);
+        // Large batches: one obstruction launch per segment place, last segment first, each skipping the paths already
+        // blocked (flags per path).  Small batches are launch-bound: one launch over all segments (flags per segment).
+        const bool by_rounds = path_hint >= (1 << 15);
+        Queues q{(PathRec *)(w + off_paths), (double *)(w + off_segs), path_cap, seg_cap, d_counters, d_hits, by_rounds ? 1 : 0};
 
         // lines of sight: queued like every other path, tested against the polygons the emitter sees only
         // (ray_tracing.py:232-237); this launch also starts the queue counters
         timer.begin(3);
-        hipLaunchKernelGGL(k_los_emit, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, q);
+        hipLaunchKernelGGL(k_los_emit, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, q, r0 == 0 ? 1 : 0);
         timer.end(3);
 
         // reflections of every order, one launch
@@ -1220,41 +1316,31 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
             timer.end(1);
         }
         // obstruction of the queued segments and the final filter, sized on the device
-        const int64_t seg_hint = scene->hint_segments > 0 ? scene->hint_segments : std::min<int64_t>(seg_cap, 1 << 22);
-        const int64_t path_hint = scene->hint_paths > 0 ? scene->hint_paths : std::min<int64_t>(path_cap, 1 << 21);
-        // Large batches: one launch per segment place, last segment first, each skipping the paths already blocked
-        // (flags per path).  Small batches are launch-bound: one launch over all segments (flags per segment).
-        const bool by_rounds = path_hint >= (1 << 15);
         timer.begin(2);
         if (by_rounds) {
             int max_nseg = 0;
             for (int k = 1; k <= mo; ++k)
                 if (cand->groups[k - 1].count > 0) max_nseg = std::max(max_nseg, k + 1);
             if (any_diffraction) max_nseg = std::max(max_nseg, 2);
-            if (rt_launch_zero_bytes(scene, d_hits, path_cap, d_counters, path_hint)) {
-                free_temps();
-                return -1;
-            }
             for (int round = 0; round < max_nseg; ++round)
-                if (rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters, path_hint, q.paths, round)) {
+                if (rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters, path_hint, q.paths, round, false)) {
                     free_temps();
                     return -1;
                 }
-        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, seg_hint, nullptr, 0)) {
+        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, seg_hint, nullptr, 0, false)) {
             free_temps();
             return -1;
         }
         timer.end(2);
         timer.begin(3);
         if (path_hint >= (1 << 16))
-            hipLaunchKernelGGL(k_finalize<8>, dim3(std::min<unsigned>(blocks_for(path_hint, 256 * 8), 1u << 16)), dim3(256), 0, st,
-                               q.paths, d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out);
+            hipLaunchKernelGGL(k_finalize<8>, dim3(std::min<unsigned>(blocks_for(path_hint, 256 * 8), 4096u)), dim3(256), 0, st,
+                               q.paths, d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out, h_counters_dev);
         else
             hipLaunchKernelGGL(k_finalize<1>, dim3(blocks_for(path_hint + path_hint / 4 + 256, 256)), dim3(256), 0, st, q.paths,
-                               d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out);
+                               d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out, h_counters_dev);
         timer.end(3);
-        SOLVE_HIP(hipMemcpyAsync(h_counters, d_counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        SOLVE_HIP(hipStreamSynchronize(st));
+        SOLVE_HIP(hipStreamSynchronize(st));  // the filter's last block has written h_counters
         SOLVE_HIP(hipGetLastError());
         const int64_t n_paths = (int64_t)h_counters[0], n_segs = (int64_t)h_counters[1];
         if (n_paths > path_cap || n_segs > seg_cap) {
