@@ -61,10 +61,70 @@ __device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double
     }
 }
 
+// polygon_cuts_segment for a polygon whose plane and ring sit in LDS (ring = nv vertices of 3 doubles).  The box
+// shortcut of the global-memory form is left out: it only saves looking at the vertices, which costs little here, and
+// never changes the result.
+__device__ inline bool polygon_cuts_segment_lds(const double *ring, int nv, d3 n, double d, d3 A, d3 B) {
+    const d3 V = B - A;
+    d3 fx, fy, fz;
+    frame_from_vector(V, fx, fy, fz);
+    const double z_min = dot(A, fz), z_max = dot(B, fz);
+    const double px = dot(A, fx), py = dot(A, fy);
+    double zlo = INFINITY, zhi = -INFINITY;
+    bool inside = false, boundary = false;
+    const d3 Pl = ld3(ring + 3 * (nv - 1));
+    double ax = dot(Pl, fx), ay = dot(Pl, fy);
+    for (int k = 0; k < nv; ++k) {
+        const d3 P = ld3(ring + 3 * k);
+        const double z = dot(P, fz);
+        zlo = fmin(zlo, z);
+        zhi = fmax(zhi, z);
+        const double bx = dot(P, fx), by = dot(P, fy);
+        const double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+        if (cr == 0.0 && fmin(ax, bx) <= px && px <= fmax(ax, bx) && fmin(ay, by) <= py && py <= fmax(ay, by)) boundary = true;
+        if ((ay > py) != (by > py)) {
+            if ((cr > 0.0) == (by > ay)) inside = !inside;
+        }
+        ax = bx;
+        ay = by;
+    }
+    if (!(zhi > z_min && zlo < z_max)) return false;
+    if (!(boundary || inside)) return false;
+    const double t = -(d + dot(A, n)) / dot(V, n);
+    return 1e-8 < t && t < 1 - 1e-8;
+}
+
+#define OBS_STAGE 128
+#define OBS_STAGE_VERTS 1024
+
+// obstruct_drain for entries whose polygons are those of the stage in LDS: recs[i], ring of polygon i =
+// verts[3 * voff[i] .. 3 * voff[i + 1]); an entry's polygon field counts from the stage's first polygon.
+__device__ __forceinline__ void obstruct_drain_lds(const OccRec *recs, const int *voff, const double *verts,
+                                                   const double *__restrict__ segs, const int64_t *wave_seg,
+                                                   const int64_t *wave_item, const uint32_t *entries, int n_entries,
+                                                   int lane, volatile uint8_t *wave_hit, uint8_t *__restrict__ out) {
+    if (lane < n_entries) {
+        const uint32_t e = entries[lane];
+        const int L = (int)(e & 63u);
+        if (!wave_hit[L]) {
+            const int64_t s = wave_seg[L];
+            const int i = (int)(e >> 6);
+            const OccRec &r = recs[i];
+            const int v0 = voff[i], nv = voff[i + 1] - v0;
+            if (polygon_cuts_segment_lds(verts + 3 * v0, nv, mk3(r.nx, r.ny, r.nz), r.d, ld3(segs + 6 * s), ld3(segs + 6 * s + 3))) {
+                wave_hit[L] = 1;
+                out[wave_item[L]] = 1;
+            }
+        }
+    }
+}
+
 // Every-polygon walk.  n_dev, when given, holds the segment count on the device (clamped to n_cap; a count above n_cap
 // means the producer overflowed its queue and the launch does nothing).  The block stages the pre-test records of its
-// polygon range through LDS, OBS_STAGE at a time, so the inner loop reads them at LDS latency.
-#define OBS_STAGE 128
+// polygon range through LDS, OBS_STAGE at a time, so the inner loop reads them at LDS latency, and with them the
+// polygons' rings when they fit (OBS_STAGE_VERTS vertices): a small launch is a chain of dependent memory accesses, and
+// the exact test of a roof with tens of vertices was the longest link of it (13 of 28 us on 10 000 segments x 237
+// polygons).  Pairs parked during a stage are then examined before the next stage replaces the rings.
 #define RT_GRID_MIN_POLYGONS 512
 #define OBS_PASSES 2
 #define OBS_FIRST_PASS_TRIPS 24
@@ -76,6 +136,8 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
     const double *__restrict__ segs = items.segs;
     __shared__ OccRec s_rec[OBS_STAGE];
     __shared__ uint8_t s_mask[OBS_STAGE];
+    __shared__ double s_verts[3 * OBS_STAGE_VERTS];
+    __shared__ int s_voff[OBS_STAGE + 1];
     __shared__ uint32_t wave_queue[4][128];
     __shared__ uint8_t wave_hits[4][64];
     int64_t n_seg = n_cap;
@@ -111,6 +173,8 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
         for (int p0 = p_begin; p0 < p_end; p0 += OBS_STAGE) {
             if (__syncthreads_and(wave_done)) break;  // also: the previous stage has been consumed
             const int cnt = p_end - p0 < OBS_STAGE ? p_end - p0 : OBS_STAGE;
+            const int v_begin = sc.vert_off[p0], v_count = sc.vert_off[p0 + cnt] - v_begin;
+            const bool rings_staged = v_count <= OBS_STAGE_VERTS;  // block-uniform
             {
                 const uint4 *src = (const uint4 *)(sc.poly_recs + p0);
                 uint4 *dst = (uint4 *)s_rec;
@@ -118,9 +182,21 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                 if (MASKED) {
                     for (int i = threadIdx.x; i < cnt; i += blockDim.x) s_mask[i] = mask[p0 + i];
                 }
+                if (rings_staged) {
+                    const double *vs = sc.verts + 3 * (size_t)v_begin;
+                    for (int i = threadIdx.x; i < 3 * v_count; i += blockDim.x) s_verts[i] = vs[i];
+                    for (int i = threadIdx.x; i <= cnt; i += blockDim.x) s_voff[i] = sc.vert_off[p0 + i] - v_begin;
+                }
             }
             __syncthreads();
             if (wave_done) continue;
+            const int stage_first = rings_staged ? p0 - p_begin : 0;  // what an entry's polygon field counts from
+            if (rings_staged && qn > 0) {  // pairs parked during a stage whose rings did not fit
+                obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
+                __builtin_amdgcn_wave_barrier();
+                qn = 0;
+                hit = wave_hit[lane] != 0;
+            }
             for (int r = 0; r < cnt; ++r) {
                 bool wanted = active && !hit;
                 if (MASKED) wanted = wanted && (!use_mask || s_mask[r]);
@@ -128,12 +204,17 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                 // pairs that pass the padded pre-test are parked and examined exactly 64 at a time, all lanes busy
                 const unsigned long long m = __ballot(cand);
                 if (m != 0) {
-                    if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)(p0 + r - p_begin) << 6) | (uint32_t)lane;
+                    if (cand)
+                        wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)(p0 + r - p_begin - stage_first) << 6) | (uint32_t)lane;
                     qn += __popcll(m);
                     __builtin_amdgcn_wave_barrier();
                     if (qn >= 64) {
                         qn -= 64;
-                        obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq + qn, 64, lane, wave_hit, out);
+                        if (rings_staged)
+                            obstruct_drain_lds(s_rec, s_voff, s_verts, segs, wave_segs[wave], wave_items[wave], wq + qn, 64, lane,
+                                               wave_hit, out);
+                        else
+                            obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq + qn, 64, lane, wave_hit, out);
                         __builtin_amdgcn_wave_barrier();
                         hit = wave_hit[lane] != 0;
                         if (__all(hit || !active)) {
@@ -143,6 +224,13 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                         }
                     }
                 }
+            }
+            if (rings_staged && qn > 0) {  // before the next stage replaces the rings
+                obstruct_drain_lds(s_rec, s_voff, s_verts, segs, wave_segs[wave], wave_items[wave], wq, qn, lane, wave_hit, out);
+                __builtin_amdgcn_wave_barrier();
+                qn = 0;
+                hit = wave_hit[lane] != 0;
+                if (__all(hit || !active)) wave_done = true;
             }
         }
         if (qn > 0) obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
