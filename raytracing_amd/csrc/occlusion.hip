@@ -24,6 +24,7 @@ struct ObstructItems {
     int round;
     int64_t n_masked;
     const int32_t *index;  // when given, work item k is item index[k] (second pass over the stragglers of a first)
+    int64_t count_add;     // added to the item count read from the device
 };
 
 __device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t &i, const uint8_t *__restrict__ out,
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
     __shared__ uint8_t wave_hits[4][64];
     int64_t n_seg = n_cap;
     if (n_dev) {
-        const unsigned long long nd = *n_dev;
+        const unsigned long long nd = *n_dev + (unsigned long long)items.count_add;
         if (nd > (unsigned long long)n_cap) return;
         n_seg = (int64_t)nd;
     }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
     __shared__ uint8_t wave_hits[4][64];
     int64_t n_seg = n_cap;
     if (n_dev) {
-        const unsigned long long nd = *n_dev;
+        const unsigned long long nd = *n_dev + (unsigned long long)items.count_add;
         if (nd > (unsigned long long)n_cap) return;
         n_seg = (int64_t)nd;
     }
@@ -424,8 +425,9 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
     }
 }
 
-__global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const unsigned long long *__restrict__ n_dev) {
-    const unsigned long long nd = *n_dev;
+__global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const unsigned long long *__restrict__ n_dev,
+                             int64_t count_add) {
+    const unsigned long long nd = *n_dev + (unsigned long long)count_add;
     const int64_t n = nd > (unsigned long long)n_cap ? 0 : (int64_t)nd;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0;
 }
@@ -434,10 +436,10 @@ __global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const uns
 // the flags then accumulate over the rounds).  The flags are cleared first when clear_flags is set; otherwise whoever
 // queued the items has cleared them.  d_mask, when given, restricts the polygons
 // for the first n_masked segments / the line-of-sight paths.  With d_count the device holds the item
-// count (<= n_item) and the grid is sized for n_hint of them.
+// count less count_add (the sum <= n_item) and the grid is sized for n_hint of them.
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, const uint8_t *d_mask, int64_t n_masked,
-                       uint8_t *d_out, const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths,
-                       int round, bool clear_flags) {
+                       uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
+                       const PathRec *d_paths, int round, bool clear_flags) {
     if (n_item == 0) return 0;
     hipStream_t stream = scene->stream;
     const int block = 256;
@@ -455,11 +457,11 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     if (clear_flags) {
         if (d_count)
             hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)(grid < 1024 ? grid : 1024)), dim3(block), 0, scene->stream,
-                               d_out, n_item, d_count);
+                               d_out, n_item, d_count, count_add);
         else
             RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_item, scene->stream));
     }
-    const ObstructItems items{d_segs, d_paths, round, d_mask ? n_masked : 0, nullptr};
+    const ObstructItems items{d_segs, d_paths, round, d_mask ? n_masked : 0, nullptr, d_count ? count_add : 0};
     // small launches on small scenes are latency-bound: there the every-polygon walk, split over grid.y, is quicker
     const bool walk_grid = scene->occlusion_mode == 2 ||
                            (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
@@ -498,6 +500,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
                 unsigned g = (unsigned)grid;
                 if (pass > 0) {
                     it.index = scene->late_items + (size_t)((pass - 1) & 1) * n_item;
+                    it.count_add = 0;
                     n_in = counts + ((pass - 1) & 1);
                     g = (unsigned)std::max<int64_t>(1024, grid >> (2 * pass));
                 }
@@ -531,7 +534,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
     if (!segs || !out) RT_FAIL("rt_obstruct_segments: null array");
     RT_HIP(hipSetDevice(scene->device));
     if (on_device) {
-        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, nullptr, 0, true)) return -1;
+        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, 0, nullptr, 0, true)) return -1;
         RT_HIP(hipStreamSynchronize(scene->stream));
         return 0;
     }
@@ -545,7 +548,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
         if (hipMemcpyAsync(d_segs, segs, sizeof(double) * 6 * n_seg, hipMemcpyHostToDevice, scene->stream) != hipSuccess)
             break;
         if (mask && hipMemcpyAsync(d_mask, mask, scene->view.n, hipMemcpyHostToDevice, scene->stream) != hipSuccess) break;
-        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, nullptr, 0, true)) break;
+        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, 0, nullptr, 0, true)) break;
         if (hipMemcpyAsync(out, d_out, n_seg, hipMemcpyDeviceToHost, scene->stream) != hipSuccess) break;
         if (hipStreamSynchronize(scene->stream) != hipSuccess) break;
         rc = 0;

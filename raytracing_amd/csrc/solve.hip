@@ -25,8 +25,8 @@
 #include "rt_common.h"
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, int64_t n_masked,
-                       uint8_t *d_out, const unsigned long long *d_count, int64_t n_hint, const PathRec *d_paths,
-                       int round, bool clear_flags);
+                       uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
+                       const PathRec *d_paths, int round, bool clear_flags);
 
 #define MIN_DISTANCE_TOL 0.005 /* ray_tracing.py:252 */
 
@@ -34,7 +34,8 @@ struct Queues {
     PathRec *paths;
     double *segs;
     int64_t path_cap, seg_cap;
-    unsigned long long *counters;  // [0] paths, [1] segments
+    unsigned long long *counters;  // [0] paths, [1] segments queued behind the lines of sight
+    int64_t base;                  // records and segments [0, base) are the chunk's lines of sight
     uint8_t *hits;                 // obstruction flags, cleared by whoever queues a path
     int hits_per_path;             // one flag per path (else one per segment)
 };
@@ -472,8 +473,8 @@ __device__ inline bool reserve(const Queues &q, int nseg, int64_t &path_slot, in
     const unsigned phi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bp >> 32));
     const unsigned slo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bs);
     const unsigned shi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bs >> 32));
-    path_slot = (int64_t)((((unsigned long long)phi << 32) | plo) + rank);
-    seg_slot = (int64_t)((((unsigned long long)shi << 32) | slo) + (unsigned long long)rank * (unsigned)nseg);
+    path_slot = q.base + (int64_t)((((unsigned long long)phi << 32) | plo) + rank);
+    seg_slot = q.base + (int64_t)((((unsigned long long)shi << 32) | slo) + (unsigned long long)rank * (unsigned)nseg);
     return path_slot < q.path_cap && seg_slot + nseg <= q.seg_cap;
 }
 
@@ -660,8 +661,8 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
     const int total = sh.n_survivors[0] + sh.n_survivors[1] + sh.n_survivors[2] + sh.n_survivors[3];
     if (total == 0) return;
     if (threadIdx.x == 0) {
-        sh.base[0] = (long long)atomicAdd(&q.counters[0], (unsigned long long)total);
-        sh.base[1] = (long long)atomicAdd(&q.counters[1], (unsigned long long)total * (unsigned)(K + 1));
+        sh.base[0] = q.base + (long long)atomicAdd(&q.counters[0], (unsigned long long)total);
+        sh.base[1] = q.base + (long long)atomicAdd(&q.counters[1], (unsigned long long)total * (unsigned)(K + 1));
     }
     __syncthreads();
     if (sh.base[0] + total > q.path_cap || sh.base[1] + (long long)total * (K + 1) > q.seg_cap) return;  // chunk is redone
@@ -670,6 +671,22 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
     if (lane < sn)
         reflect_write<K>(sc, chains, group, tx, rx, c_base, r_begin, q, ws[lane], sh.base[0] + before + lane,
                          sh.base[1] + (int64_t)(before + lane) * (K + 1));
+}
+
+// The line of sight of receiver rx0 + i of the chunk as record i of the path queue (group -1, one segment): the
+// candidate kernels append behind the chunk's lines of sight (Queues::base).
+__device__ __forceinline__ void los_emit_one(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t i, const Queues &q) {
+    PathRec &rec = q.paths[i];
+    rec.rx = (int32_t)(rx0 + i);
+    rec.group = -1;
+    rec.cand = 0;
+    rec.nseg = 1;
+    rec.seg0 = i;
+    rec.seg_stride = 1;
+    clear_hits(q, i, i, 1, 1);
+    for (int k = 0; k < RT_MAX_ORDER * 3; ++k) rec.pts[k] = 0.0;
+    st3(q.segs + 6 * i, tx);
+    st3(q.segs + 6 * i + 3, ld3(rx + 3 * (rx0 + i)));
 }
 
 // All reflection orders of a solve in ONE launch (a small step is bound by the number of dependent launches): the
@@ -685,6 +702,10 @@ __global__ __launch_bounds__(256) void k_reflect(SceneView sc, ReflectGroups g, 
                                                   int64_t rx0, int64_t rx1, int rx_tile, Queues q) {
     __shared__ ReflectShared wave_queue;
     const unsigned b = blockIdx.x;
+    if (b == 0) {  // the lines of sight of this row of blocks' receivers
+        const int64_t r = rx0 + (int64_t)blockIdx.y * rx_tile + threadIdx.x;
+        if ((int)threadIdx.x < rx_tile && r < rx1) los_emit_one(tx, rx, rx0, r - rx0, q);
+    }
     if (b < g.first_block[1]) {
         reflect_block<1>(sc, g.chains[0], g.count[0], 0, tx, rx, rx0, rx1, rx_tile, q, b, wave_queue);
     } else if (MO >= 2 && b < g.first_block[2]) {
@@ -867,8 +888,8 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
     const int total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
     if (total == 0) return;
     if (threadIdx.x == 0) {
-        s_base[0] = (long long)atomicAdd(&q.counters[0], (unsigned long long)total);
-        s_base[1] = (long long)atomicAdd(&q.counters[1], 2ull * (unsigned long long)total);
+        s_base[0] = q.base + (long long)atomicAdd(&q.counters[0], (unsigned long long)total);
+        s_base[1] = q.base + (long long)atomicAdd(&q.counters[1], 2ull * (unsigned long long)total);
     }
     __syncthreads();
     if (s_base[0] + total > q.path_cap || s_base[1] + 2 * (long long)total > q.seg_cap) return;  // host redoes the chunk
@@ -902,31 +923,10 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
     }
 }
 
-// The line of sight of every receiver of the chunk as the first records of the path queue (group -1, one segment),
-// and the queue counters started at that many records: the candidate kernels append behind them.  The first chunk of
-// a solve also starts the result counter ([2]) and the count of finished filter blocks ([3]).
-__global__ void k_los_emit(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t n, Queues q, int first_chunk) {
+// Lines of sight on their own, for a solve without reflection candidates (otherwise k_reflect queues them).
+__global__ void k_los_emit(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t n, Queues q) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        q.counters[0] = (unsigned long long)n;
-        q.counters[1] = (unsigned long long)n;
-        if (first_chunk) {
-            q.counters[2] = 0;
-            q.counters[3] = 0;
-        }
-    }
-    if (i >= n) return;
-    PathRec &rec = q.paths[i];
-    rec.rx = (int32_t)(rx0 + i);
-    rec.group = -1;
-    rec.cand = 0;
-    rec.nseg = 1;
-    rec.seg0 = i;
-    rec.seg_stride = 1;
-    clear_hits(q, i, i, 1, 1);
-    for (int k = 0; k < RT_MAX_ORDER * 3; ++k) rec.pts[k] = 0.0;
-    st3(q.segs + 6 * i, tx);
-    st3(q.segs + 6 * i + 3, ld3(rx + 3 * (rx0 + i)));
+    if (i < n) los_emit_one(tx, rx, rx0, i, q);
 }
 
 struct OutArrays {
@@ -936,18 +936,20 @@ struct OutArrays {
     unsigned long long *count;
 };
 
-// Keeps the queued paths none of whose segments is obstructed.  counters[0], counters[1] = paths and segments the
-// producers asked for; when either exceeds its queue the records are incomplete and nothing is done (the host redoes
+// Keeps the queued paths none of whose segments is obstructed.  base + counters[0], base + counters[1] = paths and
+// segments the producers asked for; when either exceeds its queue the records are incomplete and nothing is done (the host redoes
 // the chunk with larger queues).  hit holds one flag per segment, or (per_path) one per path.  A wave looks at 512
 // paths and reserves the room of its survivors with one atomic.
 // FINALIZE_ITEMS = 8 paths per lane for large batches (few atomics), 1 for small ones (more waves, shorter chains).
-// The block that finishes last copies counters[0..2] to host_counters (host memory the device can write), so the host
-// needs no copy after the launch, and clears the count of finished blocks (counters[3]) for the next launch.
+// The block that finishes last copies the counts to host_counters (host memory the device can write), so the host
+// needs no copy after the launch, and leaves the queue counters and the count of finished blocks (counters[3]) at
+// zero for the next launch (the result counter too after a solve's last chunk): a solve starts without a memset.
 template <int FINALIZE_ITEMS>
 __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ paths, const uint8_t *__restrict__ hit,
-                                                   unsigned long long *counters, int64_t path_cap, int64_t seg_cap,
-                                                   int per_path, OutArrays out, unsigned long long *host_counters) {
-    const unsigned long long np = counters[0], ns = counters[1];
+                                                   unsigned long long *counters, int64_t base, int64_t path_cap,
+                                                   int64_t seg_cap, int per_path, OutArrays out,
+                                                   unsigned long long *host_counters, int last_chunk) {
+    const unsigned long long np = counters[0] + (unsigned long long)base, ns = counters[1] + (unsigned long long)base;
     const bool fits = np <= (unsigned long long)path_cap && ns <= (unsigned long long)seg_cap;
     const int64_t n = fits ? (int64_t)np : 0;
     const int lane = threadIdx.x & 63;
@@ -1001,7 +1003,10 @@ __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ pa
             host_counters[0] = np;
             host_counters[1] = ns;
             host_counters[2] = atomicAdd(&counters[2], 0ull);
+            counters[0] = 0;
+            counters[1] = 0;
             counters[3] = 0;
+            if (fits && last_chunk) counters[2] = 0;
             __threadfence_system();
         }
     }
@@ -1048,7 +1053,8 @@ struct EventTimer {
     }
 };
 
-static void launch_reflect(rt_scene *s, const rt_candidates *cand, d3 tx, const double *rx, int64_t rx0, int64_t rx1,
+// false when there is no reflection candidate (nothing launched: the caller queues the lines of sight itself)
+static bool launch_reflect(rt_scene *s, const rt_candidates *cand, d3 tx, const double *rx, int64_t rx0, int64_t rx1,
                            int rx_tile, const Queues &q) {
     const int mo = cand->max_order;
     ReflectGroups g{};
@@ -1064,7 +1070,7 @@ static void launch_reflect(rt_scene *s, const rt_candidates *cand, d3 tx, const 
         }
     }
     g.first_block[RT_MAX_ORDER] = blocks;
-    if (blocks == 0) return;
+    if (blocks == 0) return false;
     dim3 grid(blocks, blocks_for(rx1 - rx0, rx_tile));
     switch (top) {
         case 1: hipLaunchKernelGGL(k_reflect<1>, grid, dim3(256), 0, s->stream, s->view, g, tx, rx, rx0, rx1, rx_tile, q); break;
@@ -1072,6 +1078,7 @@ static void launch_reflect(rt_scene *s, const rt_candidates *cand, d3 tx, const 
         case 3: hipLaunchKernelGGL(k_reflect<3>, grid, dim3(256), 0, s->stream, s->view, g, tx, rx, rx0, rx1, rx_tile, q); break;
         default: hipLaunchKernelGGL(k_reflect<4>, grid, dim3(256), 0, s->stream, s->view, g, tx, rx, rx0, rx1, rx_tile, q); break;
     }
+    return true;
 }
 
 template <int M>
@@ -1150,6 +1157,8 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     unsigned long long *h_counters = scene->h_counters;
     unsigned long long *h_counters_dev = nullptr;  // the same words as the device addresses them
     SOLVE_HIP(hipHostGetDevicePointer((void **)&h_counters_dev, h_counters, 0));
+    // the final filter of a chunk leaves the queue counters at zero; only a solve that was cut short does not
+    if (scene->counters_dirty) SOLVE_HIP(hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
     if (on_device) {
         out.rx = out_rx;
         out.group = out_group;
@@ -1204,7 +1213,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_HIP(hipStreamSynchronize(st));
         if (n0 == 0) continue;
         timer.begin(2);
-        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, nullptr, 0, true)) {
+        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, 0, nullptr, 0, true)) {
             free_temps();
             return -1;
         }
@@ -1288,18 +1297,20 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         // Large batches: one obstruction launch per segment place, last segment first, each skipping the paths already
         // blocked (flags per path).  Small batches are launch-bound: one launch over all segments (flags per segment).
         const bool by_rounds = path_hint >= (1 << 15);
-        Queues q{(PathRec *)(w + off_paths), (double *)(w + off_segs), path_cap, seg_cap, d_counters, d_hits, by_rounds ? 1 : 0};
+        Queues q{(PathRec *)(w + off_paths), (double *)(w + off_segs), path_cap, seg_cap, d_counters, nr, d_hits, by_rounds ? 1 : 0};
 
-        // lines of sight: queued like every other path, tested against the polygons the emitter sees only
-        // (ray_tracing.py:232-237); this launch also starts the queue counters
-        timer.begin(3);
-        hipLaunchKernelGGL(k_los_emit, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, q, r0 == 0 ? 1 : 0);
-        timer.end(3);
-
-        // reflections of every order, one launch
+        // Lines of sight: queued like every other path (the first nr records), tested against the polygons the emitter
+        // sees only (ray_tracing.py:232-237).  The reflection launch queues them on the way; reflections of every
+        // order are one launch.
+        scene->counters_dirty = true;
         timer.begin(0);
-        launch_reflect(scene, cand, TX, d_rx, r0, r1, rx_tile, q);
+        const bool los_queued = launch_reflect(scene, cand, TX, d_rx, r0, r1, rx_tile, q);
         timer.end(0);
+        if (!los_queued) {
+            timer.begin(3);
+            hipLaunchKernelGGL(k_los_emit, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, q);
+            timer.end(3);
+        }
         // diffractions
         if (any_diffraction) {
             timer.begin(1);
@@ -1323,11 +1334,11 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
                 if (cand->groups[k - 1].count > 0) max_nseg = std::max(max_nseg, k + 1);
             if (any_diffraction) max_nseg = std::max(max_nseg, 2);
             for (int round = 0; round < max_nseg; ++round)
-                if (rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters, path_hint, q.paths, round, false)) {
+                if (rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters, nr, path_hint, q.paths, round, false)) {
                     free_temps();
                     return -1;
                 }
-        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, seg_hint, nullptr, 0, false)) {
+        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, nr, seg_hint, nullptr, 0, false)) {
             free_temps();
             return -1;
         }
@@ -1335,10 +1346,12 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         timer.begin(3);
         if (path_hint >= (1 << 16))
             hipLaunchKernelGGL(k_finalize<8>, dim3(std::min<unsigned>(blocks_for(path_hint, 256 * 8), 4096u)), dim3(256), 0, st,
-                               q.paths, d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out, h_counters_dev);
+                               q.paths, d_hits, d_counters, nr, path_cap, seg_cap, by_rounds ? 1 : 0, out, h_counters_dev,
+                               r1 == n_rx ? 1 : 0);
         else
             hipLaunchKernelGGL(k_finalize<1>, dim3(blocks_for(path_hint + path_hint / 4 + 256, 256)), dim3(256), 0, st, q.paths,
-                               d_hits, d_counters, path_cap, seg_cap, by_rounds ? 1 : 0, out, h_counters_dev);
+                               d_hits, d_counters, nr, path_cap, seg_cap, by_rounds ? 1 : 0, out, h_counters_dev,
+                               r1 == n_rx ? 1 : 0);
         timer.end(3);
         SOLVE_HIP(hipStreamSynchronize(st));  // the filter's last block has written h_counters
         SOLVE_HIP(hipGetLastError());
@@ -1350,6 +1363,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
             continue;
         }
         found_before = h_counters[2];
+        scene->counters_dirty = false;
         scene->hint_paths = std::max<int64_t>(n_paths, 1);
         scene->hint_segments = std::max<int64_t>(n_segs, 1);
         scene->last_segments += n_segs;
