@@ -75,19 +75,28 @@ __device__ inline bool polygon_cuts_segment_lds(const double *ring, int nv, d3 n
     bool inside = false, boundary = false;
     const d3 Pl = ld3(ring + 3 * (nv - 1));
     double ax = dot(Pl, fx), ay = dot(Pl, fy);
-    for (int k = 0; k < nv; ++k) {
-        const d3 P = ld3(ring + 3 * k);
-        const double z = dot(P, fz);
-        zlo = fmin(zlo, z);
-        zhi = fmax(zhi, z);
-        const double bx = dot(P, fx), by = dot(P, fy);
-        const double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-        if (cr == 0.0 && fmin(ax, bx) <= px && px <= fmax(ax, bx) && fmin(ay, by) <= py && py <= fmax(ay, by)) boundary = true;
-        if ((ay > py) != (by > py)) {
-            if ((cr > 0.0) == (by > ay)) inside = !inside;
+    for (int k0 = 0; k0 < nv; k0 += 4) {
+        d3 Ps[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ps[j] = ld3(ring + 3 * (k0 + j < nv ? k0 + j : nv - 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k0 + j < nv) {
+                const d3 P = Ps[j];
+                const double z = dot(P, fz);
+                zlo = fmin(zlo, z);
+                zhi = fmax(zhi, z);
+                const double bx = dot(P, fx), by = dot(P, fy);
+                const double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+                if (cr == 0.0 && fmin(ax, bx) <= px && px <= fmax(ax, bx) && fmin(ay, by) <= py && py <= fmax(ay, by))
+                    boundary = true;
+                if ((ay > py) != (by > py)) {
+                    if ((cr > 0.0) == (by > ay)) inside = !inside;
+                }
+                ax = bx;
+                ay = by;
+            }
         }
-        ax = bx;
-        ay = by;
     }
     if (!(zhi > z_min && zlo < z_max)) return false;
     if (!(boundary || inside)) return false;
