@@ -179,6 +179,22 @@ int rt_fields(rt_scene *scene, const double *tx, const double *rx, int64_t n_rx,
               double *out_power, double *out_angles, double *out_time, int32_t *out_status, double *out_power_db,
               int on_device);
 
+
+/* ---- channel statistics of the result table (electromagnetism_fun/electromagnetism_plots.py:287-460) -----------------
+ * Per receiver g, over its paths [group_off[g], group_off[g+1]) (rows of the table in their order, receivers without
+ * a path have an empty range): compute_RMS_delay_spreads (:389-400), compute_RMS_angular_spreads (:403-431),
+ * compute_percent_coming_from_n_rays (:445-460, n = n_strongest) and compute_angular_windows (:287-387,
+ * POWER_PERCENT = power_percent, including the way the reference picks the bundle's centre and reads the two angles).
+ * Per path: power [W], time [s], arrival elevation / azimuth [deg] (the table's rx_angles), xyz[3] = the point
+ * (sin el cos az, sin el sin az, cos el) as the reference forms it, is_los (path_type == "LOS").
+ * out[g*8 + ..]: 0 RMS delay spread [s], 1 RMS azimuth spread, 2 RMS elevation spread [deg], 3 share of the
+ * n_strongest strongest rays [%], 4 1.0 if the receiver has a line of sight (the reference reports the share for those
+ * only), 5 window azimuth, 6 window elevation [deg] (NaN where the reference fails: a bundle of one ray), 7 number of
+ * paths.  Receivers without a path get NaN in 0-6.  All pointers host, or all device with on_device. */
+int rt_channel_stats(int device, int64_t n_groups, const int64_t *group_off, const double *power, const double *time,
+                     const double *el_deg, const double *az_deg, const double *xyz, const uint8_t *is_los,
+                     int32_t n_strongest, double power_percent, double *out, int on_device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ _SIGNATURES = {
                                c_int64, c_void_p, c_void_p, c_int]),
     "rt_solve_last_timing": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "rt_describe_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "rt_channel_stats": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int32, c_double, c_void_p, c_int]),
     "rt_fields": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_int]),
@@ -414,3 +416,24 @@ def solve_reflections_and_diffraction(origin, destinations, planes, edge, device
                                                 _ptr(dests), len(dests), _ptr(planes) if k else None, k, _ptr(edge),
                                                 _ptr(out), _ptr(ok)), "rt_solve_reflections_diffraction")
     return out, ok.astype(bool)
+
+
+def channel_stats(group_off, power, time, el_deg, az_deg, xyz, is_los, n_strongest=1, power_percent=0.99, device=None):
+    """Per-receiver channel statistics of a result table whose rows are grouped by receiver (see rt_channel_stats):
+    returns an (n_groups, 8) array [delay, rms_az, rms_el, percent, has_los, win_az, win_el, n_paths]."""
+    lib = require_gpu()
+    off = np.ascontiguousarray(group_off, dtype=np.int64)
+    n_groups = len(off) - 1
+    n = int(off[-1]) if n_groups >= 0 else 0
+    arrays = [_f64(power).reshape(-1), _f64(time).reshape(-1), _f64(el_deg).reshape(-1), _f64(az_deg).reshape(-1),
+              _f64(xyz).reshape(-1, 3)]
+    los = np.ascontiguousarray(is_los, dtype=np.uint8).reshape(-1)
+    if any(len(a) != n for a in arrays) or len(los) != n:
+        raise ValueError("channel_stats: the per-path arrays must have group_off[-1] entries")
+    out = np.zeros((max(n_groups, 0), 8), dtype=np.float64)
+    if n_groups > 0:
+        ptrs = [_ptr(a) if n else None for a in arrays]
+        _check(lib.rt_channel_stats(default_device() if device is None else device, n_groups, _ptr(off), *ptrs,
+                                    _ptr(los) if n else None, int(n_strongest), float(power_percent), _ptr(out), 0),
+               "rt_channel_stats")
+    return out
