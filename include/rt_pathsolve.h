@@ -165,9 +165,14 @@ typedef struct rt_antenna_params {
  *   aim_tx / aim_rx [n_rx*3]  points the two antennas are aimed at, per receiver (both or neither)
  *   path_origin [n_paths*3]   first point of each path instead of tx
  *   path_e_in   [n_paths*6]   complex field (re, im interleaved) arriving at the first interaction instead of the source
- *                             field of the emitter's antenna */
+ *                             field of the emitter's antenna
+ *   n_late_polygons           the scene's last n_late_polygons polygons were added after the paths were found: the
+ *                             crowns my_field_computation puts on the tree trunks (em:745, geometry.py:2789-2802).
+ *                             Every segment of every path is attenuated by the crowns it crosses (em:179-199 called at
+ *                             em:338, 348, 506, 725); a line of sight by whatever it crosses, as before. */
 typedef struct rt_field_options {
     const double *aim_tx, *aim_rx, *path_origin, *path_e_in;
+    int32_t n_late_polygons;
 } rt_field_options;
 int rt_describe_paths(rt_candidates *cand, const int32_t *path_group, const int32_t *path_cand, int64_t n_paths,
                       int32_t *out_kind, int32_t *out_chain, int32_t *out_edge_polys, double *out_edge_points,

@@ -201,10 +201,12 @@ class FieldOracle:
             the_path = reflections_path[ind:ind + 3]
             _, Si, _, Sr = self._normalize_path(the_path)
             R = self.dyadic_ref_coeff(the_path, self.polys[surf_id])
+            E_r = self.account_for_trees(E_r, np.array([the_path[0], the_path[1]]))  # electromagnetism.py:338
             field = (E_r.reshape(1, 3) @ R) * np.exp(-1j * self.K * Sr) * (Si / (Si + Sr))
             E_r = field.reshape(3,)
             assert np.linalg.norm(E_i) >= np.linalg.norm(field), "reflected field should be less powerful"
-        return E_r
+        last = reflections_path[len(surfaces_ids) - 1:len(surfaces_ids) + 2]
+        return self.account_for_trees(E_r, np.array([last[1], last[2]]))  # electromagnetism.py:346-348
 
     # ---- electromagnetism.py:353-507 ---------------------------------------------------------------
     @staticmethod
@@ -276,7 +278,7 @@ class FieldOracle:
             phi_i_vv.reshape(3, 1) @ phi_d_vv.reshape(1, 3) * D_par
         field = (E_i.reshape(1, 3) @ D) * np.sqrt(Si / (Sd * (Sd + Si))) * np.exp(-1j * self.K * Sd)
         assert np.linalg.norm(E_i) >= np.linalg.norm(field), "diffracted field should be less powerful"
-        return field.reshape(3,)
+        return self.account_for_trees(field.reshape(3,), np.array([diff_path[1], diff_path[2]]))  # :506
 
     # ---- electromagnetism.py:610-644 ---------------------------------------------------------------
     @staticmethod
@@ -325,7 +327,10 @@ class FieldOracle:
             for order in rt.diffractions[receiver]:
                 for the_path, ids, diff_ids, corner_points in rt.diffractions[receiver][order]:
                     E_0 = self.from_path([tx, the_path[1]], tx_antenna)
-                    E_i = E_0 if len(the_path) == 3 else self.my_reflect(E_0, the_path[0:-1], ids)
+                    if len(the_path) == 3:  # electromagnetism.py:724-725
+                        E_i = self.account_for_trees(E_0, np.array([the_path[0], the_path[1]]))
+                    else:
+                        E_i = self.my_reflect(E_0, the_path[0:-1], ids)
                     E = self.my_diff(E_i, the_path[-3:], diff_ids, corner_points)
                     sols.append(("R" * (order - 1) + "D", the_path, E))
             for path_type, path, field in sols:

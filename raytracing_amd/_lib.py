@@ -20,7 +20,8 @@ class RtError(RuntimeError):
 
 
 class FieldOptions(ctypes.Structure):
-    _fields_ = [("aim_tx", c_void_p), ("aim_rx", c_void_p), ("path_origin", c_void_p), ("path_e_in", c_void_p)]
+    _fields_ = [("aim_tx", c_void_p), ("aim_rx", c_void_p), ("path_origin", c_void_p), ("path_e_in", c_void_p),
+                ("n_late_polygons", c_int32)]
 
 
 class AntennaParams(ctypes.Structure):
@@ -328,9 +329,10 @@ class Scene:
 
     def fields(self, tx, rx, path_rx, path_kind, path_chain, path_edge_polys, path_edge_points, path_points,
                frequencies, tx_gain=1.0, rx_gain=1.0, p_in=1.0, isotropic=True, alpha=10, aim_tx=None, aim_rx=None,
-               path_origin=None, path_e_in=None):
+               path_origin=None, path_e_in=None, n_late_polygons=0):
         """Host-array form of ``rt_fields``; returns dict(field complex [P,F,3], power [P,F], angles [P,4], time [P],
-        status [P], power_db [R,F])."""
+        status [P], power_db [R,F]).  ``n_late_polygons``: the scene's last polygons that were added after the paths
+        were found (tree crowns): every segment is attenuated by the ones it crosses."""
         tx = _f64(tx).reshape(3)
         rx = _f64(rx).reshape(-1, 3)
         p_rx = np.ascontiguousarray(path_rx, dtype=np.int32)
@@ -351,7 +353,7 @@ class Scene:
         power_db = np.zeros((len(rx), nf), dtype=np.float64)
         keep = []
         opts = None
-        if any(a is not None for a in (aim_tx, aim_rx, path_origin, path_e_in)):
+        if any(a is not None for a in (aim_tx, aim_rx, path_origin, path_e_in)) or n_late_polygons:
             def dev(a, shape):
                 if a is None:
                     return None
@@ -363,7 +365,7 @@ class Scene:
                 e = np.asarray(path_e_in, dtype=np.complex128).reshape(n, 3)
                 e_in = np.stack([e.real, e.imag], axis=-1).reshape(n, 6)
             opts = FieldOptions(dev(aim_tx, (len(rx), 3)), dev(aim_rx, (len(rx), 3)), dev(path_origin, (n, 3)),
-                                dev(e_in, (n, 6)))
+                                dev(e_in, (n, 6)), int(n_late_polygons))
         _check(load().rt_fields(self.handle, _ptr(tx), _ptr(rx), len(rx), _ptr(p_rx), _ptr(p_kind), _ptr(p_chain),
                                 _ptr(p_ep), _ptr(p_epts), _ptr(p_pts), n, _ptr(freqs), nf, ctypes.byref(ap),
                                 ctypes.byref(opts) if opts is not None else None, _ptr(field), _ptr(power), _ptr(angles), _ptr(time), _ptr(status), _ptr(power_db), 0),

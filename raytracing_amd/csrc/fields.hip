@@ -36,6 +36,7 @@ struct PathArrays {
     const double *e_in;         // [n * 6] field arriving at the first interaction instead of the emitter's own field
     const double *aim_tx;       // [n_rx * 3] point the emitter's antenna is aimed at, per receiver
     const double *aim_rx;       // [n_rx * 3] point the receiver's antenna is aimed at
+    int n_late;                 // the scene's last n_late polygons were added after the paths were found (tree crowns)
 };
 
 enum FieldStatus {
@@ -323,9 +324,12 @@ __global__ void k_best_index(PathArrays pa, d3 tx, const double *__restrict__ rx
         atomicMin(&best_idx[pa.rx[i]], (unsigned long long)i);
 }
 
-// Loss the reference applies to a line of sight that crosses geometry the emitter-visibility mask did not contain:
-// whatever it crosses is treated as tree crowns (electromagnetism.py:179-199, geometry.py:868-921).
-__device__ inline double los_tree_factor(const SceneView &sc, d3 A, d3 B, double freq, int &status) {
+// Loss the reference applies to a segment that crosses geometry: whatever it crosses is treated as tree crowns
+// (electromagnetism.py:179-199, geometry.py:868-921).  Polygons p_begin.. are looked at: all of them for a line of
+// sight (it was only checked against the polygons the emitter sees), and for the other segments the polygons added
+// after the paths were found (the crowns put on the trunks, electromagnetism.py:745) — the solve has already found
+// those segments clear of every other polygon with the same test.
+__device__ inline double tree_factor(const SceneView &sc, d3 A, d3 B, double freq, int &status, int p_begin) {
     double factor = 1.0;
     int first = -1, second = -1, count = 0;
     auto flush = [&]() {
@@ -352,7 +356,7 @@ __device__ inline double los_tree_factor(const SceneView &sc, d3 A, d3 B, double
     };
     const d3 V = B - A;
     const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
-    for (int p = 0; p < sc.n; ++p) {
+    for (int p = p_begin; p < sc.n; ++p) {
         // the cheap conservative test first; the exact one only for the few polygons it lets through
         if (!occ_pretest(sc.poly_recs + p, sc, A, V, pad) || !polygon_cuts_segment(sc, p, A, B)) continue;
         if (count == 0) {
@@ -436,18 +440,25 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
             E = source_field(txa, P[1], K, ap, st);
         }
         const double e0 = cnorm3(E);
-        if (kind == 0 && !pa.e_in) {
-            const double fac = los_tree_factor(sc, P[0], P[1], ft.freq[f], st);
+        const int late_begin = sc.n - pa.n_late;
+        auto through_trees = [&](d3 A, d3 B, int p_begin) {
+            if (p_begin >= sc.n) return;
+            const double fac = tree_factor(sc, A, B, ft.freq[f], st, p_begin);
             E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
-        }
+        };
+        if (kind == 0 && !pa.e_in) through_trees(P[0], P[1], 0);  // electromagnetism.py:669
         for (int k = 0; k < n_refl; ++k) {
+            through_trees(P[k], P[k + 1], late_begin);  // :338
             E = reflect_field(sc, E, P[k], P[k + 1], P[k + 2], chain[k], ft, f, st);
             if (!(e0 >= cnorm3(E)) && st == ST_OK) st = ST_REFLECTED_GAIN;  // electromagnetism.py:342 (E_i is the first field)
         }
+        if (n_refl > 0) through_trees(P[n_refl], P[n_refl + 1], late_begin);  // :346-348
         if (has_edge) {
+            if (n_refl == 0 && !pa.e_in) through_trees(P[0], P[1], late_begin);  // :724-725
             const d3 c0 = ld3(pa.edge_pts + 6 * (size_t)i), c1 = ld3(pa.edge_pts + 6 * (size_t)i + 3);
             E = diffract_field(sc, E, P[np - 3], P[np - 2], P[np - 1], pa.edge_polys[2 * i], pa.edge_polys[2 * i + 1], c0,
                                c1, K, st);
+            through_trees(P[np - 2], P[np - 1], late_begin);  // :506
         }
         // received power (electromagnetism.py:779-787)
         const double Ae = (ft.lambda[f] * ft.lambda[f] / (4 * M_PI)) * ap.rx_gain * radiation_pattern(rx_el, ap);
@@ -734,6 +745,12 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         pa.e_in = opt_dev[1];
         pa.aim_tx = opt_dev[2];
         pa.aim_rx = opt_dev[3];
+        if (options->n_late_polygons < 0 || options->n_late_polygons > scene->view.n) {
+            rt_set_error("rt_fields: n_late_polygons outside the scene");
+            cleanup();
+            return -1;
+        }
+        pa.n_late = options->n_late_polygons;
     }
     fo.power_sum = (double *)dalloc(sizeof(double) * n_rx * nf);
     unsigned long long *best_len = (unsigned long long *)dalloc(sizeof(unsigned long long) * n_rx);

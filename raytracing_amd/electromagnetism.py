@@ -201,10 +201,14 @@ def my_field_computation(rtp, save_name="problem_fields", frequency=None, save=T
     receivers = np.asarray(rtp.receivers, dtype=float).reshape(-1, 3)
     n_rx = len(rtp.solved_receivers)
     batch, lines = paths_of_problem(rtp)
-    scene = rtp._device_scene()
+    # the crowns come last in the place's polygon order, behind the polygons the problem was solved with
+    all_polygons = rtp.place.get_polygons_list()
+    n_late = len(all_polygons) - len(rtp.polygons)
+    scene = geom.scene_arrays_of(all_polygons).device_scene() if n_late > 0 else rtp._device_scene()
     rows = []
     if len(batch):
-        res = batch.run(scene, tx, receivers, [mat.FREQUENCY if frequency is None else frequency])
+        res = batch.run(scene, tx, receivers, [mat.FREQUENCY if frequency is None else frequency],
+                        n_late_polygons=max(n_late, 0))
         _raise_on_status(res["status"], batch.labels)
     per_rx = {}
     for i, r in enumerate(batch.rx):

@@ -17,6 +17,7 @@ generator, so a scene is a pure function of (file, seed).
 import itertools
 import json
 import math
+import random
 import re
 import uuid
 
@@ -24,7 +25,8 @@ import numpy as np
 
 from . import array_utils
 from . import container_utils
-from .materials_properties import MATERIAL_ID, material_of_building_type, set_properties
+from .materials_properties import (MATERIAL_ID, MAX_TREE_HEIGHT, MIN_TREE_HEIGHT, material_of_building_type,
+                                   set_properties)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -216,6 +218,16 @@ class OrientedPolygon(OrientedGeometry):
         return bool(_lib.polygon_contains_points(self, np.asarray(point, dtype=float).reshape(1, 3),
                                                  check_in_plane, plane_tol)[0])
 
+    def rotate(self, axis, angle_deg):
+        """Rotates the polygon about ``axis`` through its bounding-box centre (reference :1900-1920)."""
+        from scipy.spatial.transform import Rotation
+
+        center = self.get_centroid()
+        matrix = Rotation.from_rotvec(np.radians(angle_deg) * np.asarray(axis, dtype=float)).as_matrix()
+        self.points = np.dot(self.points - center, matrix.T) + center
+        self.parametric = self.matrix = self.domain = self.centroid = None
+        return self
+
     def to_json(self):
         return dict(id=self.id, **self.attributes, geotype="polygon", properties=self.properties,
                     building_id=self.building_id, part=self.part, points=self.points.tolist())
@@ -231,6 +243,41 @@ class OrientedPolygon(OrientedGeometry):
         polygon = cls(np.array(data.pop("points")), **data)
         polygon.part, polygon.properties, polygon.building_id = part, properties, building_id
         return polygon
+
+
+class Square(OrientedPolygon):
+    """Axis-parallel square given by two opposite corners or by centre and side (reference :1942-2002)."""
+
+    @staticmethod
+    def by_2_corner_points(points):
+        P1, P2 = points
+        assert not np.array_equal(P1, P2), "points must be different (P1=P2)"
+        assert P1[1] != P2[1] and P1[0] != P2[0], "points must be diagonally opposite"
+        points = array_utils.sort_by_columns(np.asarray(points, dtype=float))
+        p = np.empty((4, 3), dtype=float)
+        p[0, :] = points[0, :]
+        p[1, :] = [points[0, 0], points[1, 1], points[0, 2]]
+        p[2, :] = points[1, :]
+        p[3, :] = [points[1, 0], points[0, 1], points[1, 2]]
+        return Square(p)
+
+    @staticmethod
+    def by_center_and_side(center, side, rotate=False):
+        """``rotate=True`` turns the square about z by ``random.randint(0, 90)`` degrees, as the reference does
+        (seed Python's ``random`` for a reproducible scene)."""
+        P1 = np.array([center[0] + side / 2, center[1] + side / 2, center[2]])
+        P2 = np.array([center[0] - side / 2, center[1] - side / 2, center[2]])
+        square = Square.by_2_corner_points(np.array([P1, P2]))
+        if rotate:
+            square.rotate(axis=np.array([0, 0, 1]), angle_deg=random.randint(0, 90))
+        return square
+
+    @staticmethod
+    def center(points):
+        (x1, y1, z1), (x2, y2, z2), (x3, y3, z3), (x4, y4, z4) = points[0], points[1], points[2], points[3]
+        mid1 = ((x1 + x2) / 2, (y1 + y2) / 2, (z1 + z2) / 2)
+        mid2 = ((x3 + x4) / 2, (y3 + y4) / 2, (z3 + z4) / 2)
+        return np.array([(mid1[0] + mid2[0]) / 2, (mid1[1] + mid2[1]) / 2, (mid1[2] + mid2[2]) / 2])
 
 
 class OrientedSurface(OrientedGeometry):
@@ -382,6 +429,32 @@ class Building(OrientedPolyhedron):
                                               keep_ground=keep_ground, flat_roof=flat_roof)
 
 
+    @staticmethod
+    def create_tree_trunk(trunk_spot, trunk_size, trunk_height, rotate, crown_size=None, crown_height=None):
+        """Square column of type "tree_trunk" (reference :2475-2486); the crown it will carry is noted in its
+        attributes.  ``trunk_height=None`` draws it with ``random.uniform`` between the tree height bounds."""
+        if trunk_height is None:
+            trunk_height = random.uniform(MIN_TREE_HEIGHT, MAX_TREE_HEIGHT)
+        trunk_top = Square.by_center_and_side(trunk_spot, trunk_size, rotate=rotate).get_points()
+        trunk = Building.by_polygon_and_height(trunk_top, trunk_height, keep_ground=False)
+        trunk.building_type = "tree_trunk"
+        trunk.apply_properties_to_polygons()
+        if crown_size is not None and crown_height is not None:
+            trunk.attributes["crown_size"] = crown_size
+            trunk.attributes["crown_height"] = crown_height
+        return trunk
+
+    @staticmethod
+    def create_tree_crown(tree_trunk, crown_size, crown_height, rotate=False):
+        """Box of type "tree_crown" standing on the trunk's top face (reference :2488-2496)."""
+        center = Square.center(tree_trunk.get_top_face().points)
+        crown_footprint = Square.by_center_and_side(center, crown_size, rotate=rotate)
+        crown = Building.by_polygon_and_height(crown_footprint, crown_height, keep_ground=True)
+        crown.building_type = "tree_crown"
+        crown.apply_properties_to_polygons()
+        return crown
+
+
 class Cube(OrientedPolyhedron):
     """Axis-aligned cube around a point; its 6 faces are the emitter's screens (reference :2502-2531)."""
 
@@ -442,13 +515,27 @@ class OrientedPlace(OrientedGeometry):
     def obstructs_line_path(self, points):
         return polygons_obstruct_line_path(self.get_polygons_list(), points)
 
+    def add_polyhedron(self, polyhedron, allow_overlap=True):
+        """Appends a polyhedron (reference :2742-2748; the overlap check of the reference goes through Shapely and is
+        not made here)."""
+        assert isinstance(polyhedron, OrientedPolyhedron), "given polyhedron is not of type OrientedPolyhedron"
+        self.polyhedra.append(polyhedron)
+        self._scene_arrays = None
+
     def add_tree_crowns(self):
-        """Adds a crown on every tree trunk (reference :2789-2802); scenes built here have no trunks."""
+        """Puts a crown on every tree trunk that carries crown attributes (reference :2789-2802).  Called after the
+        place has been solved, so that rays pass through the crowns and are only attenuated by them.  Returns the
+        number of polygons added (they come last in the polygon order)."""
         crowns = []
         for polyhedron in self.polyhedra:
             if polyhedron.building_type == "tree_trunk":
-                raise NotImplementedError("tree trunks are not part of the scenes this package builds")
+                crowns.append(Building.create_tree_crown(polyhedron, crown_size=polyhedron.attributes["crown_size"],
+                                                         crown_height=polyhedron.attributes["crown_height"],
+                                                         rotate=False))
         self.polyhedra.extend(crowns)
+        if crowns:
+            self._scene_arrays = None
+        return sum(len(c.polygons) for c in crowns)
 
     def to_json(self, filename=None):
         data = dict(id=self.id, **self.attributes, geotype="place", surface=self.surface.to_json(),

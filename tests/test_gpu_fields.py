@@ -199,3 +199,59 @@ def test_levant_fields_match_oracle(tmp_path, monkeypatch):
     got_db = emu.get_power_db_each_receiver(df)
     want_db = eo.power_db_each_receiver(rows, len(rx))
     assert np.abs(got_db - want_db).max() <= DB_TOL
+
+
+def test_tree_crowns_attenuate_every_segment_they_cross(tmp_path, monkeypatch):
+    """Trunks stand in the scene while it is solved; my_field_computation puts the crowns on them afterwards and every
+    segment of every path loses what the crowns it crosses take (electromagnetism.py:179-199 at :338, 348, 506, 669,
+    725).  Oracle: the same on the CPU, scanning every polygon for every segment as the reference does."""
+    import random
+
+    from oracle import em_oracle as eo
+    from oracle import ray_tracing_oracle as ro
+    from raytracing_amd import electromagnetism as em
+    from raytracing_amd import geometry as geom
+    from raytracing_amd.ray_tracing import RayTracingProblem
+
+    monkeypatch.setenv("RAYTRACING_AMD_RESULTS", str(tmp_path))
+    random.seed(11)
+    place = geom.load_place("data/small.geojson")
+    for spot, crown in (((6.0, 5.0, 0.0), (5.0, 6.0)), ((2.0, -12.0, 0.0), (6.0, 5.0)), ((10.0, 14.0, 0.0), (4.0, 7.0))):
+        place.add_polyhedron(geom.Building.create_tree_trunk(np.array(spot), 0.6, 7.0, rotate=True, crown_size=crown[0],
+                                                             crown_height=crown[1]))
+    tx, rx = small_tx_rx(12)
+    place.add_set_of_points(rx)
+    problem = RayTracingProblem(tx.reshape(1, 3), place)
+    problem.solve(max_order=2)
+
+    def with_buildings(polys):
+        ids = {}
+        for p, q in zip(polys, place.get_polygons_list()):
+            p.building = ids.setdefault(q.building_id, len(ids))
+        return polys
+
+    solved_with = with_buildings(oracle_polys(place))
+    oracle = ro.RayTracingOracle(tx, solved_with, rx, visibility_matrix=problem.visibility_matrix, solver="exact")
+    oracle.solve(max_order=2)
+    assert problem.path_set() == oracle.path_set()
+
+    df = em.my_field_computation(problem, "small_trees")
+    assert len(place.get_polygons_list()) == len(solved_with) + 3 * 6  # three crowns: top, bottom, four sides
+    with_crowns = with_buildings(oracle_polys(place))
+    rows = eo.FieldOracle(with_crowns).field_computation(oracle, rx)
+    bare = eo.FieldOracle(with_crowns)
+    bare.account_for_trees = lambda E, points: E
+    rows_bare = bare.field_computation(oracle, rx)
+    assert len(df) == len(rows) == len(rows_bare) > 50
+    assert list(df["path_type"]) == [r["path_type"] for r in rows]
+    attenuated = {}
+    for (_, got), want, plain in zip(df.iterrows(), rows, rows_bare):
+        if want["path_type"] == "Impossible":
+            continue
+        assert abs(db(got["path_power"]) - db(want["path_power"])) <= DB_TOL
+        np.testing.assert_allclose(got["field_strength"], want["field_strength"], rtol=1e-6,
+                                   atol=1e-9 * np.abs(want["field_strength"]).max())
+        if db(plain["path_power"]) - db(want["path_power"]) > 1.0:
+            attenuated[want["path_type"]] = attenuated.get(want["path_type"], 0) + 1
+    # the crowns matter in this scene: lines of sight, reflected and diffracted paths lose more than 1 dB to them
+    assert attenuated.get("LOS", 0) >= 1 and sum(v for k, v in attenuated.items() if k != "LOS") >= 3, attenuated

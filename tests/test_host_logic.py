@@ -213,3 +213,29 @@ def test_array_to_string_is_numpys_encoding():
         cases.append(a)
     for a in cases:
         assert array_to_string(a) == numpy_way(a), repr(a)
+
+
+def test_tree_builders_reproduce_reference_vectors():
+    """Square, rotate, create_tree_trunk and create_tree_crown against tests/golden/trees.npz (the reference's own
+    builders, Python's random seeded the same way)."""
+    import random
+
+    from raytracing_amd import geometry as geom
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "trees.npz"))
+    for k in range(3):
+        a = g[f"case{k}_args"]
+        spot, size, height, rotate, crown_size, crown_height, seed = a[:3], a[3], a[4], bool(a[5]), a[6], a[7], int(a[8])
+        random.seed(seed)
+        trunk = geom.Building.create_tree_trunk(spot, size, None if height < 0 else height, rotate, crown_size=crown_size,
+                                                crown_height=crown_height)
+        crown = geom.Building.create_tree_crown(trunk, crown_size, crown_height, rotate=False)
+        np.testing.assert_array_equal(np.array([p.points for p in trunk.polygons]), g[f"case{k}_trunk"])
+        np.testing.assert_array_equal(np.array([p.points for p in crown.polygons]), g[f"case{k}_crown"])
+        np.testing.assert_array_equal(np.array([p.get_parametric() for p in trunk.polygons]), g[f"case{k}_trunk_planes"])
+        np.testing.assert_array_equal(np.array([p.get_parametric() for p in crown.polygons]), g[f"case{k}_crown_planes"])
+        assert [trunk.polygons[0].properties["material"], crown.polygons[0].properties["material"]] == list(g[f"case{k}_materials"])
+        assert trunk.building_type == "tree_trunk" and crown.building_type == "tree_crown"
+    sq = geom.Square.by_2_corner_points(np.array([[3.0, 4.0, 1.0], [-1.0, -2.0, 1.0]]))
+    np.testing.assert_array_equal(sq.points, g["square_points"])
+    np.testing.assert_array_equal(geom.Square.center(sq.points), g["square_center"])
