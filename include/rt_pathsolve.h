@@ -72,6 +72,10 @@ int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, 
  * default, picks by scene size.  Both give the same flags; the switch exists so that tests can check one against the
  * other (no reference counterpart). */
 int rt_debug_set_occlusion_mode(rt_scene *scene, int mode);
+/* The reflection kernel meets the receivers one by one (mode 1) or sorted into spatial tiles, rejecting whole tiles
+ * with an interval form of its pre-test (mode 2); mode 0, the default, picks by batch size.  Same paths either way;
+ * the switch exists so that tests can check one against the other (no reference counterpart). */
+int rt_debug_set_reflect_mode(rt_scene *scene, int mode);
 /* First size of the solve's path queue in records (0 = chosen from the batch).  A queue that turns out too small is
  * grown and the chunk redone; the switch exists so that tests can take that route (no reference counterpart). */
 int rt_debug_set_path_queue_capacity(rt_scene *scene, int64_t n_paths);

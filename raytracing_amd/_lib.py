@@ -44,6 +44,7 @@ _SIGNATURES = {
     "rt_debug_visibility_stats": (c_int, [c_void_p]),
     "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
     "rt_scene_set_timing": (c_int, [c_void_p, c_int]),
+    "rt_debug_set_reflect_mode": (c_int, [c_void_p, c_int]),
     "rt_debug_set_path_queue_capacity": (c_int, [c_void_p, c_int64]),
     "rt_visibility_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "rt_sharp_edges": (c_int, [c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -241,6 +242,10 @@ class Scene:
     def set_occlusion_mode(self, mode):
         """0: obstruction kernel chosen by scene size (default); 1: every-polygon walk; 2: grid walk."""
         _check(load().rt_debug_set_occlusion_mode(self.handle, int(mode)), "rt_debug_set_occlusion_mode")
+
+    def set_reflect_mode(self, mode):
+        """0: reflection kernel chosen by batch size (default); 1: receivers one by one; 2: receivers in spatial tiles."""
+        _check(load().rt_debug_set_reflect_mode(self.handle, int(mode)), "rt_debug_set_reflect_mode")
 
     def set_timing(self, on):
         """Per-kernel-family timing of the solves on (default) or off; ``last_timing`` reports zeros while off."""

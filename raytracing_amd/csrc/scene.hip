@@ -196,6 +196,12 @@ extern "C" int rt_debug_set_occlusion_mode(rt_scene *s, int mode) {
     return 0;
 }
 
+extern "C" int rt_debug_set_reflect_mode(rt_scene *s, int mode) {
+    if (!s || mode < 0 || mode > 2) RT_FAIL("rt_debug_set_reflect_mode: bad argument");
+    s->reflect_mode = mode;
+    return 0;
+}
+
 extern "C" int rt_scene_set_timing(rt_scene *s, int on) {
     if (!s) RT_FAIL("rt_scene_set_timing: null scene");
     s->timing = on != 0;

@@ -673,6 +673,188 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
                          sh.base[1] + (int64_t)(before + lane) * (K + 1));
 }
 
+// ---- large batches: receivers in spatial tiles, whole tiles rejected at once -------------------------------------
+// A reflection candidate reaches only the receivers inside the pyramid from its image of the emitter through its last
+// polygon, a sliver of a coverage map.  The receivers are therefore sorted into spatial tiles of RX_TILE (cells of a
+// uniform grid in Morton order, RX_TILE consecutive receivers per tile, each tile with its box), and a lane first
+// tests its candidate against a tile's box with interval arithmetic: the pre-test of the one-by-one loop evaluated for
+// every receiver position in the box at once, widened so that it can only err towards keeping the tile.  (candidate,
+// tile) pairs that survive are parked and expanded 64 at a time into the per-receiver pre-test; its survivors go to
+// the exact solve as before.
+#define RX_TILE 16
+struct RxTiles {
+    const double *rxs;     // receiver positions in tile order
+    const int32_t *perm;   // perm[k] = index of sorted receiver k in the caller's array
+    const double *boxes;   // [n_tiles * 6] centre and half extent of each tile's box
+};
+
+struct ReflectTiledShared {
+    uint32_t tile_queue[4][128];   // candidate lane << 16 | tile within the block's range
+    uint32_t wave_queue[4][128];   // candidate lane << 26 | receiver within the chunk (sorted order)
+    uint32_t survivors[4][128];    // same encoding
+    double cand[4][64][13];        // per candidate lane: image, plane normal, g, box of the last polygon
+    int n_survivors[4];
+    long long base[2];
+};
+
+template <int K>
+__device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const int32_t *__restrict__ chains, int64_t count,
+                                                    int group, d3 tx, const RxTiles &rt, int64_t r0, int64_t r1,
+                                                    int tiles_per_block, const Queues &q, unsigned block_x,
+                                                    ReflectTiledShared &sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c_base = (int64_t)block_x * blockDim.x + wave * 64;
+    const int64_t c = c_base + lane;
+    const bool active = c < count;
+    d3 prev = tx, nk = mk3(0, 0, 1);
+    double gk = 0;
+    int32_t last = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        last = active ? chains[c * K + i] : 0;
+        const double *pl = sc.planes + 4 * (size_t)last;
+        nk = ld3(pl);
+        const double s = pl[3] + dot(prev, nk);
+        prev = prev - (2.0 * s) * nk;
+        gk = -s;
+    }
+    const d3 im = prev;
+    const double *bb = sc.bbox + 6 * (size_t)last;
+    const double b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
+    {
+        double *cd = sh.cand[wave][lane];
+        cd[0] = im.x; cd[1] = im.y; cd[2] = im.z; cd[3] = nk.x; cd[4] = nk.y; cd[5] = nk.z; cd[6] = gk;
+        cd[7] = b0; cd[8] = b1; cd[9] = b2; cd[10] = b3; cd[11] = b4; cd[12] = b5;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int64_t tile0 = r0 / RX_TILE + (int64_t)blockIdx.y * tiles_per_block;  // r0 is a multiple of RX_TILE
+    const int64_t tile_end_all = (r1 + RX_TILE - 1) / RX_TILE;
+    const int64_t tile1 = tile0 + tiles_per_block < tile_end_all ? tile0 + tiles_per_block : tile_end_all;
+    int tn = 0, qn = 0, sn = 0;  // wave-uniform
+    uint32_t *tq = sh.tile_queue[wave], *wq = sh.wave_queue[wave], *ws = sh.survivors[wave];
+
+    auto solve_batch = [&](bool has, uint32_t e) {
+        bool ok = false;
+        if (has) {
+            d3 X[K];
+            ok = reflect_exact<K>(sc, chains, c_base + (e >> 26), tx, ld3(rt.rxs + 3 * (r0 + (e & 0x3ffffffu))), X);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m == 0) return;
+        if (ok) ws[sn + __popcll(m & ((1ull << lane) - 1))] = e;
+        sn += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (sn >= 64) {
+            sn -= 64;
+            int64_t ps, ss;
+            if (reserve(q, K + 1, ps, ss)) {
+                const uint32_t w = ws[sn + lane];
+                const int64_t rr = r0 + (w & 0x3ffffffu);
+                const d3 R = ld3(rt.rxs + 3 * rr);
+                d3 X[K];
+                (void)reflect_exact<K>(sc, chains, c_base + (w >> 26), tx, R, X);
+                reflect_emit<K>(q, ps, ss, group, c_base + (w >> 26), rt.perm[rr], tx, R, X);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    // the receivers of the tile of every lane that has a (candidate, tile) entry, one by one
+    auto expand_tiles = [&](bool has, uint32_t e) {
+        const double *cd = sh.cand[wave][has ? (e >> 16) : 0];
+        const d3 eim = mk3(cd[0], cd[1], cd[2]), enk = mk3(cd[3], cd[4], cd[5]);
+        const double eg = cd[6], e0 = cd[7], e1 = cd[8], e2 = cd[9], e3 = cd[10], e4 = cd[11], e5 = cd[12];
+        const int64_t rb = (tile0 + (e & 0xffffu)) * RX_TILE;
+        for (int j = 0; j < RX_TILE; ++j) {
+            const int64_t r = rb + j;
+            bool pass = false;
+            if (has && r < r1) {
+                const d3 R = ld3(rt.rxs + 3 * r);
+                const d3 dir = R - eim;
+                const double t = -eg * fast_rcp_s(dot(dir, enk));
+                const double pad = 1e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 1e-6;
+                const double hx = eim.x + t * dir.x, hy = eim.y + t * dir.y, hz = eim.z + t * dir.z;
+                pass = t > -1e-6 && t < 1.0 + 1e-6 && hx >= e0 - pad && hx <= e3 + pad && hy >= e1 - pad &&
+                       hy <= e4 + pad && hz >= e2 - pad && hz <= e5 + pad;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (m == 0) continue;
+            if (pass) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((e >> 16) << 26) | (uint32_t)(r - r0);
+            qn += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= 64) {
+                qn -= 64;
+                solve_batch(true, wq[qn + lane]);
+            }
+        }
+    };
+
+    for (int64_t t = tile0; t < tile1; ++t) {
+        const double *bx = rt.boxes + 6 * t;  // wave-uniform
+        const double cx = bx[0], cy = bx[1], cz = bx[2], ex = bx[3], ey = bx[4], ez = bx[5];
+        // every receiver position R = centre + d, |d| <= half extent:  D = (R - im).n in Dc +- Dr
+        const double ux = cx - im.x, uy = cy - im.y, uz = cz - im.z;
+        const double Dc = ux * nk.x + uy * nk.y + uz * nk.z;
+        const double Dr = (ex * fabs(nk.x) + ey * fabs(nk.y) + ez * fabs(nk.z)) * (1.0 + 1e-9) + 1e-9 * (fabs(Dc) + 1.0);
+        bool keep = active;
+        if (keep && fabs(Dc) > Dr) {
+            // t = -g / D over the box (D keeps its sign), cut to the pre-test's range
+            const double ta = -gk / (Dc - Dr), tb = -gk / (Dc + Dr);
+            double tlo = fmin(ta, tb), thi = fmax(ta, tb);
+            const double tw = 1e-9 * (fabs(tlo) + fabs(thi)) + 1e-12;
+            tlo = fmax(tlo - tw, -1e-6);
+            thi = fmin(thi + tw, 1.0 + 1e-6);
+            if (tlo > thi) {
+                keep = false;
+            } else {
+                const double pad = 1e-5 * fmax(fabs(ux) + ex, fmax(fabs(uy) + ey, fabs(uz) + ez)) + 2e-6;
+                // hit coordinate im + t u over t in [tlo, thi], u in [uc - e, uc + e]: the extremes are at corners
+                auto outside = [&](double imc, double uc, double e, double lo, double hi) {
+                    const double u0 = uc - e, u1 = uc + e;
+                    const double p0 = tlo * u0, p1 = tlo * u1, p2 = thi * u0, p3 = thi * u1;
+                    const double hmin = imc + fmin(fmin(p0, p1), fmin(p2, p3)), hmax = imc + fmax(fmax(p0, p1), fmax(p2, p3));
+                    const double w = 1e-9 * (fabs(imc) + fabs(hmin) + fabs(hmax)) + pad;
+                    return hmax + w < lo || hmin - w > hi;
+                };
+                if (outside(im.x, ux, ex, b0, b3) || outside(im.y, uy, ey, b1, b4) || outside(im.z, uz, ez, b2, b5)) keep = false;
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m == 0) continue;
+        if (keep) tq[tn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)lane << 16) | (uint32_t)(t - tile0);
+        tn += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (tn >= 64) {
+            tn -= 64;
+            expand_tiles(true, tq[tn + lane]);
+        }
+    }
+    if (tn > 0) expand_tiles(lane < tn, lane < tn ? tq[lane] : 0u);
+    if (qn > 0) solve_batch(lane < qn, lane < qn ? wq[lane] : 0u);
+    // one reservation for what the four waves still hold
+    if (lane == 0) sh.n_survivors[wave] = sn;
+    __syncthreads();
+    const int total = sh.n_survivors[0] + sh.n_survivors[1] + sh.n_survivors[2] + sh.n_survivors[3];
+    if (total == 0) return;
+    if (threadIdx.x == 0) {
+        sh.base[0] = q.base + (long long)atomicAdd(&q.counters[0], (unsigned long long)total);
+        sh.base[1] = q.base + (long long)atomicAdd(&q.counters[1], (unsigned long long)total * (unsigned)(K + 1));
+    }
+    __syncthreads();
+    if (sh.base[0] + total > q.path_cap || sh.base[1] + (long long)total * (K + 1) > q.seg_cap) return;  // chunk is redone
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += sh.n_survivors[w];
+    if (lane < sn) {
+        const uint32_t w = ws[lane];
+        const int64_t rr = r0 + (w & 0x3ffffffu);
+        const d3 R = ld3(rt.rxs + 3 * rr);
+        d3 X[K];
+        (void)reflect_exact<K>(sc, chains, c_base + (w >> 26), tx, R, X);
+        reflect_emit<K>(q, sh.base[0] + before + lane, sh.base[1] + (int64_t)(before + lane) * (K + 1), group,
+                        c_base + (w >> 26), rt.perm[rr], tx, R, X);
+    }
+}
+
 // The line of sight of receiver rx0 + i of the chunk as record i of the path queue (group -1, one segment): the
 // candidate kernels append behind the chunk's lines of sight (Queues::base).
 __device__ __forceinline__ void los_emit_one(d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t i, const Queues &q) {
@@ -717,6 +899,74 @@ __global__ __launch_bounds__(256) void k_reflect(SceneView sc, ReflectGroups g, 
     } else if (MO >= 4) {
         reflect_block<(MO >= 4 ? 4 : 1)>(sc, g.chains[3], g.count[3], 3, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[3],
                                          wave_queue);
+    }
+}
+
+template <int MO>
+__global__ __launch_bounds__(256) void k_reflect_tiled(SceneView sc, ReflectGroups g, d3 tx, RxTiles rt, int64_t r0,
+                                                        int64_t r1, int tiles_per_block, Queues q) {
+    __shared__ ReflectTiledShared sh;
+    const unsigned b = blockIdx.x;
+    if (b < g.first_block[1]) {
+        reflect_block_tiled<1>(sc, g.chains[0], g.count[0], 0, tx, rt, r0, r1, tiles_per_block, q, b, sh);
+    } else if (MO >= 2 && b < g.first_block[2]) {
+        reflect_block_tiled<(MO >= 2 ? 2 : 1)>(sc, g.chains[1], g.count[1], 1, tx, rt, r0, r1, tiles_per_block, q,
+                                               b - g.first_block[1], sh);
+    } else if (MO >= 3 && b < g.first_block[3]) {
+        reflect_block_tiled<(MO >= 3 ? 3 : 1)>(sc, g.chains[2], g.count[2], 2, tx, rt, r0, r1, tiles_per_block, q,
+                                               b - g.first_block[2], sh);
+    } else if (MO >= 4) {
+        reflect_block_tiled<(MO >= 4 ? 4 : 1)>(sc, g.chains[3], g.count[3], 3, tx, rt, r0, r1, tiles_per_block, q,
+                                               b - g.first_block[3], sh);
+    }
+}
+
+// ---- receivers into tiles: cell of a uniform grid over the scene (Morton order), counting sort, boxes ------------
+__device__ __forceinline__ uint32_t morton_spread(uint32_t v) {
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+__device__ __forceinline__ uint32_t rx_cell(const double *__restrict__ rx, int64_t i, double x0, double y0, double inv,
+                                            int g_side) {
+    const double fx = (rx[3 * i] - x0) * inv, fy = (rx[3 * i + 1] - y0) * inv;
+    const int cx = fx > 0.0 ? (fx < (double)(g_side - 1) ? (int)fx : g_side - 1) : 0;  // also NaN -> 0
+    const int cy = fy > 0.0 ? (fy < (double)(g_side - 1) ? (int)fy : g_side - 1) : 0;
+    return morton_spread((uint32_t)cx) | (morton_spread((uint32_t)cy) << 1);
+}
+__global__ void k_rx_count(const double *__restrict__ rx, int64_t n, double x0, double y0, double inv, int g_side,
+                           int32_t *__restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&counts[rx_cell(rx, i, x0, y0, inv, g_side)], 1);
+}
+__global__ void k_rx_scatter(const double *__restrict__ rx, int64_t n, double x0, double y0, double inv, int g_side,
+                             const int64_t *__restrict__ cell_off, int32_t *__restrict__ cursor,
+                             double *__restrict__ rxs, int32_t *__restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t cell = rx_cell(rx, i, x0, y0, inv, g_side);
+    const int64_t pos = cell_off[cell] + atomicAdd(&cursor[cell], 1);
+    rxs[3 * pos] = rx[3 * i];
+    rxs[3 * pos + 1] = rx[3 * i + 1];
+    rxs[3 * pos + 2] = rx[3 * i + 2];
+    perm[pos] = (int32_t)i;
+}
+__global__ void k_rx_boxes(const double *__restrict__ rxs, int64_t n, double *__restrict__ boxes) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * RX_TILE >= n) return;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = 0; j < RX_TILE && t * RX_TILE + j < n; ++j)
+        for (int a = 0; a < 3; ++a) {
+            const double v = rxs[3 * (t * RX_TILE + j) + a];
+            lo[a] = fmin(lo[a], v);
+            hi[a] = fmax(hi[a], v);
+        }
+    for (int a = 0; a < 3; ++a) {
+        boxes[6 * t + a] = 0.5 * (lo[a] + hi[a]);
+        // half extent rounded up so that the box holds its receivers whatever the rounding of the centre
+        boxes[6 * t + 3 + a] = 0.5 * (hi[a] - lo[a]) * (1.0 + 1e-12) + 1e-12 * (fabs(lo[a]) + fabs(hi[a]));
     }
 }
 
@@ -1081,6 +1331,39 @@ static bool launch_reflect(rt_scene *s, const rt_candidates *cand, d3 tx, const 
     return true;
 }
 
+static bool launch_reflect_tiled(rt_scene *s, const rt_candidates *cand, d3 tx, const RxTiles &rt, int64_t r0, int64_t r1,
+                                 const Queues &q) {
+    const int mo = cand->max_order;
+    ReflectGroups g{};
+    unsigned blocks = 0;
+    int top = 0;
+    for (int k = 1; k <= RT_MAX_ORDER; ++k) {
+        g.first_block[k - 1] = blocks;
+        if (k <= mo && cand->groups[k - 1].count > 0) {
+            g.chains[k - 1] = cand->groups[k - 1].chains;
+            g.count[k - 1] = cand->groups[k - 1].count;
+            blocks += blocks_for(g.count[k - 1], 256);
+            top = k;
+        }
+    }
+    g.first_block[RT_MAX_ORDER] = blocks;
+    if (blocks == 0) return false;
+    // tiles per block: enough to spread the set-up of a block's candidates, few enough for some thousand blocks
+    const int64_t n_tiles = (r1 - r0 + RX_TILE - 1) / RX_TILE;
+    int64_t per_block = n_tiles * (int64_t)blocks / 8192;
+    per_block = per_block < 4 ? 4 : (per_block > 64 ? 64 : per_block);
+    per_block = per_block > n_tiles ? n_tiles : per_block;
+    dim3 grid(blocks, blocks_for(n_tiles, (int)per_block));
+    const int tpb = (int)per_block;
+    switch (top) {
+        case 1: hipLaunchKernelGGL(k_reflect_tiled<1>, grid, dim3(256), 0, s->stream, s->view, g, tx, rt, r0, r1, tpb, q); break;
+        case 2: hipLaunchKernelGGL(k_reflect_tiled<2>, grid, dim3(256), 0, s->stream, s->view, g, tx, rt, r0, r1, tpb, q); break;
+        case 3: hipLaunchKernelGGL(k_reflect_tiled<3>, grid, dim3(256), 0, s->stream, s->view, g, tx, rt, r0, r1, tpb, q); break;
+        default: hipLaunchKernelGGL(k_reflect_tiled<4>, grid, dim3(256), 0, s->stream, s->view, g, tx, rt, r0, r1, tpb, q); break;
+    }
+    return true;
+}
+
 template <int M>
 static void launch_diffract(rt_scene *s, const DiffSetup *setup, const AliveRec *alive, int64_t count, int group,
                             const double *rx, int64_t rx0, int64_t rx1, const Queues &q) {
@@ -1272,6 +1555,41 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     int rx_tile = (int)std::min<int64_t>(32, std::max<int64_t>(4, chunk * std::max<int64_t>(cand_blocks, 1) / 512));
     rx_tile &= ~3;
     chunk = std::min<int64_t>(chunk, 65535ll * rx_tile);  // grid.y of the candidate kernels
+
+    // Large batches: the reflection kernel works on receivers sorted into spatial tiles and rejects whole tiles.
+    int64_t reflect_cand = 0;
+    for (int k = 0; k < mo; ++k) reflect_cand += cand->groups[k].count;
+    const bool tiled = reflect_cand > 0 && (scene->reflect_mode == 2 ||
+                                            (scene->reflect_mode == 0 && n_rx >= 128 && n_rx * reflect_cand >= (1ll << 28)));
+    RxTiles tiles{};
+    if (tiled) {
+        chunk = std::max<int64_t>(RX_TILE, std::min<int64_t>(chunk, 1ll << 22) / RX_TILE * RX_TILE);
+        int g_side = 1;
+        while (g_side < 256 && (int64_t)g_side * g_side * 4 < n_rx) g_side *= 2;
+        const SceneView &v = scene->view;
+        const double extent = std::max(v.gside * v.gnx, v.gside * v.gny);
+        const double inv = extent > 0.0 ? g_side / extent : 0.0;
+        const int64_t n_cells = (int64_t)g_side * g_side, n_tiles = (n_rx + RX_TILE - 1) / RX_TILE;
+        int32_t *counts = (int32_t *)temp_alloc(sizeof(int32_t) * 2 * n_cells);
+        int64_t *cell_off = (int64_t *)temp_alloc(sizeof(int64_t) * (n_cells + 1));
+        double *rxs = (double *)temp_alloc(sizeof(double) * 3 * n_rx);
+        int32_t *perm = (int32_t *)temp_alloc(sizeof(int32_t) * n_rx);
+        double *boxes = (double *)temp_alloc(sizeof(double) * 6 * n_tiles);
+        SOLVE_PTR(counts);
+        SOLVE_PTR(cell_off);
+        SOLVE_PTR(rxs);
+        SOLVE_PTR(perm);
+        SOLVE_PTR(boxes);
+        SOLVE_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * n_cells, st));
+        timer.begin(0);
+        hipLaunchKernelGGL(k_rx_count, dim3(blocks_for(n_rx, 256)), dim3(256), 0, st, d_rx, n_rx, v.gx0, v.gy0, inv, g_side, counts);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, counts, n_cells, cell_off);
+        hipLaunchKernelGGL(k_rx_scatter, dim3(blocks_for(n_rx, 256)), dim3(256), 0, st, d_rx, n_rx, v.gx0, v.gy0, inv, g_side,
+                           cell_off, counts + n_cells, rxs, perm);
+        hipLaunchKernelGGL(k_rx_boxes, dim3(blocks_for(n_tiles, 256)), dim3(256), 0, st, rxs, n_rx, boxes);
+        timer.end(0);
+        tiles = RxTiles{rxs, perm, boxes};
+    }
     unsigned long long found_before = 0;
 
     for (int64_t r0 = 0; r0 < n_rx;) {
@@ -1304,7 +1622,10 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         // order are one launch.
         scene->counters_dirty = true;
         timer.begin(0);
-        const bool los_queued = launch_reflect(scene, cand, TX, d_rx, r0, r1, rx_tile, q);
+        // (on tiles the reflection launch takes the receivers [r0, r1) of the sorted order: over the chunks every
+        // receiver meets every candidate once all the same; it queues no lines of sight)
+        const bool los_queued = tiled ? (launch_reflect_tiled(scene, cand, TX, tiles, r0, r1, q), false)
+                                      : launch_reflect(scene, cand, TX, d_rx, r0, r1, rx_tile, q);
         timer.end(0);
         if (!los_queued) {
             timer.begin(3);

@@ -277,3 +277,48 @@ def test_many_receivers_in_one_call(places):
     assert got == want and len(want) > 100
     cand.close()
     scene.close()
+
+
+@pytest.mark.parametrize("name,order,n_side,diffraction", [("place_levant", 2, 40, True), ("ny", 3, 14, False),
+                                                           ("lln", 2, 30, False)])
+def test_tiled_reflection_kernel_finds_the_same_paths(places, name, order, n_side, diffraction):
+    """Large batches sort the receivers into spatial tiles and reject whole tiles with an interval form of the
+    pre-test; the paths (and their points, bit for bit) must be those of the one-by-one loop.  Receivers in a
+    scrambled order, some far outside the scene, a count that is no multiple of the tile size."""
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import scenarios
+
+    place = places(name)
+    polygons = place.get_polygons_list()
+    lo, hi = place.get_domain()
+    tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 25.0)
+    rng = np.random.default_rng(3)
+    rx = scenarios.lattice_receivers(place, n_side, 1.5)
+    far = np.column_stack([rng.uniform(lo[0] - 500, hi[0] + 500, 37), rng.uniform(lo[1] - 500, hi[1] + 500, 37),
+                           rng.uniform(0.5, 60.0, 37)])
+    rx = np.concatenate([rx, far])[rng.permutation(len(rx) + 37)][:len(rx) + 30]
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    cand = scene.enumerate(vis, ev, pairs, edges, order, with_diffraction=diffraction)
+
+    def as_set(res):
+        return {(int(r), int(g), int(c)) + tuple(p[:3 * max(cand.group_kind(int(g))[0], 0) if g >= 0 else 0].ravel().tolist())
+                for r, g, c, p in zip(res["rx"], res["group"], res["cand"], res["points"].reshape(len(res["rx"]), -1))}
+
+    scene.set_reflect_mode(1)
+    one_by_one = scene.solve_paths(cand, tx, rx)
+    scene.set_reflect_mode(2)
+    tiled = scene.solve_paths(cand, tx, rx)
+    again = scene.solve_paths(cand, tx, rx)
+    scene.set_reflect_mode(0)
+    assert tiled["n_attempted"] == one_by_one["n_attempted"]
+    n_reflected = int(np.sum((one_by_one["group"] >= 0) & (one_by_one["group"] < order)))
+    assert n_reflected > 100, n_reflected
+    assert as_set(tiled) == as_set(one_by_one)
+    assert as_set(again) == as_set(one_by_one)
+    cand.close()
+    scene.close()
