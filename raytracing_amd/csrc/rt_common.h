@@ -72,6 +72,7 @@ struct SceneView {
     const double *frames;    // [n*9] rows: x axis, y axis, z axis (= reported normal) of the polygon's own frame
     const double *bbox;      // [n*6] min xyz, max xyz
     const double *uv;        // [vtot*2] vertices in the polygon's own frame (first two coordinates)
+    const double *uv_recs;   // [n*16] x axis (3), y axis (3) of the own frame, then min u, min v, max u, max v of the ring
     const int32_t *material; // [n]
     const int32_t *building; // [n]
     // Uniform grid of square cells over the horizontal extent of the scene (buildings are extrusions, so a 2-D grid

@@ -235,7 +235,7 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
     s->h_vert_off.assign(vert_off, vert_off + n_poly + 1);
     s->h_verts.assign(verts, verts + 3 * (size_t)vtot);
     s->h_planes.assign(planes, planes + 4 * (size_t)n_poly);
-    std::vector<double> frames(9 * (size_t)n_poly), uv(2 * (size_t)vtot);
+    std::vector<double> frames(9 * (size_t)n_poly), uv(2 * (size_t)vtot), uv_recs(16 * (size_t)n_poly, 0.0);
     s->h_bbox.resize(6 * (size_t)n_poly);
     std::vector<int32_t> mat(n_poly, 1), bld(n_poly, 0);
     if (material_id) mat.assign(material_id, material_id + n_poly);
@@ -260,10 +260,19 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
             bb[k] = INFINITY;
             bb[3 + k] = -INFINITY;
         }
+        double *ur = uv_recs.data() + 16 * (size_t)i;
+        st3(ur, fx);
+        st3(ur + 3, fy);
+        ur[6] = ur[7] = INFINITY;
+        ur[8] = ur[9] = -INFINITY;
         for (int v = 0; v < nv; ++v) {
             d3 P = ld3(p + 3 * v);
             uv[2 * (size_t)(v0 + v)] = dot(P, fx);
             uv[2 * (size_t)(v0 + v) + 1] = dot(P, fy);
+            ur[6] = std::fmin(ur[6], uv[2 * (size_t)(v0 + v)]);
+            ur[7] = std::fmin(ur[7], uv[2 * (size_t)(v0 + v) + 1]);
+            ur[8] = std::fmax(ur[8], uv[2 * (size_t)(v0 + v)]);
+            ur[9] = std::fmax(ur[9], uv[2 * (size_t)(v0 + v) + 1]);
             for (int k = 0; k < 3; ++k) {
                 bb[k] = std::fmin(bb[k], p[3 * v + k]);
                 bb[3 + k] = std::fmax(bb[3 + k], p[3 * v + k]);
@@ -273,6 +282,7 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
     bool ok = upload(s, s->h_vert_off, &s->view.vert_off) == 0 && upload(s, s->h_verts, &s->view.verts) == 0 &&
               upload(s, s->h_planes, &s->view.planes) == 0 && upload(s, frames, &s->view.frames) == 0 &&
               upload(s, s->h_bbox, &s->view.bbox) == 0 && upload(s, uv, &s->view.uv) == 0 &&
+              upload(s, uv_recs, &s->view.uv_recs) == 0 &&
               upload(s, mat, &s->view.material) == 0 && upload(s, bld, &s->view.building) == 0 &&
               build_grid(s, n_poly, vert_off, verts, planes) == 0 && commit_uploads(s) == 0;
     if (ok && hipHostMalloc((void **)&s->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {

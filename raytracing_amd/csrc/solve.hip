@@ -515,6 +515,17 @@ __device__ inline bool reflect_exact(const SceneView &sc, const int32_t *__restr
         prev = img[i];
     }
     if (!unfold_exact<K>(nrm, g, img, R, X)) return false;
+    // Most pairs that come this far fail because an earlier reflection point misses its polygon by far: the extent of
+    // every polygon in its own frame (one record each) settles those before the rings are looked at.  The coordinates
+    // are the ones the point-in-polygon test forms, so a point inside a ring is inside its extent.
+    bool near = true;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const double *ur = sc.uv_recs + 16 * (size_t)poly[i];
+        const double u = dot(X[i], ld3(ur)), v = dot(X[i], ld3(ur + 3));
+        near = near && u >= ur[6] - 1e-9 && u <= ur[8] + 1e-9 && v >= ur[7] - 1e-9 && v <= ur[9] + 1e-9;
+    }
+    if (!near) return false;
     // ray_tracing.py:253-255; all K tests are made before looking at any of them, so that their loads overlap
     bool inside = true;
 #pragma unroll
@@ -555,7 +566,7 @@ __device__ inline void reflect_emit(const Queues &q, int64_t ps, int64_t ss, int
 }
 
 // Reflection candidates: lane = candidate of a K-reflection group, loop = receivers of the block's tile.
-// The loop only runs the padded pre-test (is the last reflection point near its polygon's box?); pairs that pass are
+// The loop only runs the padded pre-test (is the last reflection point within the extent of its polygon?); pairs that pass are
 // parked in a per-wave LDS queue and solved exactly 64 at a time, so the expensive part runs with all lanes busy
 // instead of once per receiver with one or two lanes.  Survivors are parked again (few per wave) and written out at
 // the end of the block with ONE reservation in the path and segment queues for the whole block: atomics on one
@@ -600,8 +611,12 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
         gk = -s;  // d + img·n = -(d + prev·n)
     }
     const d3 im = prev;
-    const double *bb = sc.bbox + 6 * (size_t)last;
-    const double b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
+    // the last polygon's own frame and the extent of its ring in it: the crossing point of the mirror plane lies in
+    // the plane, so two coordinates settle whether it is near the polygon (for a wall, a rectangle, whether it is in it)
+    const double *ur = sc.uv_recs + 16 * (size_t)last;
+    const d3 fu = ld3(ur), fv = ld3(ur + 3);
+    const double u_lo = ur[6], v_lo = ur[7], u_hi = ur[8], v_hi = ur[9];
+    const double imu = dot(im, fu), imv = dot(im, fv);
 
     const int64_t r_begin = rx0 + (int64_t)blockIdx.y * rx_tile;
     const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
@@ -635,10 +650,10 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
             const d3 R = ld3(rx + 3 * r);  // wave-uniform
             const d3 dir = R - im;
             const double t = -gk * fast_rcp_s(dot(dir, nk));
-            const double pad = 1e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 1e-6;
-            const double hx = im.x + t * dir.x, hy = im.y + t * dir.y, hz = im.z + t * dir.z;
-            pass[j] = active && r4 + j < r_end && t > -1e-6 && t < 1.0 + 1e-6 && hx >= b0 - pad && hx <= b3 + pad &&
-                      hy >= b1 - pad && hy <= b4 + pad && hz >= b2 - pad && hz <= b5 + pad;
+            const double pad = 2e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 2e-6;
+            const double hu = imu + t * dot(dir, fu), hv = imv + t * dot(dir, fv);
+            pass[j] = active && r4 + j < r_end && t > -1e-6 && t < 1.0 + 1e-6 && hu >= u_lo - pad && hu <= u_hi + pad &&
+                      hv >= v_lo - pad && hv <= v_hi + pad;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -682,6 +697,14 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
 // tile) pairs that survive are parked and expanded 64 at a time into the per-receiver pre-test; its survivors go to
 // the exact solve as before.
 #define RX_TILE 16
+#ifdef RT_REFLECT_STATS
+__device__ unsigned long long g_reflect_stats[4];  // tile tests, tiles kept, receiver pre-tests passed, undecided (D spans 0)
+extern "C" int rt_debug_reflect_stats(unsigned long long *out4) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_reflect_stats), sizeof(g_reflect_stats)) != hipSuccess) return -1;
+    unsigned long long z[4] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_reflect_stats), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 struct RxTiles {
     const double *rxs;     // receiver positions in tile order
     const int32_t *perm;   // perm[k] = index of sorted receiver k in the caller's array
@@ -692,7 +715,7 @@ struct ReflectTiledShared {
     uint32_t tile_queue[4][128];   // candidate lane << 16 | tile within the block's range
     uint32_t wave_queue[4][128];   // candidate lane << 26 | receiver within the chunk (sorted order)
     uint32_t survivors[4][128];    // same encoding
-    double cand[4][64][13];        // per candidate lane: image, plane normal, g, box of the last polygon
+    double cand[4][64][19];        // per candidate lane: image, plane normal, g, frame axes and extent of the last polygon
     int n_survivors[4];
     long long base[2];
 };
@@ -719,12 +742,15 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
         gk = -s;
     }
     const d3 im = prev;
-    const double *bb = sc.bbox + 6 * (size_t)last;
-    const double b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
+    const double *ur = sc.uv_recs + 16 * (size_t)last;
+    const d3 fu = ld3(ur), fv = ld3(ur + 3);
+    const double u_lo = ur[6], v_lo = ur[7], u_hi = ur[8], v_hi = ur[9];
+    const double imu = dot(im, fu), imv = dot(im, fv);
     {
         double *cd = sh.cand[wave][lane];
         cd[0] = im.x; cd[1] = im.y; cd[2] = im.z; cd[3] = nk.x; cd[4] = nk.y; cd[5] = nk.z; cd[6] = gk;
-        cd[7] = b0; cd[8] = b1; cd[9] = b2; cd[10] = b3; cd[11] = b4; cd[12] = b5;
+        cd[7] = fu.x; cd[8] = fu.y; cd[9] = fu.z; cd[10] = fv.x; cd[11] = fv.y; cd[12] = fv.z;
+        cd[13] = u_lo; cd[14] = v_lo; cd[15] = u_hi; cd[16] = v_hi; cd[17] = imu; cd[18] = imv;
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -763,7 +789,9 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
     auto expand_tiles = [&](bool has, uint32_t e) {
         const double *cd = sh.cand[wave][has ? (e >> 16) : 0];
         const d3 eim = mk3(cd[0], cd[1], cd[2]), enk = mk3(cd[3], cd[4], cd[5]);
-        const double eg = cd[6], e0 = cd[7], e1 = cd[8], e2 = cd[9], e3 = cd[10], e4 = cd[11], e5 = cd[12];
+        const double eg = cd[6];
+        const d3 efu = mk3(cd[7], cd[8], cd[9]), efv = mk3(cd[10], cd[11], cd[12]);
+        const double eu_lo = cd[13], ev_lo = cd[14], eu_hi = cd[15], ev_hi = cd[16], eimu = cd[17], eimv = cd[18];
         const int64_t rb = (tile0 + (e & 0xffffu)) * RX_TILE;
         for (int j = 0; j < RX_TILE; ++j) {
             const int64_t r = rb + j;
@@ -772,12 +800,15 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
                 const d3 R = ld3(rt.rxs + 3 * r);
                 const d3 dir = R - eim;
                 const double t = -eg * fast_rcp_s(dot(dir, enk));
-                const double pad = 1e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 1e-6;
-                const double hx = eim.x + t * dir.x, hy = eim.y + t * dir.y, hz = eim.z + t * dir.z;
-                pass = t > -1e-6 && t < 1.0 + 1e-6 && hx >= e0 - pad && hx <= e3 + pad && hy >= e1 - pad &&
-                       hy <= e4 + pad && hz >= e2 - pad && hz <= e5 + pad;
+                const double pad = 2e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 2e-6;
+                const double hu = eimu + t * dot(dir, efu), hv = eimv + t * dot(dir, efv);
+                pass = t > -1e-6 && t < 1.0 + 1e-6 && hu >= eu_lo - pad && hu <= eu_hi + pad && hv >= ev_lo - pad &&
+                       hv <= ev_hi + pad;
             }
             const unsigned long long m = __ballot(pass);
+#ifdef RT_REFLECT_STATS
+            if (lane == 0 && m != 0) atomicAdd(&g_reflect_stats[2], (unsigned long long)__popcll(m));
+#endif
             if (m == 0) continue;
             if (pass) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((e >> 16) << 26) | (uint32_t)(r - r0);
             qn += __popcll(m);
@@ -789,7 +820,8 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
         }
     };
 
-    for (int64_t t = tile0; t < tile1; ++t) {
+    // does the candidate of this lane reach any receiver position inside the box of tile t?
+    auto tile_kept = [&](int64_t t) -> bool {
         const double *bx = rt.boxes + 6 * t;  // wave-uniform
         const double cx = bx[0], cy = bx[1], cz = bx[2], ex = bx[3], ey = bx[4], ez = bx[5];
         // every receiver position R = centre + d, |d| <= half extent:  D = (R - im).n in Dc +- Dr
@@ -797,36 +829,62 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
         const double Dc = ux * nk.x + uy * nk.y + uz * nk.z;
         const double Dr = (ex * fabs(nk.x) + ey * fabs(nk.y) + ez * fabs(nk.z)) * (1.0 + 1e-9) + 1e-9 * (fabs(Dc) + 1.0);
         bool keep = active;
-        if (keep && fabs(Dc) > Dr) {
-            // t = -g / D over the box (D keeps its sign), cut to the pre-test's range
-            const double ta = -gk / (Dc - Dr), tb = -gk / (Dc + Dr);
-            double tlo = fmin(ta, tb), thi = fmax(ta, tb);
-            const double tw = 1e-9 * (fabs(tlo) + fabs(thi)) + 1e-12;
-            tlo = fmax(tlo - tw, -1e-6);
-            thi = fmin(thi + tw, 1.0 + 1e-6);
-            if (tlo > thi) {
+        // The crossing parameter t = -g / D must lie in the pre-test's range (-1e-6, 1 + 1e-6): D has the sign of -g and
+        // |D| >= |g| / (1 + 1e-6), unless g is so small that the other sign could give t > -1e-6 (then the tile is kept
+        // without looking further).  Oriented so that D is positive: D in [dlo, dhi].
+        const double ag = fabs(gk);
+        if (keep && ag > 1e-3) {
+            const double sgn = gk < 0.0 ? 1.0 : -1.0;
+            const double dhi = sgn * Dc + Dr;
+            double dlo = sgn * Dc - Dr;
+            dlo = fmax(dlo, ag * (1.0 - 2e-6));
+            if (dlo > dhi) {
                 keep = false;
             } else {
-                const double pad = 1e-5 * fmax(fabs(ux) + ex, fmax(fabs(uy) + ey, fabs(uz) + ez)) + 2e-6;
-                // hit coordinate im + t u over t in [tlo, thi], u in [uc - e, uc + e]: the extremes are at corners
-                auto outside = [&](double imc, double uc, double e, double lo, double hi) {
-                    const double u0 = uc - e, u1 = uc + e;
-                    const double p0 = tlo * u0, p1 = tlo * u1, p2 = thi * u0, p3 = thi * u1;
-                    const double hmin = imc + fmin(fmin(p0, p1), fmin(p2, p3)), hmax = imc + fmax(fmax(p0, p1), fmax(p2, p3));
-                    const double w = 1e-9 * (fabs(imc) + fabs(hmin) + fabs(hmax)) + pad;
+                double tlo = ag * fast_rcp_s(dhi), thi = ag * fast_rcp_s(dlo);  // widened below by far more than their error
+                const double tw = 1e-9 * (tlo + thi) + 1e-12;
+                tlo = fmax(tlo - tw, 0.0);  // the true t is positive here
+                thi = fmin(thi + tw, 1.0 + 1e-6);
+                const double pad = 2e-5 * fmax(fabs(ux) + ex, fmax(fabs(uy) + ey, fabs(uz) + ez)) + 4e-6;
+                // in-plane coordinate of the crossing point, a + t w, over t in [tlo, thi] and w in [wc - wr, wc + wr]
+                // (w = (R - im).axis over the box): the extremes are at corners of that rectangle
+                auto outside = [&](double a, d3 axis, double lo, double hi) {
+                    const double wc = ux * axis.x + uy * axis.y + uz * axis.z;
+                    const double wr = ex * fabs(axis.x) + ey * fabs(axis.y) + ez * fabs(axis.z);
+                    const double w0 = wc - wr, w1 = wc + wr;
+                    const double hmin = a + fmin(tlo * w0, thi * w0), hmax = a + fmax(tlo * w1, thi * w1);  // t >= 0
+                    const double w = 1e-9 * (fabs(a) + fabs(hmin) + fabs(hmax)) + pad;
                     return hmax + w < lo || hmin - w > hi;
                 };
-                if (outside(im.x, ux, ex, b0, b3) || outside(im.y, uy, ey, b1, b4) || outside(im.z, uz, ez, b2, b5)) keep = false;
+                if (outside(imu, fu, u_lo, u_hi) || outside(imv, fv, v_lo, v_hi)) keep = false;
             }
         }
-        const unsigned long long m = __ballot(keep);
-        if (m == 0) continue;
-        if (keep) tq[tn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)lane << 16) | (uint32_t)(t - tile0);
-        tn += __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (tn >= 64) {
-            tn -= 64;
-            expand_tiles(true, tq[tn + lane]);
+        return keep;
+    };
+    // two tiles per trip: their tests are independent chains of fp64 operations
+    for (int64_t t2 = tile0; t2 < tile1; t2 += 2) {
+        bool kept[2];
+        kept[0] = tile_kept(t2);
+        kept[1] = t2 + 1 < tile1 && tile_kept(t2 + 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool keep = kept[j];
+            const int64_t t = t2 + j;
+            const unsigned long long m = __ballot(keep);
+#ifdef RT_REFLECT_STATS
+            if (lane == 0 && t < tile1) {
+                atomicAdd(&g_reflect_stats[0], (unsigned long long)__popcll(__ballot(active)));
+                atomicAdd(&g_reflect_stats[1], (unsigned long long)__popcll(m));
+            }
+#endif
+            if (m == 0) continue;
+            if (keep) tq[tn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)lane << 16) | (uint32_t)(t - tile0);
+            tn += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (tn >= 64) {
+                tn -= 64;
+                expand_tiles(true, tq[tn + lane]);
+            }
         }
     }
     if (tn > 0) expand_tiles(lane < tn, lane < tn ? tq[lane] : 0u);
