@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
                     j_hi = (int)fmin(fj_hi, (double)(nw - 1));
                     z_low = fmin(A.z + ta * V.z, A.z + tb * V.z) - sc.gz0 - pad;
                 }
+                // (fetching the up to three cells of a column together on entering it was slower: 18.8 against 12.5 ms)
                 const OccCell cell = sc.cells[major_x ? j * sc.gnx + i : i * sc.gnx + j];
 #ifdef RT_OCC_STATS
                 ++st_cells;
