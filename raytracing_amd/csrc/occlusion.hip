@@ -137,7 +137,9 @@ __device__ __forceinline__ void obstruct_drain_lds(const OccRec *recs, const int
 // polygons).  Pairs parked during a stage are then examined before the next stage replaces the rings.
 #define RT_GRID_MIN_POLYGONS 512
 #define OBS_PASSES 2
+#ifndef OBS_FIRST_PASS_TRIPS
 #define OBS_FIRST_PASS_TRIPS 24
+#endif
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems items, int64_t n_cap,
                                                    const unsigned long long *__restrict__ n_dev,

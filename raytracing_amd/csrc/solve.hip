@@ -1162,8 +1162,8 @@ __device__ __forceinline__ bool keller_point(const DiffSetup &S, d3 R, d3 &D) {
 #define DIFF_CHUNK 32
 template <int M>
 __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ setup, const AliveRec *__restrict__ alive,
-                                                   int64_t count, int group, const double *__restrict__ rx, int64_t rx0,
-                                                   int64_t rx1, Queues q) {
+                                                   int64_t count, int group, const double *__restrict__ rx,
+                                                   const int32_t *__restrict__ perm, int64_t rx0, int64_t rx1, Queues q) {
     __shared__ DiffSetup s_setup[DIFF_CHUNK];
     __shared__ uint16_t s_list[4][DIFF_CHUNK * 64];
     __shared__ int s_count[4];
@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
         d3 D;
         (void)keller_point(S, RR, D);
         PathRec &rec = q.paths[p0 + j];
-        rec.rx = (int32_t)rr;
+        rec.rx = perm ? perm[rr] : (int32_t)rr;  // receivers may come in tile order
         rec.group = group;
         rec.cand = S.cand;
         rec.nseg = 2;
@@ -1424,9 +1424,9 @@ static bool launch_reflect_tiled(rt_scene *s, const rt_candidates *cand, d3 tx, 
 
 template <int M>
 static void launch_diffract(rt_scene *s, const DiffSetup *setup, const AliveRec *alive, int64_t count, int group,
-                            const double *rx, int64_t rx0, int64_t rx1, const Queues &q) {
+                            const double *rx, const int32_t *perm, int64_t rx0, int64_t rx1, const Queues &q) {
     dim3 grid(blocks_for(count, DIFF_CHUNK), blocks_for(rx1 - rx0, 256));
-    hipLaunchKernelGGL(k_diffract<M>, grid, dim3(256), 0, s->stream, setup, alive, count, group, rx, rx0, rx1, q);
+    hipLaunchKernelGGL(k_diffract<M>, grid, dim3(256), 0, s->stream, setup, alive, count, group, rx, perm, rx0, rx1, q);
 }
 
 template <int M>
@@ -1614,11 +1614,10 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     rx_tile &= ~3;
     chunk = std::min<int64_t>(chunk, 65535ll * rx_tile);  // grid.y of the candidate kernels
 
-    // Large batches: the reflection kernel works on receivers sorted into spatial tiles and rejects whole tiles.
-    int64_t reflect_cand = 0;
-    for (int k = 0; k < mo; ++k) reflect_cand += cand->groups[k].count;
-    const bool tiled = reflect_cand > 0 && (scene->reflect_mode == 2 ||
-                                            (scene->reflect_mode == 0 && n_rx >= 128 && n_rx * reflect_cand >= (1ll << 28)));
+    // Large batches: the candidate kernels work on receivers sorted into spatial tiles (the reflection kernel rejects
+    // whole tiles; both queue the segments of a wave's receivers, now a compact patch, next to each other).
+    const bool tiled = total_cand > 0 && (scene->reflect_mode == 2 ||
+                                          (scene->reflect_mode == 0 && n_rx >= 128 && n_rx * total_cand >= (1ll << 28)));
     RxTiles tiles{};
     if (tiled) {
         chunk = std::max<int64_t>(RX_TILE, std::min<int64_t>(chunk, 1ll << 22) / RX_TILE * RX_TILE);
@@ -1692,15 +1691,19 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         }
         // diffractions
         if (any_diffraction) {
+            // on tiles the diffraction kernel takes the receivers in tile order too: the 64 receivers of a wave are then
+            // a compact patch, and the segments it queues from one edge point stay together longer in the grid walk
+            const double *diff_rx = tiled ? tiles.rxs : d_rx;
+            const int32_t *diff_perm = tiled ? tiles.perm : nullptr;
             timer.begin(1);
             for (int m = 0; m < mo; ++m) {
                 const int64_t cnt = diff_count[m];
                 if (cnt == 0) continue;
                 switch (m) {
-                    case 0: launch_diffract<0>(scene, diff_setup[m], nullptr, cnt, mo + m, d_rx, r0, r1, q); break;
-                    case 1: launch_diffract<1>(scene, diff_setup[m], alive[m], cnt, mo + m, d_rx, r0, r1, q); break;
-                    case 2: launch_diffract<2>(scene, diff_setup[m], alive[m], cnt, mo + m, d_rx, r0, r1, q); break;
-                    default: launch_diffract<3>(scene, diff_setup[m], alive[m], cnt, mo + m, d_rx, r0, r1, q); break;
+                    case 0: launch_diffract<0>(scene, diff_setup[m], nullptr, cnt, mo + m, diff_rx, diff_perm, r0, r1, q); break;
+                    case 1: launch_diffract<1>(scene, diff_setup[m], alive[m], cnt, mo + m, diff_rx, diff_perm, r0, r1, q); break;
+                    case 2: launch_diffract<2>(scene, diff_setup[m], alive[m], cnt, mo + m, diff_rx, diff_perm, r0, r1, q); break;
+                    default: launch_diffract<3>(scene, diff_setup[m], alive[m], cnt, mo + m, diff_rx, diff_perm, r0, r1, q); break;
                 }
             }
             timer.end(1);
