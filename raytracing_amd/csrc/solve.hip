@@ -1184,7 +1184,52 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
     const d3 R = ld3(rx + 3 * (active ? r : rx0));
     uint16_t *list = s_list[wave];
     int n = 0;  // wave-uniform
-    for (int c = 0; c < n_c; ++c) {
+    // Which of the block's candidates can reach any receiver of this wave at all?  Lane c puts candidate c's Keller
+    // condition to the box around the wave's receivers (interval arithmetic, widened to err towards yes); when the
+    // receivers come in tile order the box is a small patch and most candidates drop out here.
+    unsigned long long reach = 0;
+    {
+        double lo[3], hi[3];
+        const double rv[3] = {R.x, R.y, R.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = active ? rv[a] : INFINITY;
+            hi[a] = active ? rv[a] : -INFINITY;
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = fmin(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = fmax(hi[a], __shfl_xor(hi[a], off));
+            }
+        }
+        bool may = false;
+        if (lane < n_c && lo[0] <= hi[0]) {
+            const DiffSetup &S = s_setup[lane];
+            const d3 ctr = mk3(0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2]));
+            const d3 ext = mk3(0.5 * (hi[0] - lo[0]), 0.5 * (hi[1] - lo[1]), 0.5 * (hi[2] - lo[2]));
+            const d3 fx = ld3(S.fx), fy = ld3(S.fy), fz = ld3(S.fz);
+            const double cx = dot(ctr, fx), cy = dot(ctr, fy), cz = dot(ctr, fz);
+            const double rx_ = ext.x * fabs(fx.x) + ext.y * fabs(fx.y) + ext.z * fabs(fx.z);
+            const double ry_ = ext.x * fabs(fy.x) + ext.y * fabs(fy.y) + ext.z * fabs(fy.z);
+            const double rz_ = ext.x * fabs(fz.x) + ext.y * fabs(fz.y) + ext.z * fabs(fz.z);
+            const double mag = fabs(cx) + fabs(cy) + fabs(cz) + rx_ + ry_ + rz_ + fabs(S.xe) + fabs(S.ye) + fabs(S.az) + 1.0;
+            const double slack = 1e-9 * mag + 2e-6;
+            // distance of the receivers from the edge's axis: between rho_lo and rho_hi
+            const double rho_c = sqrt((S.xe - cx) * (S.xe - cx) + (S.ye - cy) * (S.ye - cy));
+            const double rad = sqrt(rx_ * rx_ + ry_ * ry_) + slack;
+            const double rho_lo = fmax(rho_c - rad, 0.0), rho_hi = rho_c + rad;
+            if (!(S.rhoA + rho_lo > 0.0)) {
+                may = true;
+            } else {
+                // z = zA + (zB - zA) w with w = rhoA / (rhoA + rhoB) in [w_lo, w_hi] (0 <= w <= 1), zB - zA in [d_lo, d_hi]
+                const double w_lo = S.rhoA / (S.rhoA + rho_hi) * (1.0 - 1e-12), w_hi = fmin(S.rhoA / (S.rhoA + rho_lo) * (1.0 + 1e-12), 1.0);
+                const double d_lo = cz - rz_ - S.az - slack, d_hi = cz + rz_ - S.az + slack;
+                const double z_lo = S.az + fmin(d_lo * w_lo, d_lo * w_hi), z_hi = S.az + fmax(d_hi * w_lo, d_hi * w_hi);
+                may = z_hi + slack >= S.ze && z_lo - slack <= S.z1;
+            }
+        }
+        reach = __ballot(may);
+    }
+    for (unsigned long long todo = reach; todo != 0; todo &= todo - 1) {
+        const int c = __ffsll((long long)todo) - 1;
         d3 D;
         const bool ok = active && keller_point(s_setup[c], R, D);
         const unsigned long long m = __ballot(ok);
