@@ -450,11 +450,12 @@ __global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const uns
 // Obstruction flags of n_item items: segments of the queue, or with d_paths one segment per path (see ObstructItems;
 // the flags then accumulate over the rounds).  The flags are cleared first when clear_flags is set; otherwise whoever
 // queued the items has cleared them.  d_mask, when given, restricts the polygons
-// for the first n_masked segments / the line-of-sight paths.  With d_count the device holds the item
+// for the first n_masked segments / the line-of-sight paths.  d_index, when given, lists the items to look at (the
+// count then counts list entries).  With d_count the device holds the item
 // count less count_add (the sum <= n_item) and the grid is sized for n_hint of them.
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, const uint8_t *d_mask, int64_t n_masked,
                        uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
-                       const PathRec *d_paths, int round, bool clear_flags) {
+                       const PathRec *d_paths, int round, bool clear_flags, const int32_t *d_index) {
     if (n_item == 0) return 0;
     hipStream_t stream = scene->stream;
     const int block = 256;
@@ -476,7 +477,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
         else
             RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_item, scene->stream));
     }
-    const ObstructItems items{d_segs, d_paths, round, d_mask ? n_masked : 0, nullptr, d_count ? count_add : 0};
+    const ObstructItems items{d_segs, d_paths, round, d_mask ? n_masked : 0, d_index, d_count ? count_add : 0};
     // small launches on small scenes are latency-bound: there the every-polygon walk, split over grid.y, is quicker
     const bool walk_grid = scene->occlusion_mode == 2 ||
                            (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
@@ -541,6 +542,39 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     return 0;
 }
 
+// list = the items i < *n_dev + count_add whose flag is clear, *list_count = how many (in no particular order beyond
+// that of the waves' reservations)
+__global__ __launch_bounds__(256) void k_list_clear_flags(const uint8_t *__restrict__ flags, int64_t n_cap,
+                                                          const unsigned long long *__restrict__ n_dev, int64_t count_add,
+                                                          int32_t *__restrict__ list, unsigned long long *list_count) {
+    const unsigned long long nd = *n_dev + (unsigned long long)count_add;
+    if (nd > (unsigned long long)n_cap) return;
+    const int64_t n = (int64_t)nd;
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane); base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + lane;
+        const bool keep = i < n && flags[i] == 0;
+        const unsigned long long m = __ballot(keep);
+        if (m == 0) continue;
+        unsigned long long slot = 0;
+        if (lane == 0) slot = atomicAdd(list_count, (unsigned long long)__popcll(m));
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)slot);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(slot >> 32));
+        slot = ((unsigned long long)hi << 32) | lo;
+        if (keep) list[slot + __popcll(m & ((1ull << lane) - 1))] = (int32_t)i;
+    }
+}
+
+int rt_launch_list_clear_flags(rt_scene *scene, const uint8_t *d_flags, int64_t n_cap, const unsigned long long *d_count,
+                               int64_t count_add, int64_t n_hint, int32_t *d_list, unsigned long long *d_list_count) {
+    int64_t grid = (std::max<int64_t>(n_hint, 1) + 255) / 256;
+    grid = grid > 8192 ? 8192 : grid;  // few blocks: every wave that finds something makes one reservation
+    hipLaunchKernelGGL(k_list_clear_flags, dim3((unsigned)grid), dim3(256), 0, scene->stream, d_flags, n_cap, d_count,
+                       count_add, d_list, d_list_count);
+    RT_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t n_seg, const uint8_t *mask,
                                     uint8_t *out, int on_device) {
     if (!scene) RT_FAIL("rt_obstruct_segments: null scene");
@@ -549,7 +583,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
     if (!segs || !out) RT_FAIL("rt_obstruct_segments: null array");
     RT_HIP(hipSetDevice(scene->device));
     if (on_device) {
-        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, 0, nullptr, 0, true)) return -1;
+        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, 0, nullptr, 0, true, nullptr)) return -1;
         RT_HIP(hipStreamSynchronize(scene->stream));
         return 0;
     }
@@ -563,7 +597,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
         if (hipMemcpyAsync(d_segs, segs, sizeof(double) * 6 * n_seg, hipMemcpyHostToDevice, scene->stream) != hipSuccess)
             break;
         if (mask && hipMemcpyAsync(d_mask, mask, scene->view.n, hipMemcpyHostToDevice, scene->stream) != hipSuccess) break;
-        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, 0, nullptr, 0, true)) break;
+        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, 0, nullptr, 0, true, nullptr)) break;
         if (hipMemcpyAsync(out, d_out, n_seg, hipMemcpyDeviceToHost, scene->stream) != hipSuccess) break;
         if (hipStreamSynchronize(scene->stream) != hipSuccess) break;
         rc = 0;

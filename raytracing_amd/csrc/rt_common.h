@@ -109,7 +109,7 @@ struct rt_scene {
     bool timing = true;  // per-kernel-family events around the launches of a solve
     int reflect_mode = 0;  // 0 by batch size, 1 receivers one by one, 2 receivers in spatial tiles
     bool counters_dirty = true;  // d_counters[0..3] may be non-zero (first solve, or a solve that failed half-way)
-    int64_t hint_paths = 0, hint_segments = 0;
+    int64_t hint_paths = 0, hint_segments = 0, hint_clear = 0;
     int32_t *late_items = nullptr;  // items handed from the first to the second obstruction pass (grows on demand)
     size_t late_cap = 0;
     int64_t queue_capacity_override = 0;  // > 0: first size of the path queue (tests of the grow-and-redo route)

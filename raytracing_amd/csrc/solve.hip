@@ -26,7 +26,9 @@
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, int64_t n_masked,
                        uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
-                       const PathRec *d_paths, int round, bool clear_flags);
+                       const PathRec *d_paths, int round, bool clear_flags, const int32_t *d_index);
+int rt_launch_list_clear_flags(rt_scene *scene, const uint8_t *d_flags, int64_t n_cap, const unsigned long long *d_count,
+                               int64_t count_add, int64_t n_hint, int32_t *d_list, unsigned long long *d_list_count);
 
 #define MIN_DISTANCE_TOL 0.005 /* ray_tracing.py:252 */
 
@@ -1356,6 +1358,8 @@ __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ pa
             host_counters[0] = np;
             host_counters[1] = ns;
             host_counters[2] = atomicAdd(&counters[2], 0ull);
+            host_counters[3] = counters[8];  // paths listed as clear after the first obstruction round
+            counters[8] = 0;
             counters[0] = 0;
             counters[1] = 0;
             counters[3] = 0;
@@ -1544,7 +1548,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     unsigned long long *h_counters_dev = nullptr;  // the same words as the device addresses them
     SOLVE_HIP(hipHostGetDevicePointer((void **)&h_counters_dev, h_counters, 0));
     // the final filter of a chunk leaves the queue counters at zero; only a solve that was cut short does not
-    if (scene->counters_dirty) SOLVE_HIP(hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
+    if (scene->counters_dirty) SOLVE_HIP(hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 16, st));
     if (on_device) {
         out.rx = out_rx;
         out.group = out_group;
@@ -1599,7 +1603,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_HIP(hipStreamSynchronize(st));
         if (n0 == 0) continue;
         timer.begin(2);
-        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, 0, nullptr, 0, true)) {
+        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, 0, nullptr, 0, true, nullptr)) {
             free_temps();
             return -1;
         }
@@ -1703,7 +1707,8 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         size_t off_paths = 0;
         size_t off_segs = align_up(off_paths + sizeof(PathRec) * path_cap);
         size_t off_hits = align_up(off_segs + sizeof(double) * 6 * seg_cap);
-        size_t total = align_up(off_hits + (size_t)seg_cap);
+        size_t off_list = align_up(off_hits + (size_t)seg_cap);
+        size_t total = align_up(off_list + sizeof(int32_t) * path_cap);
         void *ws = nullptr;
         if (rt_scene_workspace(scene, total, &ws)) {
             free_temps();
@@ -1711,6 +1716,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         }
         char *w = (char *)ws;
         uint8_t *d_hits = (uint8_t *)(w + off_hits);
+        int32_t *d_list = (int32_t *)(w + off_list);  // paths still clear after the first obstruction round
 
         const int64_t seg_hint = scene->hint_segments > 0 ? scene->hint_segments : std::min<int64_t>(seg_cap, 1 << 22);
         const int64_t path_hint = scene->hint_paths > 0 ? scene->hint_paths : std::min<int64_t>(path_cap, 1 << 21);
@@ -1760,12 +1766,21 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
             for (int k = 1; k <= mo; ++k)
                 if (cand->groups[k - 1].count > 0) max_nseg = std::max(max_nseg, k + 1);
             if (any_diffraction) max_nseg = std::max(max_nseg, 2);
-            for (int round = 0; round < max_nseg; ++round)
-                if (rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters, nr, path_hint, q.paths, round, false)) {
-                    free_temps();
-                    return -1;
-                }
-        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, nr, seg_hint, nullptr, 0, false)) {
+            // round 0 looks at the last segment of every path; nearly all of a coverage map's paths end there, so the
+            // paths still clear are listed and the later rounds look at those only
+            int rc = rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters, nr, path_hint, q.paths, 0,
+                                        false, nullptr);
+            if (rc == 0 && max_nseg > 1)
+                rc = rt_launch_list_clear_flags(scene, d_hits, path_cap, d_counters, nr, path_hint, d_list, d_counters + 8);
+            const int64_t list_hint = scene->hint_clear > 0 ? scene->hint_clear : std::min<int64_t>(path_hint, 1 << 20);
+            for (int round = 1; rc == 0 && round < max_nseg; ++round)
+                rc = rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters + 8, 0, list_hint, q.paths,
+                                        round, false, d_list);
+            if (rc) {
+                free_temps();
+                return -1;
+            }
+        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, nr, seg_hint, nullptr, 0, false, nullptr)) {
             free_temps();
             return -1;
         }
@@ -1793,6 +1808,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         scene->counters_dirty = false;
         scene->hint_paths = std::max<int64_t>(n_paths, 1);
         scene->hint_segments = std::max<int64_t>(n_segs, 1);
+        scene->hint_clear = std::max<int64_t>((int64_t)h_counters[3], 1);
         scene->last_segments += n_segs;
         r0 = r1;
     }
