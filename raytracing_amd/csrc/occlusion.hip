@@ -19,7 +19,10 @@
 // group -1: the lines of sight, which the reference tests against the polygons the emitter sees only
 // (ray_tracing.py:232-237); every other segment is tested against the whole scene.
 struct ObstructItems {
-    const double *segs;
+    const double *segs;    // the segment queue; null with paths: a path's segments are then formed from its record, the
+                           // emitter and the receiver's position (nothing but the records was queued)
+    d3 tx;
+    const double *rx;
     const PathRec *paths;
     int round;
     int64_t n_masked;
@@ -28,32 +31,42 @@ struct ObstructItems {
 };
 
 __device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t &i, const uint8_t *__restrict__ out,
-                                             int64_t &seg, bool &masked) {
+                                             bool &masked, d3 &A, d3 &B) {
     if (it.index) i = it.index[i];
-    seg = i;
     masked = i < it.n_masked;
-    if (!it.paths) return true;
+    if (!it.paths) {
+        A = ld3(it.segs + 6 * i);
+        B = ld3(it.segs + 6 * i + 3);
+        return true;
+    }
     const PathRec &p = it.paths[i];
     masked = p.group < 0;
     if (it.round >= p.nseg || out[i]) return false;
-    seg = p.seg0 + (int64_t)(p.nseg - 1 - it.round) * p.seg_stride;
+    if (it.segs) {
+        const int64_t seg = p.seg0 + (int64_t)(p.nseg - 1 - it.round) * p.seg_stride;
+        A = ld3(it.segs + 6 * seg);
+        B = ld3(it.segs + 6 * seg + 3);
+    } else {
+        const int e = p.npts - it.round;  // the segment ends at point e, npts standing for the receiver
+        B = e >= p.npts ? ld3(it.rx + 3 * (int64_t)p.rx) : ld3(p.pts + 3 * e);
+        A = e >= 1 ? ld3(p.pts + 3 * (e - 1)) : it.tx;
+    }
     return true;
 }
 
 // Runs the exact test for up to 64 parked (item lane, polygon) pairs of a wave, one pair per lane.  BATCHED picks the
 // arrangement of the exact test for latency-bound launches.
 template <bool BATCHED>
-__device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double *__restrict__ segs,
-                                               const int64_t *wave_seg, const int64_t *wave_item, int p_begin,
+__device__ __forceinline__ void obstruct_drain(const SceneView &sc, const double (*wave_ab)[6],
+                                               const int64_t *wave_item, int p_begin,
                                                const uint32_t *entries, int n_entries, int lane,
                                                volatile uint8_t *wave_hit, uint8_t *__restrict__ out) {
     if (lane < n_entries) {
         const uint32_t e = entries[lane];
         const int L = (int)(e & 63u);
         if (!wave_hit[L]) {
-            const int64_t s = wave_seg[L];
             const int p = p_begin + (int)(e >> 6);
-            const d3 A = ld3(segs + 6 * s), B = ld3(segs + 6 * s + 3);
+            const d3 A = ld3(wave_ab[L]), B = ld3(wave_ab[L] + 3);
             if (BATCHED ? polygon_cuts_segment_batched(sc, p, A, B) : polygon_cuts_segment(sc, p, A, B)) {
                 wave_hit[L] = 1;
                 out[wave_item[L]] = 1;  // out starts at zero; several polygon chunks may set the same byte
@@ -110,18 +123,17 @@ __device__ inline bool polygon_cuts_segment_lds(const double *ring, int nv, d3 n
 // obstruct_drain for entries whose polygons are those of the stage in LDS: recs[i], ring of polygon i =
 // verts[3 * voff[i] .. 3 * voff[i + 1]); an entry's polygon field counts from the stage's first polygon.
 __device__ __forceinline__ void obstruct_drain_lds(const OccRec *recs, const int *voff, const double *verts,
-                                                   const double *__restrict__ segs, const int64_t *wave_seg,
+                                                   const double (*wave_ab)[6],
                                                    const int64_t *wave_item, const uint32_t *entries, int n_entries,
                                                    int lane, volatile uint8_t *wave_hit, uint8_t *__restrict__ out) {
     if (lane < n_entries) {
         const uint32_t e = entries[lane];
         const int L = (int)(e & 63u);
         if (!wave_hit[L]) {
-            const int64_t s = wave_seg[L];
             const int i = (int)(e >> 6);
             const OccRec &r = recs[i];
             const int v0 = voff[i], nv = voff[i + 1] - v0;
-            if (polygon_cuts_segment_lds(verts + 3 * v0, nv, mk3(r.nx, r.ny, r.nz), r.d, ld3(segs + 6 * s), ld3(segs + 6 * s + 3))) {
+            if (polygon_cuts_segment_lds(verts + 3 * v0, nv, mk3(r.nx, r.ny, r.nz), r.d, ld3(wave_ab[L]), ld3(wave_ab[L] + 3))) {
                 wave_hit[L] = 1;
                 out[wave_item[L]] = 1;
             }
@@ -144,8 +156,8 @@ template <bool MASKED>
 __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems items, int64_t n_cap,
                                                    const unsigned long long *__restrict__ n_dev,
                                                    const uint8_t *__restrict__ mask, int poly_chunk, uint8_t *out) {
-    __shared__ int64_t wave_segs[4][64], wave_items[4][64];
-    const double *__restrict__ segs = items.segs;
+    __shared__ int64_t wave_items[4][64];
+    __shared__ double wave_ab[4][64][6];  // the segment of each lane, for the exact tests
     __shared__ OccRec s_rec[OBS_STAGE];
     __shared__ uint8_t s_mask[OBS_STAGE];
     __shared__ double s_verts[3 * OBS_STAGE_VERTS];
@@ -166,16 +178,13 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
     for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
-        int64_t seg = 0, item = s;
+        int64_t item = s;
         bool use_mask = false;
-        const bool active = s < n_seg && item_segment(items, item, out, seg, use_mask);
-        wave_items[wave][lane] = item;
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
-        if (active) {
-            A = ld3(segs + 6 * seg);
-            B = ld3(segs + 6 * seg + 3);
-        }
-        wave_segs[wave][lane] = seg;
+        const bool active = s < n_seg && item_segment(items, item, out, use_mask, A, B);
+        wave_items[wave][lane] = item;
+        st3(wave_ab[wave][lane], A);
+        st3(wave_ab[wave][lane] + 3, B);
         const d3 V = B - A;
         const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
         bool hit = false;
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
             if (wave_done) continue;
             const int stage_first = rings_staged ? p0 - p_begin : 0;  // what an entry's polygon field counts from
             if (rings_staged && qn > 0) {  // pairs parked during a stage whose rings did not fit
-                obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
+                obstruct_drain<true>(sc, wave_ab[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
                 __builtin_amdgcn_wave_barrier();
                 qn = 0;
                 hit = wave_hit[lane] != 0;
@@ -223,10 +232,10 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                     if (qn >= 64) {
                         qn -= 64;
                         if (rings_staged)
-                            obstruct_drain_lds(s_rec, s_voff, s_verts, segs, wave_segs[wave], wave_items[wave], wq + qn, 64, lane,
+                            obstruct_drain_lds(s_rec, s_voff, s_verts, wave_ab[wave], wave_items[wave], wq + qn, 64, lane,
                                                wave_hit, out);
                         else
-                            obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq + qn, 64, lane, wave_hit, out);
+                            obstruct_drain<true>(sc, wave_ab[wave], wave_items[wave], p_begin, wq + qn, 64, lane, wave_hit, out);
                         __builtin_amdgcn_wave_barrier();
                         hit = wave_hit[lane] != 0;
                         if (__all(hit || !active)) {
@@ -238,14 +247,14 @@ __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems it
                 }
             }
             if (rings_staged && qn > 0) {  // before the next stage replaces the rings
-                obstruct_drain_lds(s_rec, s_voff, s_verts, segs, wave_segs[wave], wave_items[wave], wq, qn, lane, wave_hit, out);
+                obstruct_drain_lds(s_rec, s_voff, s_verts, wave_ab[wave], wave_items[wave], wq, qn, lane, wave_hit, out);
                 __builtin_amdgcn_wave_barrier();
                 qn = 0;
                 hit = wave_hit[lane] != 0;
                 if (__all(hit || !active)) wave_done = true;
             }
         }
-        if (qn > 0) obstruct_drain<true>(sc, segs, wave_segs[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
+        if (qn > 0) obstruct_drain<true>(sc, wave_ab[wave], wave_items[wave], p_begin, wq, qn, lane, wave_hit, out);
         __syncthreads();  // the staging buffer is free again
     }
 }
@@ -277,8 +286,8 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
                                                         const unsigned long long *__restrict__ n_dev,
                                                         const uint8_t *__restrict__ mask, uint8_t *out, int max_trips,
                                                         unsigned long long *late_count, int32_t *late_items) {
-    __shared__ int64_t wave_segs[4][64], wave_items[4][64];
-    const double *__restrict__ segs = items.segs;
+    __shared__ int64_t wave_items[4][64];
+    __shared__ double wave_ab[4][64][6];  // the segment of each lane, for the exact tests
     __shared__ uint32_t wave_queue[4][128];
     __shared__ uint8_t wave_hits[4][64];
     int64_t n_seg = n_cap;
@@ -294,16 +303,13 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
     for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
-        int64_t seg = 0, item = s;
+        int64_t item = s;
         bool use_mask = false;
-        const bool active = s < n_seg && item_segment(items, item, out, seg, use_mask);
-        wave_items[wave][lane] = item;
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
-        if (active) {
-            A = ld3(segs + 6 * seg);
-            B = ld3(segs + 6 * seg + 3);
-        }
-        wave_segs[wave][lane] = seg;
+        const bool active = s < n_seg && item_segment(items, item, out, use_mask, A, B);
+        wave_items[wave][lane] = item;
+        st3(wave_ab[wave][lane], A);
+        st3(wave_ab[wave][lane] + 3, B);
         const d3 V = B - A;
         const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
         // walk set-up: u = major horizontal axis, w = minor, both relative to the grid origin; the columns are visited
@@ -400,13 +406,13 @@ __global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructIte
                 __builtin_amdgcn_wave_barrier();
                 if (qn >= 64) {
                     qn -= 64;
-                    obstruct_drain<false>(sc, segs, wave_segs[wave], wave_items[wave], 0, wq + qn, 64, lane, wave_hit, out);
+                    obstruct_drain<false>(sc, wave_ab[wave], wave_items[wave], 0, wq + qn, 64, lane, wave_hit, out);
                     __builtin_amdgcn_wave_barrier();
                     if (wave_hit[lane]) finished = true;
                 }
             }
         }
-        if (qn > 0) obstruct_drain<false>(sc, segs, wave_segs[wave], wave_items[wave], 0, wq, qn, lane, wave_hit, out);
+        if (qn > 0) obstruct_drain<false>(sc, wave_ab[wave], wave_items[wave], 0, wq, qn, lane, wave_hit, out);
         __builtin_amdgcn_wave_barrier();
         if (late_items) {
             // a lane whose walk is not over when the wave's trips are used up hands its item to the second pass, where
@@ -455,7 +461,8 @@ __global__ void k_zero_bytes(uint8_t *__restrict__ out, int64_t n_cap, const uns
 // count less count_add (the sum <= n_item) and the grid is sized for n_hint of them.
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, const uint8_t *d_mask, int64_t n_masked,
                        uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
-                       const PathRec *d_paths, int round, bool clear_flags, const int32_t *d_index) {
+                       const PathRec *d_paths, int round, bool clear_flags, const int32_t *d_index, const double *tx,
+                       const double *d_rx) {
     if (n_item == 0) return 0;
     hipStream_t stream = scene->stream;
     const int block = 256;
@@ -477,7 +484,9 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
         else
             RT_HIP(hipMemsetAsync(d_out, 0, (size_t)n_item, scene->stream));
     }
-    const ObstructItems items{d_segs, d_paths, round, d_mask ? n_masked : 0, d_index, d_count ? count_add : 0};
+    if (!d_segs && !(d_paths && tx && d_rx)) RT_FAIL("rt_launch_obstruct: no segments");
+    const ObstructItems items{d_segs, tx ? ld3(tx) : mk3(0, 0, 0), d_rx, d_paths, round, d_mask ? n_masked : 0, d_index,
+                              d_count ? count_add : 0};
     // small launches on small scenes are latency-bound: there the every-polygon walk, split over grid.y, is quicker
     const bool walk_grid = scene->occlusion_mode == 2 ||
                            (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
@@ -583,7 +592,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
     if (!segs || !out) RT_FAIL("rt_obstruct_segments: null array");
     RT_HIP(hipSetDevice(scene->device));
     if (on_device) {
-        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, 0, nullptr, 0, true, nullptr)) return -1;
+        if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, 0, nullptr, 0, true, nullptr, nullptr, nullptr)) return -1;
         RT_HIP(hipStreamSynchronize(scene->stream));
         return 0;
     }
@@ -597,7 +606,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
         if (hipMemcpyAsync(d_segs, segs, sizeof(double) * 6 * n_seg, hipMemcpyHostToDevice, scene->stream) != hipSuccess)
             break;
         if (mask && hipMemcpyAsync(d_mask, mask, scene->view.n, hipMemcpyHostToDevice, scene->stream) != hipSuccess) break;
-        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, 0, nullptr, 0, true, nullptr)) break;
+        if (rt_launch_obstruct(scene, d_segs, n_seg, d_mask, n_seg, d_out, nullptr, 0, 0, nullptr, 0, true, nullptr, nullptr, nullptr)) break;
         if (hipMemcpyAsync(out, d_out, n_seg, hipMemcpyDeviceToHost, scene->stream) != hipSuccess) break;
         if (hipStreamSynchronize(scene->stream) != hipSuccess) break;
         rc = 0;

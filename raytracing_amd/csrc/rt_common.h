@@ -124,8 +124,9 @@ int rt_scene_workspace(rt_scene *scene, size_t bytes, void **out);
 
 // A path waiting for its obstruction test: its interaction points and where its segments are in the segment queue.
 struct PathRec {
-    int32_t rx, group, cand, nseg;
-    int64_t seg0, seg_stride;  // segment k of the path is segs[seg0 + k * seg_stride]
+    int32_t rx, group, cand, nseg;  // nseg: segments still to be tested, counted from the receiver's end
+    int64_t seg0;                   // segment k of those is segs[seg0 + k * seg_stride] when the segment queue is kept
+    int32_t seg_stride, npts;       // npts interaction points: emitter, pts[0..npts), receiver is the whole path
     double pts[RT_MAX_ORDER * 3];
 };
 

@@ -26,7 +26,8 @@
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, int64_t n_masked,
                        uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
-                       const PathRec *d_paths, int round, bool clear_flags, const int32_t *d_index);
+                       const PathRec *d_paths, int round, bool clear_flags, const int32_t *d_index, const double *tx,
+                       const double *d_rx);
 int rt_launch_list_clear_flags(rt_scene *scene, const uint8_t *d_flags, int64_t n_cap, const unsigned long long *d_count,
                                int64_t count_add, int64_t n_hint, int32_t *d_list, unsigned long long *d_list_count);
 
@@ -34,7 +35,7 @@ int rt_launch_list_clear_flags(rt_scene *scene, const uint8_t *d_flags, int64_t 
 
 struct Queues {
     PathRec *paths;
-    double *segs;
+    double *segs;                  // null: only the records are queued (their segments follow from their points)
     int64_t path_cap, seg_cap;
     unsigned long long *counters;  // [0] paths, [1] segments queued behind the lines of sight
     int64_t base;                  // records and segments [0, base) are the chunk's lines of sight
@@ -554,17 +555,21 @@ __device__ inline void reflect_emit(const Queues &q, int64_t ps, int64_t ss, int
     rec.nseg = K + 1;
     rec.seg0 = ss;
     rec.seg_stride = 1;
+    rec.npts = K;
     clear_hits(q, ps, ss, 1, K + 1);
-    d3 a = tx;
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-        st3(rec.pts + 3 * i, X[i]);
-        st3(q.segs + 6 * (ss + i), a);
-        st3(q.segs + 6 * (ss + i) + 3, X[i]);
-        a = X[i];
+    for (int i = 0; i < K; ++i) st3(rec.pts + 3 * i, X[i]);
+    if (q.segs) {
+        d3 a = tx;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            st3(q.segs + 6 * (ss + i), a);
+            st3(q.segs + 6 * (ss + i) + 3, X[i]);
+            a = X[i];
+        }
+        st3(q.segs + 6 * (ss + K), a);
+        st3(q.segs + 6 * (ss + K) + 3, R);
     }
-    st3(q.segs + 6 * (ss + K), a);
-    st3(q.segs + 6 * (ss + K) + 3, R);
 }
 
 // Reflection candidates: lane = candidate of a K-reflection group, loop = receivers of the block's tile.
@@ -925,10 +930,13 @@ __device__ __forceinline__ void los_emit_one(d3 tx, const double *__restrict__ r
     rec.nseg = 1;
     rec.seg0 = i;
     rec.seg_stride = 1;
+    rec.npts = 0;
     clear_hits(q, i, i, 1, 1);
     for (int k = 0; k < RT_MAX_ORDER * 3; ++k) rec.pts[k] = 0.0;
-    st3(q.segs + 6 * i, tx);
-    st3(q.segs + 6 * i + 3, ld3(rx + 3 * (rx0 + i)));
+    if (q.segs) {
+        st3(q.segs + 6 * i, tx);
+        st3(q.segs + 6 * i + 3, ld3(rx + 3 * (rx0 + i)));
+    }
 }
 
 // All reflection orders of a solve in ONE launch (a small step is bound by the number of dependent launches): the
@@ -1265,16 +1273,19 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
         rec.nseg = 2;
         rec.seg0 = s0 + j;
         rec.seg_stride = n;
+        rec.npts = M + 1;
         clear_hits(q, p0 + j, s0 + j, n, 2);
         if (M > 0) {
             const AliveRec &al = alive[c_begin + (e >> 6)];
             for (int i = 0; i < M; ++i) st3(rec.pts + 3 * i, ld3(al.pts + 3 * i));
         }
         st3(rec.pts + 3 * M, D);
-        st3(q.segs + 6 * (s0 + j), ld3(S.A));
-        st3(q.segs + 6 * (s0 + j) + 3, D);
-        st3(q.segs + 6 * (s0 + n + j), D);
-        st3(q.segs + 6 * (s0 + n + j) + 3, RR);
+        if (q.segs) {
+            st3(q.segs + 6 * (s0 + j), ld3(S.A));
+            st3(q.segs + 6 * (s0 + j) + 3, D);
+            st3(q.segs + 6 * (s0 + n + j), D);
+            st3(q.segs + 6 * (s0 + n + j) + 3, RR);
+        }
     }
 }
 
@@ -1603,7 +1614,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_HIP(hipStreamSynchronize(st));
         if (n0 == 0) continue;
         timer.begin(2);
-        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, 0, nullptr, 0, true, nullptr)) {
+        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, 0, nullptr, 0, true, nullptr, nullptr, nullptr)) {
             free_temps();
             return -1;
         }
@@ -1703,11 +1714,18 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         const int64_t nr = r1 - r0;
         // workspace layout: paths | segs | hits.  The first nr records of both queues are the chunk's lines of sight.
         if (path_cap < nr + 1024) path_cap = nr + 1024;
-        const int64_t seg_cap = path_cap * 3;
+        const int64_t seg_hint = scene->hint_segments > 0 ? scene->hint_segments : std::min<int64_t>(path_cap * 3, 1 << 22);
+        const int64_t path_hint = scene->hint_paths > 0 ? scene->hint_paths : std::min<int64_t>(path_cap, 1 << 21);
+        // Large batches: one obstruction launch per segment place, last segment first, each skipping the paths already
+        // blocked (flags per path); only the path records are queued, their segments follow from the records' points.
+        // Small batches are launch-bound: one launch over all segments, which are queued too (flags per segment).
+        const bool by_rounds = path_hint >= (1 << 15);
+        const int64_t seg_cap = by_rounds ? (1ll << 60) : path_cap * 3;
+        const int64_t n_flags = by_rounds ? path_cap : seg_cap;
         size_t off_paths = 0;
         size_t off_segs = align_up(off_paths + sizeof(PathRec) * path_cap);
-        size_t off_hits = align_up(off_segs + sizeof(double) * 6 * seg_cap);
-        size_t off_list = align_up(off_hits + (size_t)seg_cap);
+        size_t off_hits = align_up(off_segs + (by_rounds ? 0 : sizeof(double) * 6 * seg_cap));
+        size_t off_list = align_up(off_hits + (size_t)n_flags);
         size_t total = align_up(off_list + sizeof(int32_t) * path_cap);
         void *ws = nullptr;
         if (rt_scene_workspace(scene, total, &ws)) {
@@ -1718,12 +1736,8 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         uint8_t *d_hits = (uint8_t *)(w + off_hits);
         int32_t *d_list = (int32_t *)(w + off_list);  // paths still clear after the first obstruction round
 
-        const int64_t seg_hint = scene->hint_segments > 0 ? scene->hint_segments : std::min<int64_t>(seg_cap, 1 << 22);
-        const int64_t path_hint = scene->hint_paths > 0 ? scene->hint_paths : std::min<int64_t>(path_cap, 1 << 21);
-        // Large batches: one obstruction launch per segment place, last segment first, each skipping the paths already
-        // blocked (flags per path).  Small batches are launch-bound: one launch over all segments (flags per segment).
-        const bool by_rounds = path_hint >= (1 << 15);
-        Queues q{(PathRec *)(w + off_paths), (double *)(w + off_segs), path_cap, seg_cap, d_counters, nr, d_hits, by_rounds ? 1 : 0};
+        Queues q{(PathRec *)(w + off_paths), by_rounds ? nullptr : (double *)(w + off_segs), path_cap, seg_cap, d_counters, nr,
+                 d_hits, by_rounds ? 1 : 0};
 
         // Lines of sight: queued like every other path (the first nr records), tested against the polygons the emitter
         // sees only (ray_tracing.py:232-237).  The reflection launch queues them on the way; reflections of every
@@ -1769,18 +1783,19 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
             // round 0 looks at the last segment of every path; nearly all of a coverage map's paths end there, so the
             // paths still clear are listed and the later rounds look at those only
             int rc = rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters, nr, path_hint, q.paths, 0,
-                                        false, nullptr);
+                                        false, nullptr, tx, d_rx);
             if (rc == 0 && max_nseg > 1)
                 rc = rt_launch_list_clear_flags(scene, d_hits, path_cap, d_counters, nr, path_hint, d_list, d_counters + 8);
             const int64_t list_hint = scene->hint_clear > 0 ? scene->hint_clear : std::min<int64_t>(path_hint, 1 << 20);
             for (int round = 1; rc == 0 && round < max_nseg; ++round)
                 rc = rt_launch_obstruct(scene, q.segs, path_cap, cand->d_ev, 0, d_hits, d_counters + 8, 0, list_hint, q.paths,
-                                        round, false, d_list);
+                                        round, false, d_list, tx, d_rx);
             if (rc) {
                 free_temps();
                 return -1;
             }
-        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, nr, seg_hint, nullptr, 0, false, nullptr)) {
+        } else if (rt_launch_obstruct(scene, q.segs, seg_cap, cand->d_ev, nr, d_hits, d_counters + 1, nr, seg_hint, nullptr, 0, false, nullptr,
+                                      nullptr, nullptr)) {
             free_temps();
             return -1;
         }
