@@ -551,33 +551,60 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     return 0;
 }
 
-// list = the items i < *n_dev + count_add whose flag is clear, *list_count = how many (in no particular order beyond
-// that of the waves' reservations)
+// list = the items i < *n_dev + count_add whose flag is clear, *list_count = how many.  A thread looks at 16 flags (one
+// 16-byte load; flags is 16-byte aligned), a block at 4096 and reserves the room of what it found with one atomic.
 __global__ __launch_bounds__(256) void k_list_clear_flags(const uint8_t *__restrict__ flags, int64_t n_cap,
                                                           const unsigned long long *__restrict__ n_dev, int64_t count_add,
                                                           int32_t *__restrict__ list, unsigned long long *list_count) {
+    __shared__ int wave_total[4];
+    __shared__ unsigned long long block_base;
     const unsigned long long nd = *n_dev + (unsigned long long)count_add;
     if (nd > (unsigned long long)n_cap) return;
     const int64_t n = (int64_t)nd;
-    const int lane = threadIdx.x & 63;
-    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane); base < n; base += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = base + lane;
-        const bool keep = i < n && flags[i] == 0;
-        const unsigned long long m = __ballot(keep);
-        if (m == 0) continue;
-        unsigned long long slot = 0;
-        if (lane == 0) slot = atomicAdd(list_count, (unsigned long long)__popcll(m));
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)slot);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(slot >> 32));
-        slot = ((unsigned long long)hi << 32) | lo;
-        if (keep) list[slot + __popcll(m & ((1ull << lane) - 1))] = (int32_t)i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 4096; base < n; base += (int64_t)gridDim.x * 4096) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * 16;
+        uint4 v = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        if (i0 + 16 <= n) {
+            v = *(const uint4 *)(flags + i0);
+        } else if (i0 < n) {
+            uint8_t *b = (uint8_t *)&v;
+            for (int k = 0; k < 16 && i0 + k < n; ++k) b[k] = flags[i0 + k];
+        }
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mine += ((w[k] >> (8 * j)) & 0xffu) == 0 ? 1 : 0;
+        int incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) wave_total[wave] = incl;
+        __syncthreads();
+        const int total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        if (threadIdx.x == 0 && total > 0) block_base = atomicAdd(list_count, (unsigned long long)total);
+        __syncthreads();
+        if (mine > 0) {
+            int before = incl - mine;
+            for (int q = 0; q < wave; ++q) before += wave_total[q];
+            int64_t pos = (int64_t)block_base + before;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((w[k] >> (8 * j)) & 0xffu) == 0) list[pos++] = (int32_t)(i0 + 4 * k + j);
+        }
+        __syncthreads();  // wave_total and block_base are reused by the next stretch
     }
 }
 
 int rt_launch_list_clear_flags(rt_scene *scene, const uint8_t *d_flags, int64_t n_cap, const unsigned long long *d_count,
                                int64_t count_add, int64_t n_hint, int32_t *d_list, unsigned long long *d_list_count) {
-    int64_t grid = (std::max<int64_t>(n_hint, 1) + 255) / 256;
-    grid = grid > 8192 ? 8192 : grid;  // few blocks: every wave that finds something makes one reservation
+    int64_t grid = (std::max<int64_t>(n_hint, 1) + 4095) / 4096;
+    grid = grid > 65536 ? 65536 : grid;
     hipLaunchKernelGGL(k_list_clear_flags, dim3((unsigned)grid), dim3(256), 0, scene->stream, d_flags, n_cap, d_count,
                        count_add, d_list, d_list_count);
     RT_HIP(hipGetLastError());
