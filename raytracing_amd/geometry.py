@@ -184,7 +184,8 @@ class OrientedPolygon(OrientedGeometry):
         """[a, b, c, d] with unit normal from the first three vertices, d = -n·p2 (reference :1747-1765)."""
         if force or self.parametric is None:
             p = self.points
-            normal = np.cross(p[1] - p[0], p[2] - p[1])
+            a, b = p[1] - p[0], p[2] - p[1]
+            normal = np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
             normal = normal / np.linalg.norm(normal)
             d = -np.dot(normal, p[2])
             self.parametric = np.array([normal[0], normal[1], normal[2], d])

@@ -35,6 +35,28 @@ def _inside_any(footprints, boxes, x, y):
     return False
 
 
+def _inside_any_many(footprints, boxes, xs, ys):
+    """``_inside_any`` for arrays of points (the same predicate, evaluated footprint by footprint on the points inside
+    its box)."""
+    inside = np.zeros(len(xs), dtype=bool)
+    for ring, (lo, hi) in zip(footprints, boxes):
+        sel = np.flatnonzero((lo[0] <= xs) & (xs <= hi[0]) & (lo[1] <= ys) & (ys <= hi[1]) & ~inside)
+        if len(sel) == 0:
+            continue
+        x, y = xs[sel], ys[sel]
+        odd = np.zeros(len(sel), dtype=bool)
+        on_edge = np.zeros(len(sel), dtype=bool)
+        n = len(ring)
+        for k in range(n):
+            ax, ay = ring[k - 1]
+            bx, by = ring[k]
+            cr = (bx - ax) * (y - ay) - (by - ay) * (x - ax)
+            on_edge |= (cr == 0) & (min(ax, bx) <= x) & (x <= max(ax, bx)) & (min(ay, by) <= y) & (y <= max(ay, by))
+            odd ^= ((ay > y) != (by > y)) & ((cr > 0) == (by > ay))
+        inside[sel] = on_edge | odd
+    return inside
+
+
 def lattice_receivers(place, n_side, z, inset=0.05, count=None):
     """n_side × n_side lattice over the ground box shrunk by ``inset``, at height z; lattice points inside a
     footprint (boundary included) are dropped and replaced by points of the same lattice shifted by half a pitch,
@@ -52,15 +74,14 @@ def lattice_receivers(place, n_side, z, inset=0.05, count=None):
     for shift in range(0, 64):
         # pass 0 is the lattice itself; pass s >= 1 is the lattice moved by (half pitch) / s
         ox, oy = (px / shift, py / shift) if shift else (0.0, 0.0)
-        for y in ys:
-            for x in xs:
-                xx, yy = x + ox, y + oy
-                if abs(xx - cx) > hx or abs(yy - cy) > hy:
-                    continue
-                if not _inside_any(fps, boxes, xx, yy):
-                    out.append((xx, yy, z))
-                    if len(out) == count:
-                        return np.array(out, dtype=float)
+        gx, gy = np.meshgrid(xs + ox, ys + oy)  # row order: y outer, x inner
+        gx, gy = gx.ravel(), gy.ravel()
+        ok = ~((np.abs(gx - cx) > hx) | (np.abs(gy - cy) > hy))
+        ok[ok] = ~_inside_any_many(fps, boxes, gx[ok], gy[ok])
+        for k in np.flatnonzero(ok):
+            out.append((gx[k], gy[k], z))
+            if len(out) == count:
+                return np.array(out, dtype=float)
     raise RuntimeError("could not place the requested number of receivers outside the footprints")
 
 
