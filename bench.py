@@ -45,16 +45,27 @@ def large_workload(local_rank, dev):
     from raytracing_amd import geometry as geom
 
     t0 = time.perf_counter()
+    stamps = {}
+
+    def stamp(name, since):
+        stamps[name] = round(time.perf_counter() - since, 3)
+        return time.perf_counter()
+
     place, tx, rx = scenarios.lln_grid(100)
     polygons = place.get_polygons_list()
+    t = stamp("scene_file_s", t0)
     scene = _lib.Scene(geom.scene_arrays_of(polygons), device=local_rank)
     pairs, edges = scene.sharp_edges()
-    vis = scene.visibility_matrix(False)
+    t = stamp("device_scene_and_sharp_edges_s", t)
     cube = geom.Cube.by_point_and_side_length(tx, 0.2)
     ev = np.zeros(len(polygons), dtype=bool)
-    for v in scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False):
+    # the matrix and the emitter's screens in one call, as RayTracingProblem.precompute asks for them
+    vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
+    for v in screens:
         ev |= v
+    t = stamp("visibility_matrix_and_emitter_screens_s", t)
     cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+    stamp("enumeration_s", t)
     precompute_s = time.perf_counter() - t0
     n_rx = len(rx)
     d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
@@ -89,7 +100,7 @@ def large_workload(local_rank, dev):
     fields_s = time.perf_counter() - t
     covered = int(np.isfinite(fields["power_db"][:, 0]).sum())
     out = {"workload": f"lln.geojson ({len(polygons)} polygons), 1 TX, 100x100 RX, reflections+diffractions up to order 2",
-           "precompute_s": round(precompute_s, 3), "solve_ms": 1e3 * best, "path_solves": int(attempted),
+           "precompute_s": round(precompute_s, 3), "precompute_breakdown": stamps, "solve_ms": 1e3 * best, "path_solves": int(attempted),
            "path_solves_per_s": attempted / best, "valid_paths": int(found), "candidates": counts,
            "segments": int(timing["segments"]), "kernel_ms": {k: float(v) for k, v in timing["ms"].items()},
            "reflect_algorithmic_tflops_fp64": reflect_flop / (timing["ms"]["reflect"] * 1e-3) / 1e12,
@@ -201,10 +212,10 @@ def main():
     polygons = place.get_polygons_list()
     arrays = geom.scene_arrays_of(polygons)
     scene = _lib.Scene(arrays, device=local_rank)
-    vis = scene.visibility_matrix(False)
     cube = geom.Cube.by_point_and_side_length(tx, 0.2)
     ev = np.zeros(len(polygons), dtype=bool)
-    for v in scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False):
+    vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
+    for v in screens:
         ev |= v
     cand = scene.enumerate(vis, ev, np.zeros((0, 2), np.int32), np.zeros((0, 2, 3)), 2, with_diffraction=False)
     precompute_s = time.perf_counter() - t_pre

@@ -68,6 +68,14 @@ int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_devic
 /* rows of that matrix before it is symmetrised (geometry.py:1036-1046 for the listed i only): out[n_rows*N], row k =
  * what polygon row_ids[k] sees.  matrix = rows | rows^T once every row is there; a node deals the rows to its GPUs. */
 int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *out);
+/* The matrix (row_ids NULL: rows_out[N*N], symmetrised, as rt_visibility_matrix) or the listed rows (rows_out[n_rows*N],
+ * as rt_visibility_rows) together with the visibility vectors of n_faces extra faces (faces_out[n_faces*N], arguments as
+ * rt_faces_visibility): the two steps RayTracingProblem.precompute takes one after the other (ray_tracing.py:208, then
+ * :210-228 for the emitter's screens).  The screens are painted on a stream of their own while the matrix is painted,
+ * instead of holding six compute units busy afterwards.  Host pointers.  Same results as the separate calls. */
+int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *rows_out,
+                             int32_t n_faces, const int32_t *face_off, const double *face_verts,
+                             const double *face_normals, const int32_t *self_index, int faces_strict, uint8_t *faces_out);
 /* Obstruction tests either walk every polygon (mode 1) or a uniform grid over the scene (mode 2); mode 0, the
  * default, picks by scene size.  Both give the same flags; the switch exists so that tests can check one against the
  * other (no reference counterpart). */

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "rt_face_visibility": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_void_p]),
     "rt_visibility_rows": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p]),
     "rt_faces_visibility": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rt_visibility_with_faces": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_void_p]),
     "rt_debug_visibility_stats": (c_int, [c_void_p]),
     "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
     "rt_scene_set_timing": (c_int, [c_void_p, c_int]),
@@ -267,6 +269,27 @@ class Scene:
         _check(load().rt_faces_visibility(self.handle, len(faces), _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs),
                                           int(bool(strict)), _ptr(out)), "rt_faces_visibility")
         return out.astype(bool)
+
+    def visibility_with_faces(self, faces, row_ids=None, strict=False, faces_strict=False):
+        """The visibility matrix (``row_ids`` None) or the listed unsymmetrised rows, and the visibility vectors of
+        ``faces`` (as ``faces_visibility`` takes them), painted side by side: returns (matrix or rows, face vectors)."""
+        off = np.zeros(len(faces) + 1, dtype=np.int32)
+        np.cumsum([len(f[0]) for f in faces], out=off[1:])
+        verts = _f64(np.concatenate([np.asarray(f[0], dtype=float).reshape(-1, 3) for f in faces]))
+        normals = _f64(np.array([np.asarray(f[1], dtype=float)[:3] for f in faces]))
+        selfs = np.array([int(f[2]) for f in faces], dtype=np.int32)
+        f_out = np.zeros((len(faces), self.n), dtype=np.uint8)
+        if row_ids is None:
+            rows, n_rows, r_ptr = None, 0, None
+            r_out = np.zeros((self.n, self.n), dtype=np.uint8)
+        else:
+            rows = np.ascontiguousarray(row_ids, dtype=np.int32)
+            n_rows, r_ptr = len(rows), _ptr(rows)
+            r_out = np.zeros((len(rows), self.n), dtype=np.uint8)
+        _check(load().rt_visibility_with_faces(self.handle, n_rows, r_ptr, int(bool(strict)), _ptr(r_out), len(faces),
+                                               _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs), int(bool(faces_strict)),
+                                               _ptr(f_out)), "rt_visibility_with_faces")
+        return r_out.astype(bool), f_out.astype(bool)
 
     def visibility_rows(self, row_ids, strict=False):
         """Rows of the visibility matrix before symmetrisation: bool [len(row_ids), N]."""

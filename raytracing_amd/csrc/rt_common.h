@@ -92,6 +92,7 @@ struct SceneView {
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;  // created on first use: work that runs beside the main stream's (emitter screens)
     SceneView view{};
     std::vector<void *> allocations;
     // host copies used by host-side set-up code

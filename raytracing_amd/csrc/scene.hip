@@ -307,6 +307,10 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
 extern "C" void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    if (s->side_stream) {
+        (void)hipStreamSynchronize(s->side_stream);
+        (void)hipStreamDestroy(s->side_stream);
+    }
     if (s->stream) {
         (void)hipStreamSynchronize(s->stream);
         (void)hipStreamDestroy(s->stream);

@@ -1056,15 +1056,22 @@ struct DevBuf {
     int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
 };
 
-// visibility rows of a batch of faces into d_out[n_faces*n] (zeroed here)
-static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, const std::vector<double> &a_verts,
-                           const std::vector<double> &a_normal, const std::vector<int32_t> &a_self, int strict,
-                           uint8_t *d_out) {
+// Device buffers of one batch of faces: they live until the batch's kernels have run.
+struct RowsJob {
+    DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work;
+};
+
+// Queues, on stream st, the kernels that write the visibility rows of a batch of faces into d_out[n_faces*n] (zeroed
+// here).  Nothing is waited for: the caller synchronises st before it lets go of job and of the host arrays.
+static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::vector<int32_t> &a_off,
+                                   const std::vector<double> &a_verts, const std::vector<double> &a_normal,
+                                   const std::vector<int32_t> &a_self, int strict, uint8_t *d_out, RowsJob &job) {
     const SceneView &sc = scene->view;
     const int n_faces = (int)a_self.size();
     if (n_faces == 0) return 0;
-    hipStream_t st = scene->stream;
-    DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work;
+    DevBuf &b_off = job.b_off, &b_verts = job.b_verts, &b_normal = job.b_normal, &b_self = job.b_self, &b_sph = job.b_sph,
+           &b_meta = job.b_meta, &b_list = job.b_list, &b_canvas = job.b_canvas, &b_cbox = job.b_cbox, &b_splits = job.b_splits,
+           &b_counter = job.b_counter, &b_order = job.b_order, &b_counts = job.b_counts, &b_work = job.b_work;
     // persistent workgroups of 4 waves, one face per workgroup at a time
     int n_blocks = n_faces > 1024 ? 1024 : n_faces;
     const int64_t split_cap = 3 * (int64_t)sc.vtot + 8;
@@ -1106,7 +1113,19 @@ static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, c
                            (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
                            (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, d_out);
     RT_HIP(hipGetLastError());
-    RT_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// visibility rows of a batch of faces into d_out[n_faces*n], on the scene's stream, waited for
+static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, const std::vector<double> &a_verts,
+                           const std::vector<double> &a_normal, const std::vector<int32_t> &a_self, int strict,
+                           uint8_t *d_out) {
+    RowsJob job;
+    if (visibility_rows_enqueue(scene, scene->stream, a_off, a_verts, a_normal, a_self, strict, d_out, job)) {
+        (void)hipStreamSynchronize(scene->stream);
+        return -1;
+    }
+    RT_HIP(hipStreamSynchronize(scene->stream));
     return 0;
 }
 
@@ -1210,6 +1229,56 @@ extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, i
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(scene->stream));
     if (!on_device) RT_HIP(hipMemcpy(out, d_dst, (size_t)n * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// The visibility matrix (or some of its rows) and the visibility vectors of extra faces (the emitter's screens) in one
+// call: what RayTracingProblem.precompute asks for one after the other (ray_tracing.py:208 then :210-228).  A few
+// screens occupy a few compute units for as long as the whole matrix takes the rest of the chip, so the screens are
+// painted on a stream of their own while the matrix is painted on the scene's.
+// row_ids null: rows_out[N*N] = the symmetrised matrix (rt_visibility_matrix); otherwise rows_out[n_rows*N] = the
+// listed rows as rt_visibility_rows gives them.
+extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict,
+                                        uint8_t *rows_out, int32_t n_faces, const int32_t *face_off,
+                                        const double *face_verts, const double *face_normals, const int32_t *self_index,
+                                        int faces_strict, uint8_t *faces_out) {
+    if (!scene || !rows_out) RT_FAIL("rt_visibility_with_faces: null argument");
+    if (n_faces < 0 || (row_ids && n_rows < 0)) RT_FAIL("rt_visibility_with_faces: negative count");
+    if (n_faces == 0) return row_ids ? rt_visibility_rows(scene, n_rows, row_ids, strict, rows_out)
+                                     : rt_visibility_matrix(scene, strict, rows_out, 0);
+    if (!face_off || !face_verts || !face_normals || !faces_out) RT_FAIL("rt_visibility_with_faces: null argument");
+    if (n_faces > 65535) RT_FAIL("rt_visibility_with_faces: at most 65535 faces per call");
+    if (face_off[0] != 0) RT_FAIL("rt_visibility_with_faces: face_off must start at 0");
+    for (int f = 0; f < n_faces; ++f) {
+        if (face_off[f + 1] - face_off[f] < 3) RT_FAIL("rt_visibility_with_faces: a face needs at least 3 vertices");
+        if (self_index && (self_index[f] < -1 || self_index[f] >= scene->view.n))
+            RT_FAIL("rt_visibility_with_faces: self_index out of range");
+    }
+    RT_HIP(hipSetDevice(scene->device));
+    if (!scene->side_stream) {
+        // a priority of its own: streams of one priority share a few hardware queues in creation order, and two
+        // streams that land on the same queue run one after the other
+        int least = 0, greatest = 0;
+        RT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        RT_HIP(hipStreamCreateWithPriority(&scene->side_stream, hipStreamNonBlocking, greatest));
+    }
+    const size_t n = (size_t)scene->view.n;
+    std::vector<int32_t> a_off(face_off, face_off + n_faces + 1), a_self(n_faces, -1);
+    if (self_index) a_self.assign(self_index, self_index + n_faces);
+    std::vector<double> a_verts(face_verts, face_verts + 3 * (size_t)face_off[n_faces]);
+    std::vector<double> a_normal(face_normals, face_normals + 3 * (size_t)n_faces);
+    DevBuf d_faces;
+    if (d_faces.alloc(n * n_faces)) RT_FAIL("rt_visibility_with_faces: out of device memory");
+    RowsJob job;  // after d_faces and the host arrays: the stream is waited for before any of them goes
+    int rc = visibility_rows_enqueue(scene, scene->side_stream, a_off, a_verts, a_normal, a_self, faces_strict,
+                                     (uint8_t *)d_faces.p, job);
+    if (rc == 0)
+        rc = row_ids ? rt_visibility_rows(scene, n_rows, row_ids, strict, rows_out)
+                     : rt_visibility_matrix(scene, strict, rows_out, 0);
+    const hipError_t e = hipStreamSynchronize(scene->side_stream);
+    if (rc) return -1;
+    if (e != hipSuccess) RT_FAIL(std::string("rt_visibility_with_faces: ") + hipGetErrorString(e));
+    RT_HIP(hipMemcpy(faces_out, d_faces.p, n * n_faces, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -128,15 +128,28 @@ def gather_visibility_rows(rows_of, n, dist=None):
     return matrix | matrix.T
 
 
-def sharded_visibility_matrix(place, strict=False):
+def sharded_visibility_matrix(place, strict=False, emitter=None, n_screens=6):
     """``place.get_visibility_matrix()`` with the rows dealt to the ranks of the process group; the result is cached on
-    the place like the reference's (geometry.py:1467-1483), on every rank."""
+    the place like the reference's (geometry.py:1467-1483), on every rank.  With ``emitter`` every rank also paints the
+    emitter's screens (ray_tracing.py:210-228) beside its rows and leaves them on the place for the problem's
+    ``precompute``."""
     from . import geometry as geom
 
     if place.visibility_matrix is None:
         polygons = place.get_polygons_list()
         scene = geom.scene_arrays_of(polygons).device_scene()
-        place.visibility_matrix = gather_visibility_rows(lambda ids: scene.visibility_rows(ids, strict), len(polygons))
+        if emitter is None:
+            rows_of = lambda ids: scene.visibility_rows(ids, strict)
+        else:
+            emitter = np.asarray(emitter, dtype=float)
+            cube = geom.Cube.by_point_and_side_length(emitter, 2 * 0.1)
+            screens = [(cube.polygons[i].points, cube.polygons[i].get_parametric(), -1) for i in range(n_screens)]
+
+            def rows_of(ids):
+                rows, screen_vis = scene.visibility_with_faces(screens, row_ids=ids, strict=strict)
+                place._screens_ahead = ((emitter.tobytes(), n_screens), screen_vis)
+                return rows
+        place.visibility_matrix = gather_visibility_rows(rows_of, len(polygons))
     return place.visibility_matrix
 
 
@@ -171,7 +184,9 @@ def multithread_solve_place(place, tx, geometry, N_CPU=16, order=3, save_name=No
     rank = dist.get_rank() if dist else 0
     t0 = time.time()
     if dist is not None and dist.get_world_size() > 1:
-        sharded_visibility_matrix(place)  # the one precompute step worth sharing out: every rank needs the whole matrix
+        # the one precompute step worth sharing out (every rank needs the whole matrix); the emitter's screens are
+        # painted beside this rank's rows
+        sharded_visibility_matrix(place, emitter=tx)
     problem = RayTracingProblem(tx, place)
     solve_sharded(problem, order)
     out_dir = electromagnetism_utils.results_dir()

@@ -58,13 +58,23 @@ class RayTracingProblem:
     def precompute(self):
         """Visibility matrix, emitter visibility through the screens of a 0.2 m cube, sharp edges, lines of sight."""
         scene = self._device_scene()
-        self.visibility_matrix = self.place.get_visibility_matrix(strict=False)
         emitter = np.asarray(self.emitter, dtype=float)
         cube = geom.Cube.by_point_and_side_length(emitter, 2 * 0.1)
         self.distance_to_screen = cube.polygons[0].distance_to_point(emitter)
 
         screens = [(cube.polygons[i].points, cube.polygons[i].get_parametric(), -1) for i in range(self.n_screens)]
-        visibilities = [(int(np.sum(vis)), vis) for vis in scene.faces_visibility(screens, False)]
+        ahead = getattr(self.place, "_screens_ahead", None)  # painted beside the matrix rows by the sharded driver
+        if ahead is not None and ahead[0] == (emitter.tobytes(), self.n_screens):
+            screen_vis = ahead[1]
+            self.visibility_matrix = self.place.get_visibility_matrix(strict=False)
+        elif self.place.visibility_matrix is None:
+            # the matrix and the screens in one call: the screens are painted while the matrix is (same results)
+            self.place.visibility_matrix, screen_vis = scene.visibility_with_faces(screens)
+            self.visibility_matrix = self.place.visibility_matrix
+        else:
+            self.visibility_matrix = self.place.get_visibility_matrix(strict=False)
+            screen_vis = scene.faces_visibility(screens, False)
+        visibilities = [(int(np.sum(vis)), vis) for vis in screen_vis]
         visibilities.sort(key=lambda x: x[0], reverse=True)
         self.emitter_visibility = visibilities[0][1].copy()
         for _, vis in visibilities[1:self.n_screens]:

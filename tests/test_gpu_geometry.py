@@ -276,3 +276,35 @@ def test_standalone_solvers_match_oracle():
     assert not sol.success
     _, sol = geom.reflexion_points_from_origin_destination_and_planes(np.array([0, 0, 1.0]), np.array([1.0, 0, 2.0]), plane)
     assert sol.success
+
+
+@pytest.mark.parametrize("name", ["small", "place_levant"])
+def test_matrix_and_screens_in_one_call_equal_the_separate_calls(places, name):
+    """The visibility matrix (or some of its rows) and the emitter's screens painted side by side on two streams are
+    the matrix, the rows and the screen vectors of the separate entry points."""
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import scenarios
+
+    place = places(name)
+    polygons = place.get_polygons_list()
+    lo, hi = place.get_domain()
+    tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 20.0)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    screens = [(s.points, s.get_parametric(), -1) for s in cube.polygons]
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    matrix = scene.visibility_matrix(False)
+    vectors = scene.faces_visibility(screens, False)
+    assert vectors.any() and matrix.any()
+    for _ in range(2):  # the side stream is made on the first call and reused
+        m2, v2 = scene.visibility_with_faces(screens)
+        np.testing.assert_array_equal(m2, matrix)
+        np.testing.assert_array_equal(v2, vectors)
+    ids = np.arange(1, len(polygons), 3)
+    r2, v3 = scene.visibility_with_faces(screens[:2], row_ids=ids)
+    np.testing.assert_array_equal(r2, scene.visibility_rows(ids))
+    np.testing.assert_array_equal(v3, vectors[:2])
+    r0, v4 = scene.visibility_with_faces(screens, row_ids=np.zeros(0, np.int32))
+    assert r0.shape == (0, len(polygons))
+    np.testing.assert_array_equal(v4, vectors)
+    scene.close()
