@@ -81,6 +81,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RtError(f"{LIB_PATH} is missing: build it with `python -m raytracing_amd.build_ext` "
                           "(there is no CPU implementation to fall back to)")
+        # PyTorch ships its own copy of the HIP runtime.  A process that loads this library first (the system runtime)
+        # and initialises torch.cuda afterwards holds two runtimes, and the second one finds no GPU; with torch
+        # imported first the loader gives this library torch's copy and both work.  So: torch first, when there is one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(lib, name)
