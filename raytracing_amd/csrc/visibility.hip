@@ -168,10 +168,16 @@ __global__ __launch_bounds__(256) void k_vis_prepare(SceneView sc, FaceBatch fb,
     double *pol = az + nv;
     double zmax = -INFINITY, rmin = INFINITY;
     double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+    // the z filter first (geometry.py:967-970): about half of a scene lies behind a face, and those polygons are not
+    // mapped (nobody reads the mapped vertices of a polygon that is not a candidate)
+    for (int v = 0; v < nv; ++v) zmax = fmax(zmax, dot(ld3(sc.verts + 3 * (size_t)(v0 + v)) - c, fz));
+    if (!(zmax > TOL_DZ)) {
+        *out = m;
+        return;
+    }
     for (int v = 0; v < nv; ++v) {
         const d3 q = ld3(sc.verts + 3 * (size_t)(v0 + v)) - c;
         const double qx = dot(q, fx), qy = dot(q, fy), qz = dot(q, fz);
-        zmax = fmax(zmax, qz);
         const double r = sqrt(qx * qx + qy * qy + qz * qz);  // geometry.py:302-306
         const double a = atan2(qy, qx);
         const double p = acos(qz / r);
@@ -181,10 +187,6 @@ __global__ __launch_bounds__(256) void k_vis_prepare(SceneView sc, FaceBatch fb,
         lo0 = fmin(lo0, a); hi0 = fmax(hi0, a);
         lo1 = fmin(lo1, p); hi1 = fmax(hi1, p);
         lo2 = fmin(lo2, r); hi2 = fmax(hi2, r);
-    }
-    if (!(zmax > TOL_DZ)) {  // geometry.py:967-970
-        *out = m;
-        return;
     }
     const double cx = (lo0 + hi0) / 2, cy = (lo1 + hi1) / 2, cz = (lo2 + hi2) / 2;
     m.key1 = rmin;  // geometry.py:980-984
