@@ -212,6 +212,20 @@ int rt_channel_stats(int device, int64_t n_groups, const int64_t *group_off, con
                      const double *el_deg, const double *az_deg, const double *xyz, const uint8_t *is_los,
                      int32_t n_strongest, double power_percent, double *out, int on_device);
 
+/* ---- radiomap of the result table (electromagnetism_fun/scenario_measures.py:31-88) ----------------------------------
+ * What compare_radiomaps computes before it draws: z = griddata(receivers, powers, (x, y), method="linear",
+ * fill_value) (:66) and mask = street.contains(Point(x, y)) (:54) for every point of the regular grid (:49-53).
+ * values[n_points]: per-receiver power [dB].  The Delaunay triangulation of the receivers is the caller's (Qhull, as
+ * scipy holds it): triangles[n_triangles*3] vertex indices and transform[n_triangles*6] = per triangle the row-major
+ * inverse of [a - c, b - c] followed by c (scipy.spatial.Delaunay.transform; NaN marks a degenerate triangle).
+ * query[n_query*2]: grid points.  out_values[n_query] (or NULL): barycentric interpolation in the triangle that holds
+ * the point to 100 machine epsilons, summed in scipy's order without fused operations; fill_value outside every
+ * triangle.  ring[n_ring*2] (no closing vertex, no holes) and out_inside[n_query] (or both NULL): 1 where the point is
+ * strictly inside the ring, 0 on its boundary and outside (shapely's contains).  Host pointers. */
+int rt_radiomap(int device, int64_t n_points, const double *values, int64_t n_triangles, const int32_t *triangles,
+                const double *transform, int64_t n_query, const double *query, double fill_value, double *out_values,
+                int32_t n_ring, const double *ring, uint8_t *out_inside);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "rt_describe_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "rt_channel_stats": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int32, c_double, c_void_p, c_int]),
+    "rt_radiomap": (c_int, [c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_double, c_void_p,
+                            c_int32, c_void_p, c_void_p]),
     "rt_fields": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_int]),
@@ -474,3 +476,29 @@ def channel_stats(group_off, power, time, el_deg, az_deg, xyz, is_los, n_stronge
                                     _ptr(los) if n else None, int(n_strongest), float(power_percent), _ptr(out), 0),
                "rt_channel_stats")
     return out
+
+
+def radiomap(values, triangles, transform, query, fill_value, ring=None, interpolate=True, device=None):
+    """Linear interpolation of per-receiver values over a triangulation at the query points, and (with a ring) which
+    query points lie strictly inside it (see rt_radiomap): returns (values or None, inside or None)."""
+    lib = require_gpu()
+    query = _f64(query).reshape(-1, 2)
+    q = len(query)
+    out = inside = None
+    vals = tris = tr = None
+    if interpolate:
+        vals = _f64(values).reshape(-1)
+        tris = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        tr = _f64(transform).reshape(-1, 6)
+        if len(tr) != len(tris):
+            raise ValueError("radiomap: one transform per triangle")
+        out = np.full(q, float(fill_value), dtype=np.float64)
+    if ring is not None:
+        ring = _f64(ring).reshape(-1, 2)
+        inside = np.zeros(q, dtype=np.uint8)
+    if q:
+        _check(lib.rt_radiomap(default_device() if device is None else device, len(vals) if interpolate else 0,
+                               _ptr(vals), len(tris) if interpolate else 0, _ptr(tris), _ptr(tr), q, _ptr(query),
+                               float(fill_value), _ptr(out), len(ring) if ring is not None else 0, _ptr(ring),
+                               _ptr(inside)), "rt_radiomap")
+    return out, (inside.astype(bool) if inside is not None else None)

@@ -9,7 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libraytracing_amd.so")
-SOURCES = ["scene.hip", "occlusion.hip", "solve.hip", "visibility.hip", "sharp_edges.hip", "fields.hip", "channel_stats.hip"]
+SOURCES = ["scene.hip", "occlusion.hip", "solve.hip", "visibility.hip", "sharp_edges.hip", "fields.hip", "channel_stats.hip",
+           "radiomap.hip"]
 HEADERS = ["rt_common.h", "rt_candidates.h", "rt_fresnel.h", os.path.join("..", "..", "include", "rt_pathsolve.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
