@@ -102,6 +102,20 @@ def small_place(n_rx=16):
     return place, tx, rx
 
 
+def two_rays_place(npoints=20):
+    """The reference's create_two_rays_place (electromagnetism_fun/place_utils.py:106-123): a concrete ground of
+    (npoints + 50) m x 24 m turned to face up, TX (5, 12, 30), receivers (55 + i, 12, 10)."""
+    from .materials_properties import set_properties
+
+    ground = geom.Square.by_2_corner_points(np.array([[0.0, 0.0, 0.0], [1.0 * npoints + 50.0, 24.0, 0.0]]))
+    ground = ground.rotate(axis=np.array([0, 1, 0]), angle_deg=180)
+    ground.properties = set_properties("road")
+    place = geom.OrientedPlace(geom.OrientedSurface(ground))
+    tx = np.array([5.0, 12.0, 30.0])
+    rx = np.array([tx + np.array([50.0 + i, 0.0, -20.0]) for i in range(npoints)])
+    return place, tx, rx
+
+
 def levant_grid(n_side=32):
     """Config 2: data/place_levant.geojson, TX above the scene centre at 18.7 m, n_side² receivers at 1.2 m."""
     place = geom.load_place(os.path.join(DATA_DIR, "place_levant.geojson"))
