@@ -180,6 +180,28 @@ class RayTracingProblem:
                 f"los: {len(self.los)}, reflections: {len(self.reflections)}, diffractions : {len(self.diffractions)}")
 
     # ---- on-disk format of the reference (:66-132) -------------------------------------------------------
+    def __eq__(self, other):
+        """The reference's comparison (ray_tracing.py:146-200): emitter, screens, emitter visibility, receivers, solved
+        receivers, screen distance, sharp edges, and the receiver keys of the three result dictionaries (it does not
+        look inside them)."""
+        if not isinstance(other, RayTracingProblem):
+            return False
+        if not np.array_equal(self.emitter, other.emitter) or self.n_screens != other.n_screens:
+            return False
+        if not np.array_equal(self.emitter_visibility, other.emitter_visibility):
+            return False
+        if not np.array_equal(self.receivers, other.receivers):
+            return False
+        if not np.array_equal(np.asarray(self.solved_receivers, dtype=object if self.solved_receivers is None else float),
+                              np.asarray(other.solved_receivers, dtype=object if other.solved_receivers is None else float)):
+            return False
+        if self.distance_to_screen != other.distance_to_screen or not self.sharp_edges == other.sharp_edges:
+            return False
+        return all(all(a == b for a, b in zip(mine, theirs)) for mine, theirs in
+                   ((self.los, other.los), (self.reflections, other.reflections), (self.diffractions, other.diffractions)))
+
+    __hash__ = object.__hash__
+
     def to_json(self, filename):
         def plain(obj):
             """Nested containers of arrays as nested lists (one C-level tolist() per array)."""
