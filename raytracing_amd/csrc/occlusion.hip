@@ -469,9 +469,10 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     const int64_t n_grid = d_count ? (n_hint < 1 ? 1 : (n_hint > n_item ? n_item : n_hint)) : n_item;
     int64_t grid = (n_grid + block - 1) / block;
     if (grid > (1 << 20)) grid = 1 << 20;  // the kernel strides over the rest
-    // few items: split the polygon list over grid.y so the launch still fills the chip (target >= ~2048 waves)
+    // few items: split the polygon list over grid.y so the launch still fills the chip (target >= ~4096 waves)
     const int64_t waves = grid * (block / RT_WAVE);
-    int64_t ny = waves >= 2048 ? 1 : (2048 + waves - 1) / waves;
+    const int64_t target_waves = 4096;  // measured on 10 402 segments x 237 polygons: 1 024: 34 us, 2 048: 33, 4 096: 30, 8 192: 31
+    int64_t ny = waves >= target_waves ? 1 : (target_waves + waves - 1) / waves;
     const int64_t max_ny = (scene->view.n + 7) / 8;
     ny = ny > max_ny ? max_ny : ny;
     ny = ny < 1 ? 1 : ny;

@@ -102,6 +102,28 @@ def small_place(n_rx=16):
     return place, tx, rx
 
 
+def dummy_place():
+    """The reference's create_dummy_place (electromagnetism_fun/place_utils.py:76-103): a 70 m x 24 m road at 10 m
+    elevation with three 4 m x 2 m x 10 m blocks along its sides, TX (5, 12, 15), one receiver at (65, 12, 15)."""
+    from .materials_properties import set_properties
+
+    z0 = 10.0
+    ground = geom.Square.by_2_corner_points(np.array([[0.0, 0.0, z0], [70.0, 24.0, z0]]))
+    ground = ground.rotate(axis=np.array([0, 1, 0]), angle_deg=180)
+    ground.properties = set_properties("road")
+    buildings = []
+    for (x0, y0), (x1, y1) in (((13.0, 22.0), (17.0, 24.0)), ((33.0, 0.0), (37.0, 2.0)), ((53.0, 22.0), (57.0, 24.0))):
+        square = geom.Square.by_2_corner_points(np.array([[x0, y0, z0], [x1, y1, z0]]))
+        building = geom.Building.by_polygon_and_height(polygon=square, height=10)
+        building.building_type = "appartments"
+        building.apply_properties_to_polygons()
+        buildings.append(building)
+    place = geom.OrientedPlace(geom.OrientedSurface(ground), buildings)
+    tx = np.array([5.0, 12.0, z0 + 5.0])
+    rx = np.array([[65.0, 12.0, z0 + 5.0]])
+    return place, tx, rx
+
+
 def two_rays_place(npoints=20):
     """The reference's create_two_rays_place (electromagnetism_fun/place_utils.py:106-123): a concrete ground of
     (npoints + 50) m x 24 m turned to face up, TX (5, 12, 30), receivers (55 + i, 12, 10)."""

@@ -93,3 +93,35 @@ def test_gpu_two_ray_model_over_frequency(freq):
     assert not res["status"].any()
     want = np.array([two.two_rays_db(np.linalg.norm(r[:2] - tx[:2]), tx[2], r[2], frequency=freq) for r in rx])
     np.testing.assert_allclose(res["power_db"][:, 0], want, rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_dummy_place_against_the_oracle(tmp_path, monkeypatch):
+    """The reference's create_dummy_place (place_utils.py:76-103: a road at 10 m with three blocks, one receiver 60 m
+    down the road): same paths as the oracle with exact roots, received power within 0.01 dB."""
+    from raytracing_amd import electromagnetism as em
+    from raytracing_amd import electromagnetism_utils as emu
+    from raytracing_amd import scenarios
+    from raytracing_amd.ray_tracing import RayTracingProblem
+
+    monkeypatch.setenv("RAYTRACING_AMD_RESULTS", str(tmp_path))
+    place, tx, rx = scenarios.dummy_place()
+    place.add_set_of_points(rx)
+    problem = RayTracingProblem(tx.reshape(1, 3), place)
+    problem.solve(max_order=2)
+    polys = oracle_polys(place)
+    ids = {}
+    for p, q in zip(polys, place.get_polygons_list()):
+        p.building = ids.setdefault(q.building_id, len(ids))
+    assert len(polys) == 19
+    oracle = ro.RayTracingOracle(tx, polys, rx, solver="exact")
+    oracle.solve(max_order=2)
+    np.testing.assert_array_equal(problem.visibility_matrix, oracle.visibility_matrix)
+    assert problem.path_set() == oracle.path_set()
+    kinds = sorted(k[1] + str(k[2]) for k in problem.path_set())
+    assert kinds.count("LOS0") == 1 and kinds.count("R1") == 2  # the road and the wall of the middle block
+    df = em.my_field_computation(problem, "dummy")
+    rows = eo.FieldOracle(polys).field_computation(oracle, rx)
+    got = emu.get_power_db_each_receiver(df)
+    want = eo.power_db_each_receiver(rows, len(rx))
+    assert np.abs(got - want).max() <= 0.01
