@@ -356,13 +356,19 @@ class Scene:
                            capacity):
         """Device-pointer form of ``rt_solve_paths`` (receivers and outputs already in this GPU's memory).
         Returns (n_found, n_attempted)."""
-        tx = _f64(tx).reshape(3)
-        found = np.zeros(1, dtype=np.int64)
-        attempted = np.zeros(1, dtype=np.int64)
-        _check(load().rt_solve_paths(self.handle, candidates.handle, _ptr(tx), rx_ptr, int(n_rx), out_rx_ptr,
-                                     out_group_ptr, out_cand_ptr, out_points_ptr, int(capacity), _ptr(found),
-                                     _ptr(attempted), 1), "rt_solve_paths")
-        return int(found[0]), int(attempted[0])
+        # a solve of a thousand receivers lasts 70 us: the two result words and the emitter's array are kept between
+        # calls instead of being made anew (a few microseconds of NumPy per call)
+        try:
+            res, res_ptr, tx_buf, tx_ptr, fn = self._solve_call
+        except AttributeError:
+            res, tx_buf = np.zeros(2, dtype=np.int64), np.zeros(3, dtype=np.float64)
+            res_ptr, tx_ptr, fn = res.ctypes.data, tx_buf.ctypes.data, load().rt_solve_paths
+            self._solve_call = (res, res_ptr, tx_buf, tx_ptr, fn)
+        tx_buf[:] = np.asarray(tx, dtype=np.float64).reshape(3)
+        if fn(self.handle, candidates.handle, tx_ptr, rx_ptr, n_rx, out_rx_ptr, out_group_ptr, out_cand_ptr,
+              out_points_ptr, capacity, res_ptr, res_ptr + 8, 1) != 0:
+            _check(-1, "rt_solve_paths")
+        return int(res[0]), int(res[1])
 
     def fields(self, tx, rx, path_rx, path_kind, path_chain, path_edge_polys, path_edge_points, path_points,
                frequencies, tx_gain=1.0, rx_gain=1.0, p_in=1.0, isotropic=True, alpha=10, aim_tx=None, aim_rx=None,
