@@ -48,8 +48,15 @@ __device__ __forceinline__ bool item_segment(const ObstructItems &it, int64_t &i
         B = ld3(it.segs + 6 * seg + 3);
     } else {
         const int e = p.npts - it.round;  // the segment ends at point e, npts standing for the receiver
-        B = e >= p.npts ? ld3(it.rx + 3 * (int64_t)p.rx) : ld3(p.pts + 3 * e);
-        A = e >= 1 ? ld3(p.pts + 3 * (e - 1)) : it.tx;
+        // (A before B on every route through this function: with the two written in different orders the optimiser
+        // merged the stores of the routes through pointers into the two structs and left both in scratch memory,
+        // 40 bytes per lane written and read back by every wave)
+        const double *b = e >= p.npts ? it.rx + 3 * (int64_t)p.rx : p.pts + 3 * e;
+        const d3 bb = ld3(b);
+        d3 a = it.tx;
+        if (e >= 1) a = ld3(p.pts + 3 * (e - 1));
+        A = a;
+        B = bb;
     }
     return true;
 }

@@ -544,6 +544,26 @@ __device__ inline bool reflect_exact(const SceneView &sc, const int32_t *__restr
     return norm3(a - R) >= MIN_DISTANCE_TOL;
 }
 
+// The reflection points of a pair that reflect_exact has passed: its image construction alone (same arithmetic, same
+// points), without the checks.  For the lanes that write a survivor out, which are not the lanes that solved it.
+template <int K>
+__device__ inline void reflect_points(const SceneView &sc, const int32_t *__restrict__ chains, int64_t c, d3 tx, d3 R,
+                                      d3 *X) {
+    d3 nrm[K], img[K];
+    double g[K];
+    d3 prev = tx;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const double *pl = sc.planes + 4 * (size_t)chains[c * K + i];
+        nrm[i] = ld3(pl);
+        const double s = pl[3] + dot(prev, nrm[i]);
+        img[i] = prev - (2.0 * s) * nrm[i];
+        g[i] = -s;
+        prev = img[i];
+    }
+    (void)unfold_exact<K>(nrm, g, img, R, X);
+}
+
 // Queue record and segments of a surviving reflection path.
 template <int K>
 __device__ inline void reflect_emit(const Queues &q, int64_t ps, int64_t ss, int group, int64_t c, int64_t r, d3 tx, d3 R,
@@ -579,11 +599,13 @@ __device__ inline void reflect_emit(const Queues &q, int64_t ps, int64_t ss, int
 // the end of the block with ONE reservation in the path and segment queues for the whole block: atomics on one
 // address serialise at about 10 ns each, which a reservation per wave and exact batch made the longest part of a
 // small launch.  A wave whose survivor list fills up before that writes 64 of them out on its own.
+#define REFLECT_MAX_RX_TILE 32
 struct ReflectShared {
     uint32_t wave_queue[4][128];  // pairs waiting for the exact solve: lane << 16 | receiver within the tile
     uint32_t survivors[4][128];   // same encoding
     int n_survivors[4];
     long long base[2];
+    double rx[3 * REFLECT_MAX_RX_TILE];  // the receivers of the block's tile
 };
 
 template <int K>
@@ -593,7 +615,7 @@ __device__ __forceinline__ void reflect_write(const SceneView &sc, const int32_t
     const int64_t rr = r_begin + (e & 0xffffu);
     const d3 R = ld3(rx + 3 * rr);
     d3 X[K];
-    (void)reflect_exact<K>(sc, chains, c_base + (e >> 16), tx, R, X);
+    reflect_points<K>(sc, chains, c_base + (e >> 16), tx, R, X);
     reflect_emit<K>(q, ps, ss, group, c_base + (e >> 16), rr, tx, R, X);
 }
 
@@ -602,6 +624,12 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
                                               int group, d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t rx1,
                                               int rx_tile, const Queues &q, unsigned block_x, ReflectShared &sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r_begin = rx0 + (int64_t)blockIdx.y * rx_tile;
+    const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
+    // The tile's receivers go to LDS first: the pre-test loop below reads a receiver per pair, the same one in every
+    // lane, and fetched from global memory trip by trip that wait was most of the loop (10.6 us of a 28 us launch over
+    // 1 024 receivers x 2 937 candidates).  The load is in flight while the lanes form their images of the emitter.
+    if ((int)threadIdx.x < 3 * (int)(r_end - r_begin)) sh.rx[threadIdx.x] = rx[3 * r_begin + threadIdx.x];
     const int64_t c_base = (int64_t)block_x * blockDim.x + wave * 64;
     const int64_t c = c_base + lane;
     const bool active = c < count;
@@ -625,8 +653,7 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
     const double u_lo = ur[6], v_lo = ur[7], u_hi = ur[8], v_hi = ur[9];
     const double imu = dot(im, fu), imv = dot(im, fv);
 
-    const int64_t r_begin = rx0 + (int64_t)blockIdx.y * rx_tile;
-    const int64_t r_end = r_begin + rx_tile < rx1 ? r_begin + rx_tile : rx1;
+    __syncthreads();  // sh.rx
     int qn = 0, sn = 0;  // wave-uniform
     uint32_t *wq = sh.wave_queue[wave], *ws = sh.survivors[wave];
     // exact solve of the queue entry e of every lane that has one; survivors go to the wave's list
@@ -654,7 +681,7 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t r = r4 + j < r_end ? r4 + j : r_end - 1;
-            const d3 R = ld3(rx + 3 * r);  // wave-uniform
+            const d3 R = ld3(sh.rx + 3 * (r - r_begin));  // the same address in every lane
             const d3 dir = R - im;
             const double t = -gk * fast_rcp_s(dot(dir, nk));
             const double pad = 2e-5 * fmax(fabs(dir.x), fmax(fabs(dir.y), fabs(dir.z))) + 2e-6;
@@ -786,7 +813,7 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
                 const int64_t rr = r0 + (w & 0x3ffffffu);
                 const d3 R = ld3(rt.rxs + 3 * rr);
                 d3 X[K];
-                (void)reflect_exact<K>(sc, chains, c_base + (w >> 26), tx, R, X);
+                reflect_points<K>(sc, chains, c_base + (w >> 26), tx, R, X);
                 reflect_emit<K>(q, ps, ss, group, c_base + (w >> 26), rt.perm[rr], tx, R, X);
             }
             __builtin_amdgcn_wave_barrier();
@@ -914,7 +941,7 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
         const int64_t rr = r0 + (w & 0x3ffffffu);
         const d3 R = ld3(rt.rxs + 3 * rr);
         d3 X[K];
-        (void)reflect_exact<K>(sc, chains, c_base + (w >> 26), tx, R, X);
+        reflect_points<K>(sc, chains, c_base + (w >> 26), tx, R, X);
         reflect_emit<K>(q, sh.base[0] + before + lane, sh.base[1] + (int64_t)(before + lane) * (K + 1), group,
                         c_base + (w >> 26), rt.perm[rr], tx, R, X);
     }
@@ -1670,8 +1697,11 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     // hundred blocks (measured on 1 024 receivers x 2 936 candidates: 42 us with 4, 34 us with 32)
     int64_t cand_blocks = 0;
     for (const CandGroup &g : cand->groups) cand_blocks += blocks_for(g.count, 256);
-    int rx_tile = (int)std::min<int64_t>(32, std::max<int64_t>(4, chunk * std::max<int64_t>(cand_blocks, 1) / 512));
-    rx_tile &= ~3;
+    // (rounded up to the loop's four receivers per trip: rounded down, 1 024 receivers x 13 candidate blocks made 559
+    // blocks, three on some compute units and two on the others, and the launch lasted as long as three)
+    int rx_tile = (int)std::min<int64_t>(REFLECT_MAX_RX_TILE,
+                                         std::max<int64_t>(4, (chunk * std::max<int64_t>(cand_blocks, 1) + 511) / 512));
+    rx_tile = std::min(REFLECT_MAX_RX_TILE, (rx_tile + 3) & ~3);
     chunk = std::min<int64_t>(chunk, 65535ll * rx_tile);  // grid.y of the candidate kernels
 
     // Large batches: the candidate kernels work on receivers sorted into spatial tiles (the reflection kernel rejects
