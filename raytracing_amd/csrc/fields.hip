@@ -13,7 +13,7 @@
 #include "rt_common.h"
 #include "rt_fresnel.h"
 
-#define N_MATERIALS 7
+#define N_MATERIALS RT_N_MATERIALS
 #define MAX_FREQ 16
 
 struct FreqTable {

@@ -47,6 +47,9 @@ void rt_set_error(const std::string &msg);
 // ---------------------------------------------------------------------------------------------------------------
 // One polygon as the obstruction pre-test wants it, 64 bytes: plane in fp64, box in fp32 relative to the grid origin
 // and rounded outwards (the pre-test only has to be conservative).
+// rows of the material table of the field step (materials_properties.py:47-109); a scene's material ids index it
+#define RT_N_MATERIALS 7
+
 struct OccRec {
     double nx, ny, nz, d;
     float lo[3], hi[3];

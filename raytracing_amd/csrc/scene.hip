@@ -220,6 +220,17 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
         rt_set_error("rt_scene_create: no such device " + std::to_string(device));
         return nullptr;
     }
+    if (vert_off[0] != 0) {
+        rt_set_error("rt_scene_create: vertex offsets must start at 0");
+        return nullptr;
+    }
+    for (int i = 0; material_id && i < n_poly; ++i) {
+        if (material_id[i] < 0 || material_id[i] >= RT_N_MATERIALS) {  // the field kernel indexes its table with it
+            rt_set_error("rt_scene_create: polygon " + std::to_string(i) + " has material id " +
+                         std::to_string(material_id[i]) + ", outside the table of " + std::to_string(RT_N_MATERIALS));
+            return nullptr;
+        }
+    }
     for (int i = 0; i < n_poly; ++i) {
         if (vert_off[i + 1] - vert_off[i] < 3) {
             rt_set_error("rt_scene_create: polygon " + std::to_string(i) + " has fewer than 3 vertices");
