@@ -19,6 +19,7 @@ import json
 import math
 import random
 import re
+import os
 import uuid
 
 import numpy as np
@@ -94,6 +95,12 @@ def _json_data(data, filename):
     return dict(data)
 
 
+def _random_id():
+    """A random identifier in the layout of str(uuid.uuid4()) (a scene makes ten thousand of them)."""
+    h = os.urandom(16).hex()
+    return f"{h[:8]}-{h[8:12]}-4{h[13:16]}-{h[16:20]}-{h[20:]}"
+
+
 class OrientedGeometry:
     """Base container (reference geometry.py:1093-1507): id, attributes and cached bounding box."""
 
@@ -101,7 +108,7 @@ class OrientedGeometry:
         self.attributes = attributes
         self.id = attributes.pop("id", None)
         if self.id is None:
-            self.id = str(uuid.uuid4())
+            self.id = _random_id()
         self.domain = None
         self.centroid = None
         self.visibility_matrix = None
@@ -467,7 +474,7 @@ class Building(OrientedPolyhedron):
         for i in range(n):
             a, b = top_points[i - 1], top_points[i]
             c, d = walls_bottom[i - 1], walls_bottom[i]
-            polygons.append(OrientedPolygon(np.vstack([a, c, d, b])))
+            polygons.append(OrientedPolygon(np.array([a, c, d, b])))
         return OrientedPolyhedron(polygons, id=id)
 
     @staticmethod

@@ -110,18 +110,26 @@ def material_of_building_type(building_type):
     return _BUILDING_TYPE_TO_MATERIAL.get(building_type, "concrete")
 
 
+_PROPERTIES_CACHE = {}
+
+
 def set_properties(building_type, frequency=FREQUENCY):
-    """Dict of STRINGS describing the material of a building type, as the reference returns it (:112-143)."""
+    """Dict of STRINGS describing the material of a building type, as the reference returns it (:112-143).  Every call
+    returns a dict of its own (the strings of a (type, frequency) pair are formed once: a scene asks once per polygon)."""
     material = material_of_building_type(building_type)
     if building_type not in _BUILDING_TYPE_TO_MATERIAL:
         print(f"Properties for the type {building_type} have not been specified, using concrete")
-    rec = next(r for r in material_records(frequency) if r["material"] == material)
-    eps_eff = np.complex128(epsilon_eff(rec["epsilon"], rec["sigma"], frequency))
-    return {
-        "material": material,
-        "mu": str(np.int64(rec["mu"])),
-        "epsilon": str(np.float64(rec["epsilon"])),
-        "sigma": str(np.float64(rec["sigma"])),
-        "roughness": str(np.float64(rec["roughness"])),
-        "epsilon_eff": str(eps_eff),
-    }
+    key = (material, float(frequency))
+    cached = _PROPERTIES_CACHE.get(key)
+    if cached is None:
+        rec = next(r for r in material_records(frequency) if r["material"] == material)
+        eps_eff = np.complex128(epsilon_eff(rec["epsilon"], rec["sigma"], frequency))
+        cached = _PROPERTIES_CACHE[key] = {
+            "material": material,
+            "mu": str(np.int64(rec["mu"])),
+            "epsilon": str(np.float64(rec["epsilon"])),
+            "sigma": str(np.float64(rec["sigma"])),
+            "roughness": str(np.float64(rec["roughness"])),
+            "epsilon_eff": str(eps_eff),
+        }
+    return dict(cached)
