@@ -178,6 +178,12 @@ class Candidates:
                                         _ptr(edge_polys), _ptr(edge_points), 0), "rt_describe_paths")
         return kind, chain, edge_polys, edge_points
 
+    def describe_device(self, group_ptr, cand_ptr, n, kind_ptr, chain_ptr, edge_polys_ptr, edge_points_ptr):
+        """Device-pointer form of ``describe``: (group, candidate) pairs as ``rt_solve_paths`` left them in this GPU's
+        memory; kind i32[n], chain i32[n, RT_MAX_ORDER], edge_polys i32[n, 2], edge_points f64[n, 6] written there."""
+        _check(load().rt_describe_paths(self.handle, group_ptr, cand_ptr, int(n), kind_ptr, chain_ptr, edge_polys_ptr,
+                                        edge_points_ptr, 1), "rt_describe_paths")
+
     @property
     def total(self):
         return int(self.counts.sum())
@@ -415,6 +421,20 @@ class Scene:
                "rt_fields")
         cfield = field[..., 0::2] + 1j * field[..., 1::2]
         return dict(field=cfield, power=power, angles=angles, time=time, status=status, power_db=power_db)
+
+    def fields_device(self, tx, rx_ptr, n_rx, path_rx_ptr, kind_ptr, chain_ptr, edge_polys_ptr, edge_points_ptr,
+                      points_ptr, n_paths, frequencies, field_ptr, power_ptr, angles_ptr, time_ptr, status_ptr,
+                      power_db_ptr, tx_gain=1.0, rx_gain=1.0, p_in=1.0, isotropic=True, alpha=10):
+        """Device-pointer form of ``rt_fields``: the per-path arrays as ``rt_solve_paths`` and ``describe_device`` left
+        them in this GPU's memory, the outputs written there (field f64[P, F, 6], power f64[P, F], angles f64[P, 4],
+        time f64[P], status i32[P], power_db f64[R, F]); the emitter and the frequencies are host values."""
+        tx = _f64(tx).reshape(3)
+        freqs = _f64(np.atleast_1d(frequencies))
+        ap = AntennaParams(float(tx_gain), float(rx_gain), float(p_in), int(bool(isotropic)), int(alpha))
+        _check(load().rt_fields(self.handle, _ptr(tx), rx_ptr, int(n_rx), path_rx_ptr, kind_ptr, chain_ptr,
+                                edge_polys_ptr, edge_points_ptr, points_ptr, int(n_paths), _ptr(freqs), len(freqs),
+                                ctypes.byref(ap), None, field_ptr, power_ptr, angles_ptr, time_ptr, status_ptr,
+                                power_db_ptr, 1), "rt_fields")
 
     def last_timing(self):
         ms = np.zeros(4, dtype=np.float64)

@@ -255,3 +255,76 @@ def test_tree_crowns_attenuate_every_segment_they_cross(tmp_path, monkeypatch):
             attenuated[want["path_type"]] = attenuated.get(want["path_type"], 0) + 1
     # the crowns matter in this scene: lines of sight, reflected and diffracted paths lose more than 1 dB to them
     assert attenuated.get("LOS", 0) >= 1 and sum(v for k, v in attenuated.items() if k != "LOS") >= 3, attenuated
+
+
+def test_device_pointer_route_equals_host_array_route(places):
+    """Solve, path description and fields through the device-pointer entry points (nothing but the result leaves the
+    GPU) against the host-array entry points on the same scene: same paths, same fields, same dB per receiver."""
+    import torch
+
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+
+    place = places("small")
+    tx, rx = small_tx_rx(16)
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+    freqs = [3.6e9, 28e9]
+    # host arrays
+    res = scene.solve_paths(cand, tx, rx)
+    n = len(res["rx"])
+    keep = res["group"] >= 0
+    kind = np.zeros(n, dtype=np.int32)
+    chain = np.zeros((n, _lib.RT_MAX_ORDER), dtype=np.int32)
+    epolys = np.zeros((n, 2), dtype=np.int32)
+    epts = np.zeros((n, 6))
+    kind[keep], chain[keep], epolys[keep], epts[keep] = cand.describe(res["group"][keep], res["cand"][keep])
+    want = scene.fields(tx, rx, res["rx"], kind, chain, epolys, epts, res["points"], freqs)
+    # device pointers
+    dev = torch.device("cuda", 0)
+    d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
+    cap = 4096
+    o_rx = torch.empty(cap, dtype=torch.int32, device=dev)
+    o_group, o_cand = torch.empty_like(o_rx), torch.empty_like(o_rx)
+    o_pts = torch.empty((cap, _lib.RT_MAX_ORDER, 3), dtype=torch.float64, device=dev)
+    found, _ = scene.solve_paths_device(cand, tx, d_rx.data_ptr(), len(rx), o_rx.data_ptr(), o_group.data_ptr(),
+                                        o_cand.data_ptr(), o_pts.data_ptr(), cap)
+    assert found == n > 100
+    d_kind = torch.empty(n, dtype=torch.int32, device=dev)
+    d_chain = torch.empty((n, _lib.RT_MAX_ORDER), dtype=torch.int32, device=dev)
+    d_epolys = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    d_epts = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    cand.describe_device(o_group.data_ptr(), o_cand.data_ptr(), n, d_kind.data_ptr(), d_chain.data_ptr(),
+                         d_epolys.data_ptr(), d_epts.data_ptr())
+    nf = len(freqs)
+    d_field = torch.empty((n, nf, 6), dtype=torch.float64, device=dev)
+    d_power = torch.empty((n, nf), dtype=torch.float64, device=dev)
+    d_angles = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    d_time = torch.empty(n, dtype=torch.float64, device=dev)
+    d_status = torch.empty(n, dtype=torch.int32, device=dev)
+    d_db = torch.empty((len(rx), nf), dtype=torch.float64, device=dev)
+    scene.fields_device(tx, d_rx.data_ptr(), len(rx), o_rx.data_ptr(), d_kind.data_ptr(), d_chain.data_ptr(),
+                        d_epolys.data_ptr(), d_epts.data_ptr(), o_pts.data_ptr(), n, freqs, d_field.data_ptr(),
+                        d_power.data_ptr(), d_angles.data_ptr(), d_time.data_ptr(), d_status.data_ptr(), d_db.data_ptr())
+    # the two solves may list the paths in another order: compare by (receiver, group, candidate)
+    def order(r, g, c):
+        return np.lexsort((c, g, r))
+    a = order(res["rx"], res["group"], res["cand"])
+    b = order(o_rx[:n].cpu().numpy(), o_group[:n].cpu().numpy(), o_cand[:n].cpu().numpy())
+    np.testing.assert_array_equal(res["rx"][a], o_rx[:n].cpu().numpy()[b])
+    np.testing.assert_array_equal(res["cand"][a], o_cand[:n].cpu().numpy()[b])
+    np.testing.assert_array_equal(kind[a], d_kind.cpu().numpy()[b])
+    paths = res["group"][a] >= 0  # the host arrays of the lines of sight above were left at zero, the device form writes -1
+    np.testing.assert_array_equal(chain[a][paths], d_chain.cpu().numpy()[b][paths])
+    np.testing.assert_array_equal(want["status"][a], d_status.cpu().numpy()[b])
+    np.testing.assert_array_equal(want["power"][a], d_power.cpu().numpy()[b])
+    np.testing.assert_array_equal(want["angles"][a], d_angles.cpu().numpy()[b])
+    # the per-receiver sums are accumulated with atomics: the order of the additions differs
+    np.testing.assert_allclose(d_db.cpu().numpy(), want["power_db"], rtol=0, atol=1e-9)
+    cand.close()
+    scene.close()
