@@ -793,6 +793,36 @@ __device__ inline bool faces_viewer(const SceneView &sc, const FaceBatch &fb, in
     return false;
 }
 
+// The order in which the persistent workgroups take the faces: the ones with the most candidates first (1 024 classes of
+// the candidate count, most first; inside a class in whatever order the atomics give, which changes no result: faces are
+// independent).  A face with thousands of candidates lasts a hundred times as long as a wall with a few dozen, and taken
+// last it would keep one compute unit busy long after the others have run out of faces.
+__global__ __launch_bounds__(1024) void k_face_queue(const int32_t *__restrict__ counts, int n_faces, int n_poly,
+                                                      int32_t *__restrict__ queue) {
+    __shared__ int hist[1024];
+    __shared__ int start[1024];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long scale = n_poly > 0 ? n_poly : 1;
+    for (int f = threadIdx.x; f < n_faces; f += 1024) {
+        const int cls = (int)((long long)counts[f] * 1023 / scale);
+        atomicAdd(&hist[1023 - (cls < 0 ? 0 : (cls > 1023 ? 1023 : cls))], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < 1024; ++b) {
+            start[b] = acc;
+            acc += hist[b];
+        }
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < n_faces; f += 1024) {
+        const int cls = (int)((long long)counts[f] * 1023 / scale);
+        queue[atomicAdd(&start[1023 - (cls < 0 ? 0 : (cls > 1023 ? 1023 : cls))], 1)] = f;
+    }
+}
+
 // One workgroup (NW waves: four when many faces are painted at once, sixteen for a handful) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
 // polygons whose box meets it and stages them in LDS; all waves then decide coverage together.
 template <typename Store, int NW>
@@ -800,7 +830,7 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                                                     const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
                                                     int m_stride, const int32_t *__restrict__ counts, PaintScratch ps,
                                                     int strict, unsigned long long *work_counter,
-                                                    uint8_t *__restrict__ out) {
+                                                    const int32_t *__restrict__ face_queue, uint8_t *__restrict__ out) {
     __shared__ int lds_counts[NW];
     __shared__ union {
         LocalStore staged;   // used once the face's canvas no longer fits the resident store
@@ -826,7 +856,7 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned long long fq = atomicAdd(work_counter, 1ull);
-            s_face = fq < (unsigned long long)fb.n_faces ? (int)fq : -1;
+            s_face = fq < (unsigned long long)fb.n_faces ? (face_queue ? face_queue[fq] : (int)fq) : -1;
         }
         __syncthreads();
         const int f = s_face;
@@ -1060,7 +1090,8 @@ struct DevBuf {
 
 // Device buffers of one batch of faces: they live until the batch's kernels have run.
 struct RowsJob {
-    DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work;
+    DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work,
+        b_queue;
 };
 
 // Queues, on stream st, the kernels that write the visibility rows of a batch of faces into d_out[n_faces*n] (zeroed
@@ -1088,7 +1119,8 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         b_list.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) || b_canvas.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) ||
         b_cbox.alloc(sizeof(double) * 4 * (size_t)sc.n * n_blocks) || b_splits.alloc(sizeof(double) * (size_t)split_cap * n_waves) ||
         b_counter.alloc(sizeof(unsigned long long)) || b_order.alloc(sizeof(int32_t) * (size_t)m_stride * n_faces) ||
-        b_counts.alloc(sizeof(int32_t) * (size_t)n_faces) || b_work.alloc(sizeof(int32_t) * 2 * (size_t)sc.vtot * n_waves))
+        b_counts.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_queue.alloc(sizeof(int32_t) * (size_t)n_faces) ||
+        b_work.alloc(sizeof(int32_t) * 2 * (size_t)sc.vtot * n_waves))
         RT_FAIL("visibility: out of device memory");
     RT_HIP(hipMemcpyAsync(b_off.p, a_off.data(), sizeof(int32_t) * a_off.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(b_verts.p, a_verts.data(), sizeof(double) * a_verts.size(), hipMemcpyHostToDevice, st));
@@ -1103,17 +1135,23 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     if (!strict)
         hipLaunchKernelGGL(k_vis_sort, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,
                            (int32_t *)b_order.p, m_stride, (int32_t *)b_counts.p);
+    const int32_t *face_queue = nullptr;
+    if (!strict && n_faces > n_blocks) {  // with a workgroup per face there is nothing to order
+        hipLaunchKernelGGL(k_face_queue, dim3(1), dim3(1024), 0, st, (const int32_t *)b_counts.p, n_faces, sc.n,
+                           (int32_t *)job.b_queue.p);
+        face_queue = (const int32_t *)job.b_queue.p;
+    }
     PaintScratch ps{(int32_t *)b_list.p, (int32_t *)b_canvas.p, (double *)b_cbox.p, (double *)b_splits.p, split_cap,
                     (int32_t *)b_work.p};
     // at most one face per CU: the large canvas store (one workgroup per CU) costs no parallelism
     if (n_faces <= 256)
         hipLaunchKernelGGL((k_vis_paint<LargeCanvasStore, 16>), dim3(n_blocks), dim3(1024), 0, st, sc, fb,
                            (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
-                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, d_out);
+                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, face_queue, d_out);
     else
         hipLaunchKernelGGL((k_vis_paint<SmallCanvasStore, 4>), dim3(n_blocks), dim3(256), 0, st, sc, fb,
                            (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
-                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, d_out);
+                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, face_queue, d_out);
     RT_HIP(hipGetLastError());
     return 0;
 }
