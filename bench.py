@@ -204,8 +204,8 @@ def cpu_baseline(place, tx, rx, chains2, budget_s=5.0, receivers_per_core=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the coverage-map-sized extra measurement")
     ap.add_argument("--n-side", type=int, default=32)
