@@ -69,3 +69,40 @@ def polygons_visibility_matrix(polys, rows=None):
     if rows is None:
         matrix = matrix | matrix.T
     return matrix
+
+
+def polygon_visibility_vector_strict(poly_a, polys, self_index=-1):
+    """The strict branch of the reference's polygon_visibility_vector (geometry.py:959-970 then :1004-1017 with the
+    painter of :974-1001 left out): polygon B is kept when, moved to A's frame about the centre of A's box, it reaches
+    z > 1e-4, and some vertex p of A has normalize(p - centre(B)) . n_B > 1e-4.  Plain NumPy.  Parity unpinned: the
+    reference holds no vector of a visibility matrix, strict or not."""
+    from . import geometry_oracle as go
+
+    vis = np.zeros(len(polys), dtype=bool)
+    a_pts = np.asarray(poly_a.points, dtype=float)
+    matrix_a = poly_a.matrix().T                 # :959
+    centre_a = go.centroid(a_pts)                # :960, centre of the bounding box
+    for i, b in enumerate(polys):
+        if i == self_index:                      # :964
+            continue
+        projected = (np.asarray(b.points, dtype=float) - centre_a) @ matrix_a.T   # translate, then project (:963)
+        if not projected[:, 2].max() > 1e-4:     # :967-970
+            continue
+        centre_b, n_b = go.centroid(np.asarray(b.points, dtype=float)), b.normal
+        for p in a_pts:                          # :1004-1014
+            v = p - centre_b
+            nv = np.linalg.norm(v)
+            v = v / nv if nv != 0 else v
+            if np.dot(v, n_b) > 1e-4:
+                vis[i] = True
+                break
+    return vis
+
+
+def polygons_visibility_matrix_strict(polys):
+    """geometry.py:1036-1048 with strict=True."""
+    n = len(polys)
+    m = np.zeros((n, n), dtype=bool)
+    for i, a in enumerate(polys):
+        m[i] = polygon_visibility_vector_strict(a, polys, i)
+    return m | m.T
