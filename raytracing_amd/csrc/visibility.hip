@@ -1295,13 +1295,8 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
             RT_FAIL("rt_visibility_with_faces: self_index out of range");
     }
     RT_HIP(hipSetDevice(scene->device));
-    if (!scene->side_stream) {
-        // a priority of its own: streams of one priority share a few hardware queues in creation order, and two
-        // streams that land on the same queue run one after the other
-        int least = 0, greatest = 0;
-        RT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        RT_HIP(hipStreamCreateWithPriority(&scene->side_stream, hipStreamNonBlocking, greatest));
-    }
+    // a second stream of the default priority (streams of different priorities are not used anywhere in this library)
+    if (!scene->side_stream) RT_HIP(hipStreamCreateWithFlags(&scene->side_stream, hipStreamNonBlocking));
     const size_t n = (size_t)scene->view.n;
     std::vector<int32_t> a_off(face_off, face_off + n_faces + 1), a_self(n_faces, -1);
     if (self_index) a_self.assign(self_index, self_index + n_faces);
