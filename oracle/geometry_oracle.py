@@ -443,11 +443,20 @@ def polygons_sharp_edges(polys, min_angle=10.0):
     normals = [p.normal for p in polys]
     centroids = [centroid(p.points) for p in polys]
     domains = [domain(p.points) for p in polys]
-    for i, j in itertools.combinations(range(len(polys)), 2):
-        normal_A, centroid_A, domain_A = normals[i], centroids[i], domains[i]
-        normal_B, centroid_B, domain_B = normals[j], centroids[j], domains[j]
-        if np.any(np.abs(centroid_A - centroid_B) > np.diff(domain_A, axis=0) + np.diff(domain_B, axis=0)):
-            continue
+    # The proximity test of geometry.py:518-521 is evaluated for all j > i of one i at once (same subtractions,
+    # additions and comparisons as the pair-by-pair form, so the same pairs pass); the rest runs pair by pair.
+    all_centroids = np.array(centroids).reshape(len(polys), 3)
+    all_extents = np.array([np.diff(d, axis=0).reshape(3) for d in domains]).reshape(len(polys), 3)
+
+    def near_pairs():
+        for i in range(len(polys) - 1):
+            far = np.any(np.abs(all_centroids[i] - all_centroids[i + 1:]) > all_extents[i] + all_extents[i + 1:], axis=1)
+            for j in np.flatnonzero(~far):
+                yield i, i + 1 + int(j)
+
+    for i, j in near_pairs():
+        normal_A, centroid_A = normals[i], centroids[i]
+        normal_B, centroid_B = normals[j], centroids[j]
         if abs(np.dot(normal_A, normal_B)) >= max_cos:
             continue
         line_A = np.vstack([centroid_A, centroid_A + normal_A])
