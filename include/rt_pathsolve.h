@@ -47,6 +47,16 @@ int32_t rt_scene_polygon_count(const rt_scene *scene);
  * passes the emitter visibility, ray_tracing.py:232-236); out[n_seg] = 1 when some polygon obstructs. */
 int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t n_seg, const uint8_t *mask, uint8_t *out,
                          int on_device);
+/* rt_obstruct_segments for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Device pointers only (segs[n_seg*6], mask[N] or NULL,
+ * out[n_seg]); calls no hipMalloc / hipFree; the kernels are queued on `stream` (a hipStream_t; NULL = the default
+ * stream) and the call returns WITHOUT waiting for them.  Same flags as rt_obstruct_segments.  The two passes of the
+ * grid walk share a hand-over list that lives in a device array of fixed size owned by the library (16 MiB per GPU,
+ * held until the process ends), so n_seg is limited to 4 194 304 per call (a larger count is refused), and two calls
+ * whose kernels overlap in time on one GPU race on that array: run them one after the other (same stream, or ordered
+ * by events). */
+int rt_obstruct_segments_noalloc(rt_scene *scene, const double *segs, int64_t n_seg, const uint8_t *mask, uint8_t *out,
+                                 void *stream);
 /* return_polygons=True form (geometry.py:868-896): out[N] = 1 for every polygon that cuts the one segment. Host. */
 int rt_segment_hits(rt_scene *scene, const double *seg, uint8_t *out);
 
@@ -91,6 +101,11 @@ int rt_debug_set_path_queue_capacity(rt_scene *scene, int64_t n_paths);
  * events around every launch; a small solve is bound by the latency of its few dependent launches and runs a little
  * faster without them.  rt_solve_last_timing reports zeros while it is off (no reference counterpart). */
 int rt_scene_set_timing(rt_scene *scene, int on);
+/* Device time, in milliseconds, of the last visibility call on this scene (HIP events on the stream the kernels ran on,
+ * while rt_scene_set_timing is on): ms[0] mapping to (azimuth, polar) and ring validity, ms[1] sorting by the painter's
+ * key, ms[2] painting, ms[3] all of it, for the rows / the matrix; ms[4..7] the same for the extra faces of
+ * rt_visibility_with_faces or for rt_faces_visibility.  No reference counterpart. */
+int rt_visibility_last_timing(rt_scene *scene, double *ms8);
 /* Work counters of the visibility painter accumulated since the last call, then zeroed (profiling aid, no reference
  * counterpart): candidates, listed canvas polygons, canvas edges entering a candidate, edge cuts, candidates settled by
  * the interior-sample shortcut, polygons shown visible, canvas-edge examinations, edge examinations. out8[8]. */
@@ -143,7 +158,9 @@ int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double *tx, const
                    int64_t *n_found, int64_t *n_attempted, int on_device);
 /* Device time, in milliseconds, and launch count of each kernel family during the last rt_solve_paths call on this
  * scene (measured with HIP events on the scene's stream): [0] reflection candidates, [1] diffraction candidates,
- * [2] segment obstruction, [3] finalisation.  ms[4], launches[4]. */
+ * [2] segment obstruction, [3] finalisation.  ms[4], launches[4].  *segments_tested = segments the obstruction kernels
+ * walked through the scene (a path that is found blocked on its last segment has its other segments never walked,
+ * and they are not counted). */
 int rt_solve_last_timing(rt_scene *scene, double *ms, int64_t *launches, int64_t *segments_tested);
 
 /* ---- field step: my_field_computation (electromagnetism.py:648-802) --------------------------------------------------
@@ -186,6 +203,9 @@ typedef struct rt_field_options {
     const double *aim_tx, *aim_rx, *path_origin, *path_e_in;
     int32_t n_late_polygons;
 } rt_field_options;
+/* Device time of the last rt_fields call on this scene, in milliseconds (HIP events on the scene's stream, while
+ * rt_scene_set_timing is on): ms[0] the field kernel, ms[1] everything the call queued.  No reference counterpart. */
+int rt_fields_last_timing(rt_scene *scene, double *ms2);
 int rt_describe_paths(rt_candidates *cand, const int32_t *path_group, const int32_t *path_cand, int64_t n_paths,
                       int32_t *out_kind, int32_t *out_chain, int32_t *out_edge_polys, double *out_edge_points,
                       int on_device);

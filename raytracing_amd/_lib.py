@@ -36,6 +36,7 @@ _SIGNATURES = {
     "rt_scene_destroy": (None, [c_void_p]),
     "rt_scene_polygon_count": (c_int32, [c_void_p]),
     "rt_obstruct_segments": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int]),
+    "rt_obstruct_segments_noalloc": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "rt_segment_hits": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rt_contains_points": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_int, c_double, c_void_p, c_int]),
     "rt_face_visibility": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_void_p]),
@@ -61,6 +62,8 @@ _SIGNATURES = {
     "rt_solve_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_void_p, c_void_p, c_int]),
     "rt_solve_last_timing": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rt_fields_last_timing": (c_int, [c_void_p, c_void_p]),
+    "rt_visibility_last_timing": (c_int, [c_void_p, c_void_p]),
     "rt_describe_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "rt_channel_stats": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int32, c_double, c_void_p, c_int]),
@@ -232,6 +235,17 @@ class Scene:
         _check(load().rt_obstruct_segments(self.handle, _ptr(segs), len(segs), _ptr(m), _ptr(out), 0),
                "rt_obstruct_segments")
         return out.astype(bool)
+
+    def obstructed_device(self, segs_ptr, n_seg, mask_ptr, out_ptr):
+        """Device-pointer form of ``obstructed``: segs f64[n_seg, 6], mask u8[N] or None, out u8[n_seg] in this GPU's
+        memory; returns once the flags are written."""
+        _check(load().rt_obstruct_segments(self.handle, segs_ptr, int(n_seg), mask_ptr, out_ptr, 1), "rt_obstruct_segments")
+
+    def obstructed_noalloc(self, segs_ptr, n_seg, mask_ptr, out_ptr, stream=None):
+        """``rt_obstruct_segments_noalloc``: the same flags without any allocation, queued on ``stream`` (a raw
+        hipStream_t, None = the default stream); returns without waiting."""
+        _check(load().rt_obstruct_segments_noalloc(self.handle, segs_ptr, int(n_seg), mask_ptr, out_ptr, stream),
+               "rt_obstruct_segments_noalloc")
 
     def segment_hits(self, segments):
         segs = _f64(segments).reshape(-1, 6)
@@ -424,17 +438,31 @@ class Scene:
 
     def fields_device(self, tx, rx_ptr, n_rx, path_rx_ptr, kind_ptr, chain_ptr, edge_polys_ptr, edge_points_ptr,
                       points_ptr, n_paths, frequencies, field_ptr, power_ptr, angles_ptr, time_ptr, status_ptr,
-                      power_db_ptr, tx_gain=1.0, rx_gain=1.0, p_in=1.0, isotropic=True, alpha=10):
+                      power_db_ptr, tx_gain=1.0, rx_gain=1.0, p_in=1.0, isotropic=True, alpha=10, n_late_polygons=0):
         """Device-pointer form of ``rt_fields``: the per-path arrays as ``rt_solve_paths`` and ``describe_device`` left
         them in this GPU's memory, the outputs written there (field f64[P, F, 6], power f64[P, F], angles f64[P, 4],
         time f64[P], status i32[P], power_db f64[R, F]); the emitter and the frequencies are host values."""
         tx = _f64(tx).reshape(3)
         freqs = _f64(np.atleast_1d(frequencies))
         ap = AntennaParams(float(tx_gain), float(rx_gain), float(p_in), int(bool(isotropic)), int(alpha))
+        opts = FieldOptions(None, None, None, None, int(n_late_polygons)) if n_late_polygons else None
         _check(load().rt_fields(self.handle, _ptr(tx), rx_ptr, int(n_rx), path_rx_ptr, kind_ptr, chain_ptr,
                                 edge_polys_ptr, edge_points_ptr, points_ptr, int(n_paths), _ptr(freqs), len(freqs),
-                                ctypes.byref(ap), None, field_ptr, power_ptr, angles_ptr, time_ptr, status_ptr,
-                                power_db_ptr, 1), "rt_fields")
+                                ctypes.byref(ap), ctypes.byref(opts) if opts is not None else None, field_ptr, power_ptr,
+                                angles_ptr, time_ptr, status_ptr, power_db_ptr, 1), "rt_fields")
+
+    def fields_timing(self):
+        """Device milliseconds of the last ``rt_fields`` call: dict(kernel, call)."""
+        ms = np.zeros(2, dtype=np.float64)
+        _check(load().rt_fields_last_timing(self.handle, _ptr(ms)), "rt_fields_last_timing")
+        return dict(kernel=float(ms[0]), call=float(ms[1]))
+
+    def visibility_timing(self):
+        """Device milliseconds of the last visibility call: dict(rows=dict(prepare, sort, paint, total), faces=...)."""
+        ms = np.zeros(8, dtype=np.float64)
+        _check(load().rt_visibility_last_timing(self.handle, _ptr(ms)), "rt_visibility_last_timing")
+        names = ("prepare", "sort", "paint", "total")
+        return dict(rows={k: float(v) for k, v in zip(names, ms[:4])}, faces={k: float(v) for k, v in zip(names, ms[4:])})
 
     def last_timing(self):
         ms = np.zeros(4, dtype=np.float64)

@@ -711,3 +711,83 @@ extern "C" int rt_contains_points(rt_scene *scene, int32_t polygon, const double
     if (e != hipSuccess) RT_FAIL(std::string("rt_contains_points: ") + hipGetErrorString(e));
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// rt_obstruct_segments for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc).  Same flags as rt_obstruct_segments with device pointers; the grid walk always runs in its two
+// passes here, and what the passes share — the count and the list of the segments still walking after the first —
+// lives in a device array of fixed size that belongs to the library instead of memory allocated per call.
+// ---------------------------------------------------------------------------------------------------------------
+#define RT_NOALLOC_MAX_SEGMENTS (1 << 22) /* 4 194 304 segments per call: a 16 MiB list */
+#define RT_NOALLOC_MAX_DEVICES 64
+
+struct NoAllocScratch {
+    unsigned long long late_count;  // segments handed from the first pass to the second
+    unsigned long long pad_[31];
+    int32_t late_items[RT_NOALLOC_MAX_SEGMENTS];
+};
+
+// One copy per GPU, at its own address on each; held until the process ends.  In host code this name is only a handle
+// for hipGetSymbolAddress: kernels and copies get the address looked up below.
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+static NoAllocScratch *g_scratch_of_device[RT_NOALLOC_MAX_DEVICES];
+
+// Looks up this device's copy of the array (called by rt_scene_create with the scene's device current).
+int rt_noalloc_setup(int device) {
+    if (device < 0 || device >= RT_NOALLOC_MAX_DEVICES) return 0;  // scenes work there, the no-allocation entry does not
+    if (g_scratch_of_device[device]) return 0;
+    void *ptr = nullptr;
+    RT_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) RT_FAIL("rt_noalloc_setup: the scratch array has no device address");
+    g_scratch_of_device[device] = (NoAllocScratch *)ptr;
+    return 0;
+}
+
+// the flags and the hand-over count start at zero (a fill kernel, not a memset node: callers may be capturing)
+__global__ __launch_bounds__(256) void k_noalloc_clear(uint8_t *__restrict__ out, int64_t n, unsigned long long *late_count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *late_count = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0;
+}
+
+extern "C" int rt_obstruct_segments_noalloc(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask,
+                                            uint8_t *d_out, void *stream) {
+    if (!scene) RT_FAIL("rt_obstruct_segments_noalloc: null scene");
+    if (n_seg < 0) RT_FAIL("rt_obstruct_segments_noalloc: negative count");
+    if (n_seg > RT_NOALLOC_MAX_SEGMENTS)
+        RT_FAIL("rt_obstruct_segments_noalloc: " + std::to_string(n_seg) + " segments, at most " +
+                std::to_string(RT_NOALLOC_MAX_SEGMENTS) + " per call (the size of the library's fixed scratch array)");
+    if (n_seg == 0) return 0;
+    if (!d_segs || !d_out) RT_FAIL("rt_obstruct_segments_noalloc: null array");
+    NoAllocScratch *scr = scene->device >= 0 && scene->device < RT_NOALLOC_MAX_DEVICES ? g_scratch_of_device[scene->device] : nullptr;
+    if (!scr) RT_FAIL("rt_obstruct_segments_noalloc: no scratch array on device " + std::to_string(scene->device));
+    RT_HIP(hipSetDevice(scene->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int block = 256;
+    int64_t grid = (n_seg + block - 1) / block;
+    if (grid > (1 << 20)) grid = 1 << 20;
+    hipLaunchKernelGGL(k_noalloc_clear, dim3((unsigned)(grid < 2048 ? grid : 2048)), dim3(block), 0, st, d_out, n_seg,
+                       &scr->late_count);
+    ObstructItems items{d_segs, mk3(0, 0, 0), nullptr, nullptr, 0, d_mask ? n_seg : 0, nullptr, 0};
+    // first pass: every wave stops after OBS_FIRST_PASS_TRIPS records per lane and lists the segments still walking
+    if (d_mask)
+        hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, st, scene->view, items, n_seg,
+                           (const unsigned long long *)nullptr, d_mask, d_out, OBS_FIRST_PASS_TRIPS, &scr->late_count,
+                           scr->late_items);
+    else
+        hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, st, scene->view, items, n_seg,
+                           (const unsigned long long *)nullptr, d_mask, d_out, OBS_FIRST_PASS_TRIPS, &scr->late_count,
+                           scr->late_items);
+    // second pass: the listed segments, walked to the end (the count is read on the device)
+    items.index = scr->late_items;
+    const unsigned g2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(grid, std::max<int64_t>(1024, grid >> 2)));
+    if (d_mask)
+        hipLaunchKernelGGL(k_obstruct_grid<true>, dim3(g2), dim3(block), 0, st, scene->view, items, n_seg,
+                           (const unsigned long long *)&scr->late_count, d_mask, d_out, 0x7fffffff,
+                           (unsigned long long *)nullptr, (int32_t *)nullptr);
+    else
+        hipLaunchKernelGGL(k_obstruct_grid<false>, dim3(g2), dim3(block), 0, st, scene->view, items, n_seg,
+                           (const unsigned long long *)&scr->late_count, d_mask, d_out, 0x7fffffff,
+                           (unsigned long long *)nullptr, (int32_t *)nullptr);
+    RT_HIP(hipGetLastError());
+    return 0;
+}

@@ -122,9 +122,31 @@ struct rt_scene {
     double last_ms[4] = {0, 0, 0, 0};
     int64_t last_launches[4] = {0, 0, 0, 0};
     int64_t last_segments = 0;
+    // device time of the last rt_fields call: [0] k_fields, [1] everything the call queued
+    double last_fields_ms[2] = {0, 0};
+    // device time of the last visibility call: rows / matrix [0] mapping, [1] sorting, [2] painting, [3] all of it;
+    // [4..7] the same for the extra faces of rt_visibility_with_faces / rt_faces_visibility
+    double last_vis_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Device memory a call needs only while it runs (candidate set-up, receiver tiles, staging of host arrays) is taken
+    // from this pool and handed back when the call ends, so that a call in a loop stops allocating after the first.
+    struct TempBlock {
+        void *p;
+        size_t bytes;
+        bool busy;
+        int idle;  // calls in a row that did not use it
+    };
+    std::vector<TempBlock> temp_pool;
 };
 
+// a block of at least `bytes` from the scene's pool (nullptr when the device is out of memory); valid until
+// rt_scene_temp_release_all, which every entry point calls before it returns
+void *rt_scene_temp(rt_scene *scene, size_t bytes);
+void rt_scene_temp_release_all(rt_scene *scene);
+
 int rt_scene_workspace(rt_scene *scene, size_t bytes, void **out);
+// looks up, once per device and with that device current, the address of the fixed scratch array that
+// rt_obstruct_segments_noalloc works in (occlusion.hip)
+int rt_noalloc_setup(int device);
 
 // A path waiting for its obstruction test: its interaction points and where its segments are in the segment queue.
 struct PathRec {

@@ -301,6 +301,7 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
         s->h_counters = nullptr;
         ok = false;
     }
+    if (ok && rt_noalloc_setup(device) != 0) ok = false;
     if (ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         rt_set_error("rt_scene_create: hipStreamCreate failed");
         ok = false;
@@ -330,11 +331,45 @@ extern "C" void rt_scene_destroy(rt_scene *s) {
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->ws) (void)hipFree(s->ws);
     if (s->late_items) (void)hipFree(s->late_items);
+    for (const rt_scene::TempBlock &b : s->temp_pool) (void)hipFree(b.p);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
     delete s;
 }
 
 extern "C" int32_t rt_scene_polygon_count(const rt_scene *s) { return s ? s->view.n : -1; }
+
+void *rt_scene_temp(rt_scene *s, size_t bytes) {
+    bytes = bytes ? bytes : 1;
+    int best = -1;
+    for (size_t i = 0; i < s->temp_pool.size(); ++i) {
+        const rt_scene::TempBlock &b = s->temp_pool[i];
+        if (b.busy || b.bytes < bytes || b.bytes > 4 * bytes + (1 << 20)) continue;
+        if (best < 0 || b.bytes < s->temp_pool[best].bytes) best = (int)i;
+    }
+    if (best >= 0) {
+        s->temp_pool[best].busy = true;
+        s->temp_pool[best].idle = 0;
+        return s->temp_pool[best].p;
+    }
+    void *d = nullptr;
+    const size_t want = bytes + bytes / 8;  // a little room, so that a slightly larger next call still fits
+    if (hipMalloc(&d, want) != hipSuccess) return nullptr;
+    s->temp_pool.push_back({d, want, true, 0});
+    return d;
+}
+
+void rt_scene_temp_release_all(rt_scene *s) {
+    for (size_t i = 0; i < s->temp_pool.size();) {
+        rt_scene::TempBlock &b = s->temp_pool[i];
+        if (!b.busy && ++b.idle > 8) {  // sizes have changed: let the block go
+            (void)hipFree(b.p);
+            s->temp_pool.erase(s->temp_pool.begin() + i);
+            continue;
+        }
+        b.busy = false;
+        ++i;
+    }
+}
 
 int rt_scene_workspace(rt_scene *s, size_t bytes, void **out) {
     if (bytes > s->ws_bytes) {
