@@ -1,18 +1,30 @@
 """Benchmark of the path-solve hot path on MI355X.
 
-One step = one pass of the solve (line of sight + every (receiver, candidate) path-solve with its checks) over one
-batch of receivers already resident in HBM.  Workload at any GPU count: config 2 of BASELINE.json — place_levant,
-one emitter, a 32×32 receiver lattice per GPU, reflections up to order 2 (rank r takes the lattice shifted by a
-rank-dependent sub-pitch offset, so every rank has its own 1024 receivers: weak scaling, no data-path collective;
-the per-receiver results are combined with one all-gather outside the timed region).
+Workload (config 3 of BASELINE.json, the one the metric's target names): lln.geojson, one emitter, a 100 x 100 receiver
+lattice, reflections and diffractions up to order 2.  With N GPUs the 10 000 receivers are split into N contiguous
+blocks (strong scaling: the whole job is fixed), the scene is replicated, and
 
-Prints ONE JSON line: whole-job path-solves/s, the roofline of the dominant kernel (device time measured with HIP
-events inside the library on the stream the kernels run on) and a CPU baseline (the oracle's restatement of the
-reference's solve, SciPy hybr per candidate, on this host's cores, on a bounded sample).
+    one step = for this rank's block, all on the GPU: lines of sight + every (receiver, candidate) path-solve with its
+               checks, the description of the surviving paths, the field step (fields, powers, per-receiver dB), the
+               condensation into one fixed-size record per receiver, and ONE all-gather of those records (RCCL), so
+               that every rank ends the step holding the whole coverage map.
+
+The precompute of the scene (device scene, sharp edges, visibility matrix and the emitter's screens — their rows dealt
+to the ranks and all-gathered — and the candidate enumeration) happens once before the steps; it is timed on its own and
+reported with one step as ``coverage_map_wall_s`` (scene file -> per-receiver dB on every rank).
+
+Prints ONE JSON line: whole-job path-solves/s, the roofline of the kernel with the most device time (device times from
+HIP events inside the library, on the stream the kernels run on), the other kernels' rooflines, and — at N = 1 — a
+secondary block for config 2 (place_levant, 1 024 receivers, reflections to order 2) and a CPU baseline (the oracle's
+restatement of the reference's solve, SciPy hybr per candidate, on this host's cores, on a bounded sample).
+
+``--gpus N`` with N > 1 and no launcher around it (no WORLD_SIZE): N worker processes are started here, one per GPU,
+before this process has touched a GPU, and rank 0's line is passed on.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,134 +35,44 @@ sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (half the 157.3 TFLOP/s fp32 vector rate)
 HBM_PEAK_GBS = 8000.0
+FREQUENCY_HZ = 12.5e9  # materials_properties.py:23 of the reference
 
 
-def measured_traffic(family):
-    """HBM bytes per launch of the family's kernels from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
-    collected in separate rocprofv3 runs of this script; scripts/pmc_traffic.py turns them into this file)."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+def committed_counters():
+    """Per-kernel counter figures of the committed rocprofv3 --pmc passes of this script (scripts/pmc_summary.py writes
+    the file): HBM bytes per launch with FETCH_SIZE doubled as gfx950 needs, and VALU issue utilisation."""
     try:
-        with open(path) as f:
-            return json.load(f).get(family)
+        with open(os.path.join(ROOT, "profiles", "r2_counters.json")) as f:
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
 
 
-def large_workload(local_rank, dev):
-    """The same solve on a coverage-map-sized batch: lln.geojson, one emitter, 100x100 receivers, reflections and
-    diffractions up to order 2 (config 3 of BASELINE.json on one GPU).  Reported beside the headline, not as it."""
-    import torch
+def launch_workers(args):
+    """--gpus N > 1 without a launcher: start the N ranks as fresh processes (this one has made no GPU call) and pass
+    rank 0's JSON line on."""
+    import socket
 
-    from raytracing_amd import _lib, scenarios
-    from raytracing_amd import geometry as geom
-
-    t0 = time.perf_counter()
-    stamps = {}
-
-    def stamp(name, since):
-        stamps[name] = round(time.perf_counter() - since, 3)
-        return time.perf_counter()
-
-    place, tx, rx = scenarios.lln_grid(100)
-    polygons = place.get_polygons_list()
-    t = stamp("scene_file_s", t0)
-    scene = _lib.Scene(geom.scene_arrays_of(polygons), device=local_rank)
-    pairs, edges = scene.sharp_edges()
-    t = stamp("device_scene_and_sharp_edges_s", t)
-    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
-    ev = np.zeros(len(polygons), dtype=bool)
-    # the matrix and the emitter's screens in one call, as RayTracingProblem.precompute asks for them
-    vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
-    for v in screens:
-        ev |= v
-    t = stamp("visibility_matrix_and_emitter_screens_s", t)
-    cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
-    stamp("enumeration_s", t)
-    precompute_s = time.perf_counter() - t0
-    n_rx = len(rx)
-    d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
-    cap = 1 << 21
-    o_rx = torch.empty(cap, dtype=torch.int32, device=dev)
-    o_group = torch.empty_like(o_rx)
-    o_cand = torch.empty_like(o_rx)
-    o_pts = torch.empty((cap, _lib.RT_MAX_ORDER, 3), dtype=torch.float64, device=dev)
-    best, timing, found, attempted = None, None, 0, 0
-    for _ in range(4):
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        found, attempted = scene.solve_paths_device(cand, tx, d_rx.data_ptr(), n_rx, o_rx.data_ptr(), o_group.data_ptr(),
-                                                    o_cand.data_ptr(), o_pts.data_ptr(), cap)
-        dt = time.perf_counter() - t
-        if best is None or dt < best:
-            best, timing = dt, scene.last_timing()
-    counts = [int(c) for c in cand.counts]
-    mo = cand.max_order
-    reflect_flop = 40.0 * n_rx * sum((g + 1) * counts[g] for g in range(mo))
-    # the rest of the coverage map, everything staying on the GPU: solve, per-path description, fields; only the
-    # per-receiver dB comes to the host
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    found, _ = scene.solve_paths_device(cand, tx, d_rx.data_ptr(), n_rx, o_rx.data_ptr(), o_group.data_ptr(),
-                                        o_cand.data_ptr(), o_pts.data_ptr(), cap)
-    n_dev = int(found)
-    d_kind = torch.empty(n_dev, dtype=torch.int32, device=dev)
-    d_chain = torch.empty((n_dev, _lib.RT_MAX_ORDER), dtype=torch.int32, device=dev)
-    d_epolys = torch.empty((n_dev, 2), dtype=torch.int32, device=dev)
-    d_epts = torch.empty((n_dev, 6), dtype=torch.float64, device=dev)
-    cand.describe_device(o_group.data_ptr(), o_cand.data_ptr(), n_dev, d_kind.data_ptr(), d_chain.data_ptr(),
-                         d_epolys.data_ptr(), d_epts.data_ptr())
-    d_field = torch.empty((n_dev, 1, 6), dtype=torch.float64, device=dev)
-    d_power = torch.empty((n_dev, 1), dtype=torch.float64, device=dev)
-    d_angles = torch.empty((n_dev, 4), dtype=torch.float64, device=dev)
-    d_time = torch.empty(n_dev, dtype=torch.float64, device=dev)
-    d_status = torch.empty(n_dev, dtype=torch.int32, device=dev)
-    d_db = torch.empty((n_rx, 1), dtype=torch.float64, device=dev)
-    scene.fields_device(tx, d_rx.data_ptr(), n_rx, o_rx.data_ptr(), d_kind.data_ptr(), d_chain.data_ptr(),
-                        d_epolys.data_ptr(), d_epts.data_ptr(), o_pts.data_ptr(), n_dev, [3.6e9], d_field.data_ptr(),
-                        d_power.data_ptr(), d_angles.data_ptr(), d_time.data_ptr(), d_status.data_ptr(), d_db.data_ptr())
-    power_db_dev = d_db.cpu().numpy()
-    device_route_s = time.perf_counter() - t
-    # the same through the host-array entry points (paths to the host, description, fields): must give the same map
-    t = time.perf_counter()
-    res = scene.solve_paths(cand, tx, rx)
-    keep = res["group"] >= 0
-    n_paths = len(res["rx"])
-    kind = np.zeros(n_paths, dtype=np.int32)
-    chain = np.zeros((n_paths, _lib.RT_MAX_ORDER), dtype=np.int32)
-    epolys = np.zeros((n_paths, 2), dtype=np.int32)
-    epts = np.zeros((n_paths, 6))
-    kind[keep], chain[keep], epolys[keep], epts[keep] = cand.describe(res["group"][keep], res["cand"][keep])
-    fields = scene.fields(tx, rx, res["rx"], kind, chain, epolys, epts, res["points"], [3.6e9])
-    host_route_s = time.perf_counter() - t
-    covered = int(np.isfinite(fields["power_db"][:, 0]).sum())
-    both = np.isfinite(fields["power_db"][:, 0])
-    if not (np.array_equal(both, np.isfinite(power_db_dev[:, 0])) and
-            np.allclose(power_db_dev[both, 0], fields["power_db"][both, 0], rtol=0, atol=1e-9)):
-        raise RuntimeError("the device route and the host-array route of the coverage map disagree")
-    out = {"workload": f"lln.geojson ({len(polygons)} polygons), 1 TX, 100x100 RX, reflections+diffractions up to order 2",
-           "precompute_s": round(precompute_s, 3), "precompute_breakdown": stamps, "solve_ms": 1e3 * best, "path_solves": int(attempted),
-           "path_solves_per_s": attempted / best, "valid_paths": int(found), "candidates": counts,
-           "segments": int(timing["segments"]), "kernel_ms": {k: float(v) for k, v in timing["ms"].items()},
-           "reflect_algorithmic_tflops_fp64": reflect_flop / (timing["ms"]["reflect"] * 1e-3) / 1e12,
-           "reflect_algorithmic_over_fp64_vector_peak": reflect_flop / (timing["ms"]["reflect"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-           "reflect_note": "40 flop per interaction of every (receiver, candidate) pair over the kernel time; the kernel "
-                           "sorts the receivers into spatial tiles and rejects whole tiles, so this is speed against "
-                           "brute force (it can exceed 1), not vector-unit utilisation",
-           "obstruct_segments_per_s": timing["segments"] / (timing["ms"]["obstruct"] * 1e-3),
-           "coverage_map_wall_s": round(precompute_s + device_route_s, 3),
-           "coverage_map_after_precompute_s": {"device_pointers": round(device_route_s, 4),
-                                               "host_arrays": round(host_route_s, 4)},
-           "coverage_map_note": "scene file -> per-receiver dB on one GPU: scene load, sharp edges, visibility matrix, "
-                                "emitter screens, enumeration, then solve, path description and fields at 3.6 GHz "
-                                "through the device-pointer entry points (only the dB per receiver comes to the host; "
-                                "the host-array route gives the same map and is timed beside it); without the "
-                                "reference's CSV / JSON files",
-           "receivers_with_power": covered}
-    cand.close()
-    scene.close()
-    return out
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or not lines:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank run failed (exit code {proc.returncode})")
+    print(lines[-1])
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (test infrastructure) timed on this host's cores; never part of the measured GPU path
+# ---------------------------------------------------------------------------------------------------------------
 def cpu_baseline_worker(args):
     """Oracle path-solves for one receiver on a strided sample of the candidate chains, for about `budget` s."""
     import warnings
@@ -180,10 +102,12 @@ def cpu_baseline_worker(args):
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(place, tx, rx, chains2, budget_s=5.0, receivers_per_core=4):
+def cpu_baseline(place, tx, rx, chains2, budget_s=5.0, receivers_per_core=2):
     import multiprocessing as mp
 
-    cores = min(16, os.cpu_count() or 1)
+    # the GPU box gives one GPU's job a share of 16 host cores (its os.cpu_count() is the whole machine's)
+    host_cpus = os.cpu_count() or 1
+    cores = min(16, host_cpus)
     polys_data = [(p.points, p.get_parametric()) for p in place.get_polygons_list()]
     stride = max(1, len(chains2) // 4000)
     sample = [tuple(int(v) for v in c) for c in chains2[::stride]]
@@ -195,189 +119,311 @@ def cpu_baseline(place, tx, rx, chains2, budget_s=5.0, receivers_per_core=4):
     wall = time.perf_counter() - t0
     solves = sum(r[0] for r in res)
     busy = sum(r[1] for r in res) / cores  # time per core, all cores busy
-    return {"value": solves / busy, "unit": "path-solves/s", "cores": cores, "kind": "port",
-            "sample": f"{len(jobs)} receivers x {len(sample)} order-2 chains (every {stride}th of {len(chains2)}) of the "
-                      f"same workload = {solves} path-solves, oracle = reference algorithm with SciPy hybr, one process "
-                      f"per core, {busy:.0f} s of work per core ({wall:.0f} s wall with process start-up)"}
+    return {"value": solves / busy, "unit": "path-solves/s", "cores": cores, "host_cpu_count": host_cpus, "kind": "port",
+            "sample": f"{len(jobs)} receivers x up to {len(sample)} order-2 chains (every {stride}th of {len(chains2)}) of "
+                      f"the same workload = {solves} path-solves; oracle = the reference's algorithm with SciPy hybr and "
+                      f"its checks, one process per core on the {cores} cores this job may use (os.cpu_count() = "
+                      f"{host_cpus}), {busy:.0f} s of work per core ({wall:.0f} s wall with process start-up)"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rooflines
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_rooflines(n_rx, counts, max_order, n_poly, n_vert, ms, launches, segments_walked, n_paths, counters,
+                     n_valid_paths):
+    """Algorithmic work of one step of one rank over the mean device time of each kernel family.  Work per unit:
+    reflection / diffraction candidates 40 flop per interaction of every (receiver, candidate) pair; obstruction
+    13 N flop per segment walked (a segment against every polygon, as the reference tests it) and, as bytes, 49 per
+    segment plus the scene once per launch; fields 24 (k + 2) + 4 k + 160 bytes per path of k interactions."""
+    refl_flop = 40.0 * n_rx * sum((g + 1) * counts[g] for g in range(max_order))
+    diff_flop = 40.0 * n_rx * sum((m + 1) * counts[max_order + m] for m in range(max_order))
+    occ_flop = 13.0 * n_poly * segments_walked
+    occ_bytes = 49.0 * segments_walked + (64.0 * n_poly + 24.0 * n_vert) * max(launches["obstruct"], 1)
+    field_bytes = float(n_paths)  # the caller passes the bytes themselves (it knows each path's interactions)
+
+    def entry(kernel, bound, work, t_ms, extra=None):
+        peak = FP64_VECTOR_PEAK_TFLOPS if bound == "valu_fp64" else HBM_PEAK_GBS
+        scale = 1e12 if bound == "valu_fp64" else 1e9
+        achieved = work / (t_ms * 1e-3) / scale if t_ms > 0 else 0.0
+        e = {"kernel": kernel, "bound": bound, "achieved": achieved, "peak": peak,
+             "unit": "TFLOP/s" if bound == "valu_fp64" else "GB/s", "frac": achieved / peak, "ms_per_step": t_ms,
+             "algorithmic_work_per_step": work}
+        c = counters.get(kernel.split("<")[0].split(" ")[0])
+        if c:
+            e["traffic"] = c.get("hbm_bytes_per_launch")
+            e["valu_issue_utilisation"] = c.get("valu_issue_utilisation")
+            e["counter_source"] = c.get("source")
+        if extra:
+            e.update(extra)
+        return e
+
+    return {
+        "reflect": entry("k_reflect_tiled<2> (orders 1 and 2)", "valu_fp64", refl_flop, ms["reflect"],
+                         {"note": "whole receiver tiles are rejected with an interval test: speed against brute force "
+                                  "(can exceed 1), not vector-unit utilisation"}),
+        "diffract": entry("k_diffract<0>, k_diffract<1>", "valu_fp64", diff_flop, ms["diffract"]),
+        "obstruct": entry("k_obstruct_grid", "valu_fp64", occ_flop, ms["obstruct"],
+                          {"launches_per_step": launches["obstruct"], "segments_walked_per_step": segments_walked,
+                           "hbm_model": {"achieved_GBs": occ_bytes / (ms["obstruct"] * 1e-3) / 1e9 if ms["obstruct"] > 0 else 0.0,
+                                         "peak_GBs": HBM_PEAK_GBS, "algorithmic_bytes_per_step": occ_bytes},
+                           "note": "13 N flop per segment is the reference's segment-against-every-polygon test; the "
+                                   "grid walk looks at ~20 of the 7 615 polygons per segment, so this fraction is speed "
+                                   "against brute force (can exceed 1)"}),
+        "fields": entry("k_fields", "hbm", field_bytes, ms["fields"], {"paths_per_step": n_valid_paths}),
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def config2_block(local_rank, dev, steps):
+    """Config 2 of BASELINE.json on one GPU (place_levant, 32 x 32 receivers, reflections to order 2): a step is the
+    solve alone, 3.0 M path-solves in three dependent launches — the latency floor of the path."""
+    import torch
+
+    from raytracing_amd import _lib, scenarios
+    from raytracing_amd import geometry as geom
+
+    place, tx, rx = scenarios.levant_grid(32)
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons), device=local_rank)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
+    ev = np.logical_or.reduce(screens)
+    cand = scene.enumerate(vis, ev, np.zeros((0, 2), np.int32), np.zeros((0, 2, 3)), 2, with_diffraction=False)
+    n_rx = len(rx)
+    d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
+    cap = 256 * n_rx
+    o_rx = torch.empty(cap, dtype=torch.int32, device=dev)
+    o_group = torch.empty_like(o_rx)
+    o_cand = torch.empty_like(o_rx)
+    o_pts = torch.empty((cap, _lib.RT_MAX_ORDER, 3), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        return scene.solve_paths_device(cand, tx, d_rx.data_ptr(), n_rx, o_rx.data_ptr(), o_group.data_ptr(),
+                                        o_cand.data_ptr(), o_pts.data_ptr(), cap)
+
+    scene.set_timing(False)
+    for _ in range(20):
+        found, attempted = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        found, attempted = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    scene.set_timing(True)
+    fam = {"reflect": 0.0, "obstruct": 0.0, "finalize": 0.0}
+    for _ in range(steps):
+        step()
+        tm = scene.last_timing()
+        for k in fam:
+            fam[k] += tm["ms"][k] / steps
+    out = {"workload": f"place_levant.geojson ({len(polygons)} polygons), 1 TX, 32x32 RX, reflections up to order 2 "
+                       "(config 2 of BASELINE.json); a step is the solve alone",
+           "steps": steps, "ms_per_step": 1e3 * dt, "path_solves_per_step": int(attempted),
+           "path_solves_per_s": attempted / dt, "valid_paths": int(found), "kernel_ms_per_step": fam}
+    cand.close()
+    scene.close()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-side", type=int, default=100, help="receivers per side of the lattice (100 = the 10k-RX map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-large", action="store_true", help="skip the coverage-map-sized extra measurement")
-    ap.add_argument("--n-side", type=int, default=32)
-    ap.add_argument("--events-in-timed-region", action="store_true",
-                    help="keep the per-launch timing events on during the timed steps")
+    ap.add_argument("--no-config2", action="store_true", help="skip the secondary config-2 block")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 (rehearsal on a one-GPU box)")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        return launch_workers(args)  # no GPU call has been made in this process
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.share_gpu:
-        local_rank = 0
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        pg = dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
 
     from raytracing_amd import _lib, scenarios
+    from raytracing_amd import device_pipeline as dp
     from raytracing_amd import geometry as geom
-
-    t_pre = time.perf_counter()
-    place, tx, rx = scenarios.levant_grid(args.n_side)
-    if world > 1:  # each rank its own receivers: the lattice moved by a rank-dependent fraction of the pitch
-        pitch = rx[1, 0] - rx[0, 0]
-        rx = rx + np.array([pitch * rank / (2.0 * world), pitch * rank / (3.0 * world), 0.0])
-    polygons = place.get_polygons_list()
-    arrays = geom.scene_arrays_of(polygons)
-    scene = _lib.Scene(arrays, device=local_rank)
-    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
-    ev = np.zeros(len(polygons), dtype=bool)
-    vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
-    for v in screens:
-        ev |= v
-    cand = scene.enumerate(vis, ev, np.zeros((0, 2), np.int32), np.zeros((0, 2, 3)), 2, with_diffraction=False)
-    precompute_s = time.perf_counter() - t_pre
-
-    n_rx = len(rx)
-    d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
-    cap = 256 * n_rx
-    o_rx = torch.empty(cap, dtype=torch.int32, device=dev)
-    o_group = torch.empty(cap, dtype=torch.int32, device=dev)
-    o_cand = torch.empty(cap, dtype=torch.int32, device=dev)
-    o_pts = torch.empty((cap, _lib.RT_MAX_ORDER, 3), dtype=torch.float64, device=dev)
-
-    def step():
-        return scene.solve_paths_device(cand, tx, d_rx.data_ptr(), n_rx, o_rx.data_ptr(), o_group.data_ptr(),
-                                        o_cand.data_ptr(), o_pts.data_ptr(), cap)
+    from raytracing_amd import multithread_solve as mts
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The timed region runs without the per-launch events (a pair of event records per launch costs a step of this
-    # size a measurable part of its time); the kernel times of the roofline come from the same number of steps run
-    # again right after it with the events on.
-    scene.set_timing(args.events_in_timed_region)
+    # ---- precompute: scene file -> candidates (once per scene and emitter) ----------------------------------------
+    barrier()
+    t_wall = time.perf_counter()
+    stamps = {}
+
+    def stamp(name, since):
+        stamps[name] = round(time.perf_counter() - since, 4)
+        return time.perf_counter()
+
+    place, tx, rx = scenarios.lln_grid(args.n_side)
+    polygons = place.get_polygons_list()
+    arrays = geom.scene_arrays_of(polygons)
+    t = stamp("scene_file_s", t_wall)
+    scene = _lib.Scene(arrays, device=local_rank)
+    pairs, edges = scene.sharp_edges()
+    t = stamp("device_scene_and_sharp_edges_s", t)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    screens = [(s.points, s.get_parametric(), -1) for s in cube.polygons]
+    # matrix rows and emitter screens dealt to the ranks, one all-gather (one rank: everything here)
+    vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg)
+    vis_timing = scene.visibility_timing()
+    ev = np.logical_or.reduce(screen_vis)
+    t = stamp("visibility_matrix_and_emitter_screens_s", t)
+    cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+    t = stamp("enumeration_s", t)
+    n_total = len(rx)
+    begin, end = mts.shard_bounds(n_total, world, rank)
+    d_rx = torch.tensor(rx[begin:end], dtype=torch.float64, device=dev).reshape(-1, 3)
+    pipe = dp.DevicePipeline(scene, cand, tx, capacity=max(1 << 16, 40 * (end - begin)))
+    barrier()
+    precompute_s = time.perf_counter() - t_wall
+
+    def step():
+        block = pipe.run(d_rx, [FREQUENCY_HZ])
+        records = dp.all_gather_records(dp.receiver_records(block), n_total, pg)
+        return block, records
+
+    # ---- the timed steps ---------------------------------------------------------------------------------------------
+    scene.set_timing(False)  # the event pairs around every launch are kept out of the timed region
     for _ in range(args.warmup):
-        found, attempted = step()
+        block, records = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        found, attempted = step()
+        block, records = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    fam_ms = {"reflect": 0.0, "diffract": 0.0, "obstruct": 0.0, "finalize": 0.0}
-    fam_launches = dict.fromkeys(fam_ms, 0)
-    segments = 0
+    # the same steps again with the per-launch events on: kernel times of the rooflines
     scene.set_timing(True)
-    step()
+    fam = {"reflect": 0.0, "diffract": 0.0, "obstruct": 0.0, "finalize": 0.0, "fields": 0.0, "fields_call": 0.0}
+    launches = {"reflect": 0, "diffract": 0, "obstruct": 0, "finalize": 0}
+    segments = 0
+    n_ev = max(1, min(args.steps, 10))
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        tm = scene.last_timing()
-        for k in fam_ms:
-            fam_ms[k] += tm["ms"][k]
-            fam_launches[k] += tm["launches"][k]
-        segments += tm["segments"]
+    for _ in range(n_ev):
+        block, records = step()
+        for k in launches:
+            fam[k] += block.solve_timing["ms"][k] / n_ev
+            launches[k] += block.solve_timing["launches"][k]
+        fam["fields"] += block.fields_timing["kernel"] / n_ev
+        fam["fields_call"] += block.fields_timing["call"] / n_ev
+        segments += block.solve_timing["segments"]
     torch.cuda.synchronize()
-    elapsed_with_events = time.perf_counter() - t1
+    ms_with_events = 1e3 * (time.perf_counter() - t1) / n_ev
+    launches = {k: v / n_ev for k, v in launches.items()}
+    segments /= n_ev
+    rec = dp.unpack_records(records.cpu().numpy(), 1)
+    attempted_local = float(block.n_attempted)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed, precompute_s], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(attempted)], dtype=torch.float64, device=cdev)
+        elapsed, precompute_s = float(t[0].item()), float(t[1].item())
+        tot = torch.tensor([attempted_local], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         attempted_all = float(tot.item())
-        # per-receiver path counts of every rank on every rank: the one collective of the path (outside the timing)
-        counts = torch.bincount(o_rx[:found].long(), minlength=n_rx).to(torch.int32).to(cdev)
-        gathered = [torch.empty_like(counts) for _ in range(world)]
-        dist.all_gather(gathered, counts)
-        paths_all = int(sum(int(g.sum().item()) for g in gathered))
     else:
-        attempted_all = float(attempted)
-        paths_all = int(found)
+        attempted_all = attempted_local
 
     if rank == 0:
-        n_poly = len(polygons)
-        pairs = n_rx * cand.total
         steps = max(1, args.steps)
-        ms = {k: fam_ms[k] / steps for k in fam_ms}
-        launches = {k: fam_launches[k] / steps for k in fam_ms}
-        seg_per_step = segments / steps
-        # algorithmic work per step.  Candidate kernels: 40 flop per interaction of every (receiver, candidate) pair
-        # (mirror image, plane crossing, containment and spacing checks).  Obstruction: every segment is read once
-        # (48 B) and its flag written once (1 B); the scene's pre-test records (64 B per polygon) and vertices are
-        # read once per launch.
-        reflect_flop = 40.0 * float(n_rx) * sum((g + 1) * int(cand.counts[g]) for g in range(cand.max_order))
-        scene_bytes = 64.0 * n_poly + 24.0 * int(arrays.verts.shape[0])
-        obstruct_bytes = 49.0 * seg_per_step + scene_bytes * launches["obstruct"]
-        by_kernel = {
-            "reflect": {"kernel": "k_reflect<2> (reflection orders 1 and 2 in one launch)", "bound": "valu_fp64",
-                        "achieved": reflect_flop / (ms["reflect"] * 1e-3) / 1e12 if ms["reflect"] > 0 else 0.0,
-                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "ms_per_step": ms["reflect"],
-                        "launches_per_step": launches["reflect"], "algorithmic_flop_per_step": reflect_flop},
-            "obstruct": {"kernel": "k_obstruct<false>+k_obstruct<true>", "bound": "hbm",
-                         "achieved": obstruct_bytes / (ms["obstruct"] * 1e-3) / 1e9 if ms["obstruct"] > 0 else 0.0,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": ms["obstruct"],
-                         "launches_per_step": launches["obstruct"], "algorithmic_bytes_per_step": obstruct_bytes,
-                         "segment_polygon_tests_per_s": seg_per_step * n_poly / (ms["obstruct"] * 1e-3)
-                         if ms["obstruct"] > 0 else 0.0},
-        }
-        for v in by_kernel.values():
-            v["frac"] = v["achieved"] / v["peak"]
-        dominant = max(by_kernel, key=lambda k: by_kernel[k]["ms_per_step"])
+        counts = [int(c) for c in cand.counts]
+        ms_step = 1e3 * elapsed / steps
+        # bytes the field kernel must move per path of k interactions: points, chain, edge, outputs (24 (k + 2) + 4 k + 160)
+        k_inter = ((block.kind & 255) + (block.kind >> 8)).to(torch.float64)
+        field_bytes = float((24.0 * (k_inter + 2) + 4.0 * k_inter + 160.0).sum().item())
+        by_kernel = kernel_rooflines(end - begin, counts, cand.max_order, len(polygons), int(arrays.verts.shape[0]), fam,
+                                     launches, segments, field_bytes, committed_counters(), block.n_paths)
+        # the visibility kernels of the precompute (this rank's share of the rows and screens)
+        n_poly, n_vert = len(polygons), int(arrays.verts.shape[0])
+        my_rows = len(range(rank, n_poly + len(screens), world))
+        vis_flop = (28.0 * n_vert + 20.0 * n_poly) * my_rows
+        for name, key in (("vis_prepare", "prepare"), ("vis_paint", "paint")):
+            t_ms = vis_timing["rows"][key] + vis_timing["faces"][key]
+            ach = vis_flop / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+            by_kernel[name] = {"kernel": "k_" + name, "bound": "valu_fp64", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "ms": t_ms,
+                               "rows_ms": vis_timing["rows"][key], "screens_ms": vis_timing["faces"][key],
+                               "algorithmic_work": vis_flop, "once_per_scene": True,
+                               "note": "18 V_B + 10 V_A + 20 flop per ordered pair of the rows this rank paints "
+                                       "(mapping, filters; the coverage test is data-dependent and not counted); rows "
+                                       "and screens run side by side, so the two times overlap"}
+        step_kernels = ("reflect", "diffract", "obstruct", "fields")
+        dominant = max(step_kernels, key=lambda k: by_kernel[k]["ms_per_step"])
         roof = dict(by_kernel[dominant])
-        detail = measured_traffic(dominant)
-        roof["traffic"] = detail["bytes_per_launch"] if detail else None
-        roof["traffic_detail"] = detail
-        roof["achieved_per_launch_basis"] = "algorithmic bytes (or flop) per step / launches per step / mean launch time"
-        roof["note"] = ("launch- and latency-bound at this size (a step is four dependent launches of 2-40 us over 3 M "
-                        "pairs); see large_workload for the same kernels on a coverage-map-sized batch")
+        roof.setdefault("traffic", None)
+        roof["achieved_per_launch_basis"] = ("algorithmic flop (or bytes) of one step of one rank / mean device time of the "
+                                             "family's launches in a step (HIP events on the library's stream)")
+        finite = np.isfinite(rec["power_db"][:, 0])
+        flagged = int(rec["n_flagged"].sum())
         out = {
             "metric": "path-solves/sec (RX x candidate paths, whole node)",
-            "value": attempted_all * args.steps / elapsed,
+            "value": attempted_all * steps / elapsed,
             "unit": "path-solves/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "place_levant.geojson (237 polygons), 1 TX, 32x32 RX lattice per GPU, "
-                                   "reflections up to order 2 (config 2 of BASELINE.json)",
-                       "receivers_per_gpu": n_rx, "candidates_per_receiver": 1 + cand.total,
-                       "candidates_by_order": [int(c) for c in cand.counts[:cand.max_order]],
-                       "valid_paths_all_gpus": paths_all, "precompute_s": round(precompute_s, 3)},
+            "config": {"workload": f"lln.geojson ({len(polygons)} polygons), 1 TX, {args.n_side}x{args.n_side} RX coverage "
+                                   "map, reflections + diffractions up to order 2 (config 3 of BASELINE.json); a step = "
+                                   "solve + path description + field step + all-gather of one record per receiver",
+                       "receivers": n_total, "receivers_per_gpu": end - begin,
+                       "candidates_per_receiver": 1 + int(sum(counts)), "candidates_by_group": counts,
+                       "path_solves_per_step": int(attempted_all), "valid_paths_rank0": int(block.n_paths),
+                       "valid_paths_all_gpus": int(rec["n_paths"].sum()), "frequency_hz": FREQUENCY_HZ,
+                       "record_bytes_per_receiver": dp.record_bytes(1), "backend": args.backend if world > 1 else None},
+            "coverage_map_wall_s": round(precompute_s + ms_step * 1e-3, 4),
+            "coverage_map": {"precompute_s": round(precompute_s, 4), "precompute_breakdown_rank0": stamps,
+                             "visibility_kernels_ms_rank0": vis_timing, "step_s": round(ms_step * 1e-3, 5),
+                             "receivers_with_power": int(finite.sum()),
+                             "paths_with_field_status": flagged,
+                             "worst_field_status": int(rec["worst_status"].max()) if len(rec["worst_status"]) else 0,
+                             "note": "scene file -> per-receiver dB on every rank: scene load, device scene, sharp edges, "
+                                     "visibility matrix and emitter screens (dealt to the ranks, all-gathered), "
+                                     "enumeration, then one step; max over ranks"},
             "roofline": roof,
             "roofline_by_kernel": by_kernel,
-            "kernel_ms_per_step": ms,
-            "kernel_ms_source": "HIP events around every launch, over the same number of steps run again after the "
-                                "timed region (which runs without them)",
-            "ms_per_step_with_events": 1e3 * elapsed_with_events / steps,
-            "segments_per_step": seg_per_step,
-            "pairs_per_step": pairs,
+            "kernel_ms_per_step": fam,
+            "kernel_ms_source": f"HIP events around every launch, over {n_ev} more steps after the timed region (which "
+                                "runs without them)",
+            "ms_per_step_with_events": ms_with_events,
+            "step_host_and_collective_ms": ms_step - sum(fam[k] for k in ("reflect", "diffract", "obstruct", "finalize",
+                                                                          "fields_call")),
         }
-        if not args.no_large and world == 1:
-            out["large_workload"] = large_workload(local_rank, dev)
-        if not args.no_cpu_baseline and world == 1:
+        if world == 1 and not args.no_config2:
+            out["config2"] = config2_block(local_rank, dev, 200)
+        if world == 1 and not args.no_cpu_baseline:
             chains2, _ = cand.group(1)
             out["cpu_baseline"] = cpu_baseline(place, tx, rx, chains2)
         else:
@@ -386,6 +432,7 @@ def main():
     cand.close()
     scene.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

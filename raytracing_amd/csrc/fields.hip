@@ -573,13 +573,7 @@ extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group,
                 RT_FAIL("rt_describe_paths: candidate index out of range");
         }
     }
-    std::vector<void *> temps;
-    auto dalloc = [&](size_t bytes) -> void * {
-        void *d = nullptr;
-        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
-        temps.push_back(d);
-        return d;
-    };
+    auto dalloc = [&](size_t bytes) -> void * { return rt_scene_temp(scene, bytes); };
     int rc = -1;
     do {
         int *d_refl = (int *)dalloc(sizeof(int) * h_refl.size()), *d_edge = (int *)dalloc(sizeof(int) * h_edge.size());
@@ -619,8 +613,11 @@ extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group,
         if (hipStreamSynchronize(st) != hipSuccess) break;
         rc = 0;
     } while (0);
-    for (void *p : temps) (void)hipFree(p);
-    if (rc) rt_set_error(std::string("rt_describe_paths: ") + hipGetErrorString(hipGetLastError()));
+    if (rc) {
+        rt_set_error(std::string("rt_describe_paths: ") + hipGetErrorString(hipGetLastError()));
+        (void)hipStreamSynchronize(st);
+    }
+    rt_scene_temp_release_all(scene);
     return rc;
 }
 
@@ -665,15 +662,10 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
     const double rough[N_MATERIALS] = {NAN, 1e-4, 1e-3, 1e-4, 1e-6, 1e-6, 1e-2};
     for (int m = 0; m < N_MATERIALS; ++m) ft.roughness[m] = rough[m];
 
-    std::vector<void *> temps;
-    auto dalloc = [&](size_t bytes) -> void * {
-        void *d = nullptr;
-        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
-        temps.push_back(d);
-        return d;
-    };
+    auto dalloc = [&](size_t bytes) -> void * { return rt_scene_temp(scene, bytes); };
     auto cleanup = [&]() {
-        for (void *p : temps) (void)hipFree(p);
+        (void)hipStreamSynchronize(st);
+        rt_scene_temp_release_all(scene);
     };
 #define F_HIP(call)                                                                                 \
     do {                                                                                            \
@@ -752,6 +744,18 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         }
         pa.n_late = options->n_late_polygons;
     }
+    // device time of the call and of the field kernel alone (rt_fields_last_timing), while the scene's timing is on
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (scene->timing) {
+        while (scene->event_pool.size() < 4) {
+            hipEvent_t e = nullptr;
+            F_HIP(hipEventCreate(&e));
+            scene->event_pool.push_back(e);
+        }
+        for (int k = 0; k < 4; ++k) ev[k] = scene->event_pool[k];
+        F_HIP(hipEventRecord(ev[0], st));
+    }
+    scene->last_fields_ms[0] = scene->last_fields_ms[1] = 0;
     fo.power_sum = (double *)dalloc(sizeof(double) * n_rx * nf);
     unsigned long long *best_len = (unsigned long long *)dalloc(sizeof(unsigned long long) * n_rx);
     unsigned long long *best_idx = (unsigned long long *)dalloc(sizeof(unsigned long long) * n_rx);
@@ -765,8 +769,10 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         hipLaunchKernelGGL(k_best_length, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len);
         hipLaunchKernelGGL(k_best_index, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len, best_idx);
         F_HIP(hipMemsetAsync(fo.status, 0x7f, sizeof(int32_t) * np_, st));
+        if (ev[1]) F_HIP(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_fields, dim3((unsigned)((n_paths + 127) / 128), (unsigned)n_freq), dim3(128), 0, st, scene->view,
                            pa, ft, *antenna, TX, d_rx, best_idx, fo);
+        if (ev[2]) F_HIP(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k_status_final, dim3(grid), dim3(256), 0, st, fo.status, (int64_t)n_paths);
     }
     hipLaunchKernelGGL(k_power_db, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, fo.power_sum,
@@ -782,7 +788,20 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         }
         F_HIP(hipMemcpyAsync(out_power_db, d_db, sizeof(double) * n_rx * nf, hipMemcpyDeviceToHost, st));
     }
+    if (ev[3]) F_HIP(hipEventRecord(ev[3], st));
     F_HIP(hipStreamSynchronize(st));
-    cleanup();
+    if (ev[0]) {
+        float t = 0;
+        if (n_paths > 0 && hipEventElapsedTime(&t, ev[1], ev[2]) == hipSuccess) scene->last_fields_ms[0] = t;
+        if (hipEventElapsedTime(&t, ev[0], ev[3]) == hipSuccess) scene->last_fields_ms[1] = t;
+    }
+    rt_scene_temp_release_all(scene);
+    return 0;
+}
+
+extern "C" int rt_fields_last_timing(rt_scene *scene, double *ms2) {
+    if (!scene || !ms2) RT_FAIL("rt_fields_last_timing: null argument");
+    ms2[0] = scene->last_fields_ms[0];
+    ms2[1] = scene->last_fields_ms[1];
     return 0;
 }

@@ -1554,16 +1554,11 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     // device views of the caller's arrays
     const double *d_rx = rx;
     OutArrays out{};
-    std::vector<void *> temps;
-    auto temp_alloc = [&](size_t bytes) -> void * {
-        void *d = nullptr;
-        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
-        temps.push_back(d);
-        return d;
-    };
+    // memory of this call only: from the scene's pool (no allocation once the pool holds the sizes of this workload)
+    auto temp_alloc = [&](size_t bytes) -> void * { return rt_scene_temp(scene, bytes); };
     auto free_temps = [&]() {
-        for (void *p : temps) (void)hipFree(p);
-        temps.clear();
+        (void)hipStreamSynchronize(st);  // nothing queued may still be using them
+        rt_scene_temp_release_all(scene);
     };
 #define SOLVE_HIP(call)                                                                                   \
     do {                                                                                                  \
@@ -1805,8 +1800,8 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         }
         // obstruction of the queued segments and the final filter, sized on the device
         timer.begin(2);
+        int max_nseg = 0;
         if (by_rounds) {
-            int max_nseg = 0;
             for (int k = 1; k <= mo; ++k)
                 if (cand->groups[k - 1].count > 0) max_nseg = std::max(max_nseg, k + 1);
             if (any_diffraction) max_nseg = std::max(max_nseg, 2);
@@ -1854,7 +1849,10 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         scene->hint_paths = std::max<int64_t>(n_paths, 1);
         scene->hint_segments = std::max<int64_t>(n_segs, 1);
         scene->hint_clear = std::max<int64_t>((int64_t)h_counters[3], 1);
-        scene->last_segments += n_segs;
+        // segments walked: every queued segment on the one-launch route; by rounds, the last segment of every queued
+        // path and then, per further round, at most the paths still clear after the first (nearly all of them are
+        // walked again; those that have no segment at that place are not: an upper bound a per cent or two high)
+        scene->last_segments += by_rounds ? n_paths + (int64_t)h_counters[3] * std::max(0, max_nseg - 1) : n_segs;
         r0 = r1;
     }
     const unsigned long long found = found_before;
@@ -1869,7 +1867,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         }
     }
     timer.collect(scene->last_ms, scene->last_launches);
-    free_temps();
+    rt_scene_temp_release_all(scene);  // the stream has been waited for
     return 0;
 }
 

@@ -1092,6 +1092,20 @@ struct DevBuf {
 struct RowsJob {
     DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work,
         b_queue;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, mapped, sorted, painted
+    ~RowsJob() {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    // after the stream has been waited for: ms[0..3] += mapping, sorting, painting, all
+    void add_times(double *ms) const {
+        if (!ev[0] || !ev[3]) return;
+        float t = 0;
+        if (hipEventElapsedTime(&t, ev[0], ev[1]) == hipSuccess) ms[0] += t;
+        if (hipEventElapsedTime(&t, ev[1], ev[2]) == hipSuccess) ms[1] += t;
+        if (hipEventElapsedTime(&t, ev[2], ev[3]) == hipSuccess) ms[2] += t;
+        if (hipEventElapsedTime(&t, ev[0], ev[3]) == hipSuccess) ms[3] += t;
+    }
 };
 
 // Queues, on stream st, the kernels that write the visibility rows of a batch of faces into d_out[n_faces*n] (zeroed
@@ -1130,8 +1144,13 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     RT_HIP(hipMemsetAsync(d_out, 0, (size_t)sc.n * n_faces, st));
     FaceBatch fb{n_faces, (const int32_t *)b_off.p, (const double *)b_verts.p, (const double *)b_normal.p,
                  (const int32_t *)b_self.p};
+    if (scene->timing) {
+        for (hipEvent_t &e : job.ev) RT_HIP(hipEventCreate(&e));
+        RT_HIP(hipEventRecord(job.ev[0], st));
+    }
     hipLaunchKernelGGL(k_vis_prepare, dim3((sc.n + 255) / 256, n_faces), dim3(256), 0, st, sc, fb, (double *)b_sph.p,
                        (PolyMeta *)b_meta.p);
+    if (job.ev[1]) RT_HIP(hipEventRecord(job.ev[1], st));
     if (!strict)
         hipLaunchKernelGGL(k_vis_sort, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,
                            (int32_t *)b_order.p, m_stride, (int32_t *)b_counts.p);
@@ -1141,6 +1160,7 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
                            (int32_t *)job.b_queue.p);
         face_queue = (const int32_t *)job.b_queue.p;
     }
+    if (job.ev[2]) RT_HIP(hipEventRecord(job.ev[2], st));
     PaintScratch ps{(int32_t *)b_list.p, (int32_t *)b_canvas.p, (double *)b_cbox.p, (double *)b_splits.p, split_cap,
                     (int32_t *)b_work.p};
     // at most one face per CU: the large canvas store (one workgroup per CU) costs no parallelism
@@ -1152,20 +1172,23 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         hipLaunchKernelGGL((k_vis_paint<SmallCanvasStore, 4>), dim3(n_blocks), dim3(256), 0, st, sc, fb,
                            (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
                            (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, face_queue, d_out);
+    if (job.ev[3]) RT_HIP(hipEventRecord(job.ev[3], st));
     RT_HIP(hipGetLastError());
     return 0;
 }
 
-// visibility rows of a batch of faces into d_out[n_faces*n], on the scene's stream, waited for
+// visibility rows of a batch of faces into d_out[n_faces*n], on the scene's stream, waited for; the batch's device
+// times are added to ms4 (mapping, sorting, painting, all)
 static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, const std::vector<double> &a_verts,
                            const std::vector<double> &a_normal, const std::vector<int32_t> &a_self, int strict,
-                           uint8_t *d_out) {
+                           uint8_t *d_out, double *ms4) {
     RowsJob job;
     if (visibility_rows_enqueue(scene, scene->stream, a_off, a_verts, a_normal, a_self, strict, d_out, job)) {
         (void)hipStreamSynchronize(scene->stream);
         return -1;
     }
     RT_HIP(hipStreamSynchronize(scene->stream));
+    job.add_times(ms4);
     return 0;
 }
 
@@ -1188,7 +1211,8 @@ extern "C" int rt_faces_visibility(rt_scene *scene, int32_t n_faces, const int32
     std::vector<double> a_normal(face_normals, face_normals + 3 * (size_t)n_faces);
     DevBuf d_out;
     if (d_out.alloc((size_t)scene->view.n * n_faces)) RT_FAIL("rt_faces_visibility: out of device memory");
-    if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_out.p)) return -1;
+    for (int k = 4; k < 8; ++k) scene->last_vis_ms[k] = 0;
+    if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_out.p, scene->last_vis_ms + 4)) return -1;
     RT_HIP(hipMemcpy(out, d_out.p, (size_t)scene->view.n * n_faces, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1215,6 +1239,7 @@ extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t
     const size_t per_face = sizeof(double) * 2 * (size_t)scene->view.vtot + (sizeof(PolyMeta) + 8) * (size_t)n;
     int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_rows, ((size_t)24 << 30) / per_face));
     batch = std::min(batch, 65535);
+    for (int k = 0; k < 4; ++k) scene->last_vis_ms[k] = 0;
     for (int k0 = 0; k0 < n_rows; k0 += batch) {
         const int k1 = std::min(n_rows, k0 + batch);
         std::vector<int32_t> a_off(1, 0), a_self;
@@ -1227,7 +1252,9 @@ extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t
             a_normal.insert(a_normal.end(), scene->h_planes.begin() + 4 * (size_t)i, scene->h_planes.begin() + 4 * (size_t)i + 3);
             a_self.push_back(i);
         }
-        if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_out.p + (size_t)k0 * n)) return -1;
+        if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_out.p + (size_t)k0 * n,
+                            scene->last_vis_ms))
+            return -1;
     }
     RT_HIP(hipStreamSynchronize(scene->stream));
     RT_HIP(hipMemcpy(out, d_out.p, (size_t)n * n_rows, hipMemcpyDeviceToHost));
@@ -1246,6 +1273,7 @@ extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, i
     const size_t per_face = sizeof(double) * 2 * (size_t)sc.vtot + (sizeof(PolyMeta) + 8) * (size_t)n;
     int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)24 << 30) / per_face));
     batch = std::min(batch, 65535);
+    for (int k = 0; k < 4; ++k) scene->last_vis_ms[k] = 0;
     for (int f0 = 0; f0 < n; f0 += batch) {
         const int f1 = std::min(n, f0 + batch);
         std::vector<int32_t> a_off, a_self;
@@ -1258,7 +1286,9 @@ extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, i
             a_normal.insert(a_normal.end(), scene->h_planes.begin() + 4 * (size_t)f, scene->h_planes.begin() + 4 * (size_t)f + 3);
             a_self.push_back(f);
         }
-        if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_rows.p + (size_t)f0 * n)) return -1;
+        if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_rows.p + (size_t)f0 * n,
+                            scene->last_vis_ms))
+            return -1;
     }
     uint8_t *d_dst = out;
     if (!on_device) {
@@ -1311,9 +1341,17 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
         rc = row_ids ? rt_visibility_rows(scene, n_rows, row_ids, strict, rows_out)
                      : rt_visibility_matrix(scene, strict, rows_out, 0);
     const hipError_t e = hipStreamSynchronize(scene->side_stream);
+    for (int k = 4; k < 8; ++k) scene->last_vis_ms[k] = 0;
+    if (rc == 0 && e == hipSuccess) job.add_times(scene->last_vis_ms + 4);
     if (rc) return -1;
     if (e != hipSuccess) RT_FAIL(std::string("rt_visibility_with_faces: ") + hipGetErrorString(e));
     RT_HIP(hipMemcpy(faces_out, d_faces.p, n * n_faces, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int rt_visibility_last_timing(rt_scene *scene, double *ms8) {
+    if (!scene || !ms8) RT_FAIL("rt_visibility_last_timing: null argument");
+    for (int k = 0; k < 8; ++k) ms8[k] = scene->last_vis_ms[k];
     return 0;
 }
 

@@ -187,6 +187,76 @@ def paths_of_problem(rtp):
     return batch, lines
 
 
+TABLE_COLUMNS = ["rx_id", "receiver", "path_type", "tx_angles", "rx_angles", "time_to_receiver", "field_strength",
+                 "path_power"]
+
+
+def path_labels(kind):
+    """The reference's path_type strings ('LOS', 'R' * k, 'R' * k + 'D') of the kernel's path kinds."""
+    kind = np.asarray(kind, dtype=np.int64)
+    names = {}
+    out = []
+    for k in kind.tolist():
+        if k not in names:
+            n_refl, has_edge = k & 255, k >> 8
+            names[k] = "LOS" if k == 0 else "R" * n_refl + ("D" if has_edge else "")
+        out.append(names[k])
+    return out
+
+
+def table_from_columns(n_rx, receivers, rx, labels, angles, time, field, power):
+    """The reference's result table (electromagnetism.py:577-607) from per-path columns whose rows are already in its
+    order (by receiver; line of sight, reflections, diffractions): one row per path, and one 'Impossible' row for every
+    receiver without a path (:594-598).  Built column by column instead of row by row."""
+    import pandas as pd
+
+    rx = np.asarray(rx, dtype=np.int64)
+    receivers = np.asarray(receivers, dtype=float).reshape(-1, 3)
+    has_path = np.zeros(n_rx, dtype=bool)
+    has_path[rx] = True
+    missing = np.flatnonzero(~has_path)
+    n, m = len(rx), len(missing)
+    # where each row goes: the paths keep their order, a receiver without paths takes the place its index gives it
+    all_rx = np.concatenate([rx, missing])
+    place = np.argsort(all_rx, kind="stable")
+    angles = np.asarray(angles, dtype=float).reshape(n, 4)
+    field = np.asarray(field).reshape(n, 3)
+
+    def column(values, filler):
+        col = np.empty(n + m, dtype=object)
+        col[:n] = values
+        for k in range(n, n + m):
+            col[k] = filler() if callable(filler) else filler
+        return col[place]
+
+    def rows_of(a):
+        out = np.empty(len(a), dtype=object)
+        for i, row in enumerate(a):  # (a slice assignment would try to make one 2-D array of the rows)
+            out[i] = row
+        return out
+
+    rx_rows = rows_of(receivers[rx]) if n else np.empty(0, dtype=object)
+    data = {
+        "rx_id": all_rx[place],
+        "receiver": None,
+        "path_type": column(np.asarray(labels, dtype=object) if n else np.empty(0, dtype=object), "Impossible"),
+        "tx_angles": column(rows_of(angles[:, 0:2].copy()), None),
+        "rx_angles": column(rows_of(angles[:, 2:4].copy()), None),
+        "time_to_receiver": column(np.asarray(time, dtype=float).astype(object) if n else np.empty(0, dtype=object), None),
+        "field_strength": column(rows_of(field.copy()), lambda: np.array([0, 0, 0])),
+        "path_power": column(np.asarray(power, dtype=float).astype(object) if n else np.empty(0, dtype=object), 0),
+    }
+    receiver_col = np.empty(n + m, dtype=object)
+    receiver_col[:n] = rx_rows
+    for k, r in enumerate(missing):
+        receiver_col[n + k] = receivers[r]
+    data["receiver"] = receiver_col[place]
+    df = pd.DataFrame(data, columns=TABLE_COLUMNS)
+    for name in ("time_to_receiver", "path_power"):  # plain numbers (None -> NaN), as a table made row by row has them
+        df[name] = df[name].infer_objects()
+    return df
+
+
 def my_field_computation(rtp, save_name="problem_fields", frequency=None, save=True):
     """Field and power of every path of every solved receiver; returns the reference's DataFrame and writes the CSV.
 
@@ -205,27 +275,15 @@ def my_field_computation(rtp, save_name="problem_fields", frequency=None, save=T
     all_polygons = rtp.place.get_polygons_list()
     n_late = len(all_polygons) - len(rtp.polygons)
     scene = geom.scene_arrays_of(all_polygons).device_scene() if n_late > 0 else rtp._device_scene()
-    rows = []
     if len(batch):
         res = batch.run(scene, tx, receivers, [mat.FREQUENCY if frequency is None else frequency],
                         n_late_polygons=max(n_late, 0))
         _raise_on_status(res["status"], batch.labels)
-    per_rx = {}
-    for i, r in enumerate(batch.rx):
-        per_rx.setdefault(r, []).append(i)
-    for r in range(n_rx):
-        if r not in per_rx:
-            rows.append({"rx_id": r, "receiver": receivers[r], "path_type": "Impossible", "tx_angles": None,
-                         "rx_angles": None, "time_to_receiver": None, "field_strength": np.array([0, 0, 0]),
-                         "path_power": 0})
-            continue
-        for i in per_rx[r]:
-            rows.append({"rx_id": r, "receiver": lines[i][-1], "path_type": batch.labels[i],
-                         "tx_angles": res["angles"][i, 0:2].copy(), "rx_angles": res["angles"][i, 2:4].copy(),
-                         "time_to_receiver": float(res["time"][i]), "field_strength": res["field"][i, 0].copy(),
-                         "path_power": float(res["power"][i, 0])})
-    df = pd.DataFrame(rows, columns=["rx_id", "receiver", "path_type", "tx_angles", "rx_angles", "time_to_receiver",
-                                     "field_strength", "path_power"])
+        df = table_from_columns(n_rx, receivers, np.asarray(batch.rx, dtype=np.int64), batch.labels, res["angles"],
+                                res["time"], res["field"][:, 0], res["power"][:, 0])
+    else:
+        df = table_from_columns(n_rx, receivers, np.zeros(0, dtype=np.int64), [], np.zeros((0, 4)), np.zeros(0),
+                                np.zeros((0, 3), dtype=complex), np.zeros(0))
     if save:
         electromagnetism_utils.save_df(df, save_name)
     return df

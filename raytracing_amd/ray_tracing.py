@@ -137,25 +137,49 @@ class RayTracingProblem:
         rx = np.asarray([self.receivers[i] for i in rx_ids], dtype=float).reshape(-1, 3)
         res = scene.solve_paths(cand, emitter.reshape(3), rx)
         self.path_solves_attempted += res["n_attempted"]
-        tx_row = emitter.reshape(1, 3)
-        edge_keys = [tuple(int(v) for v in k) for k in self._edge_pairs]
-        for local_rx, g, c, pts in zip(res["rx"], res["group"], res["cand"], res["points"]):
-            if g < 0:
-                continue  # lines of sight were stored by precompute()
-            r = rx_ids[int(local_rx)]
-            n_refl, has_edge = cand.group_kind(int(g))
-            chains, edge_ids = cand.group(int(g))
-            chain = [int(v) for v in chains[int(c)]] if n_refl else []
-            n_pts = n_refl + (1 if has_edge else 0)
-            lines = np.vstack([tx_row, pts[:n_pts], self.receivers[r].reshape(1, 3)])
-            if has_edge:
-                e = int(edge_ids[int(c)])
-                self.diffractions[r][n_refl + 1].append((lines, chain, edge_keys[e], self._edge_array[e].copy()))
-            else:
-                self.reflections[r][n_refl].append((lines, chain))
+        self.store_paths(np.asarray(rx_ids, dtype=np.int64)[res["rx"]], res["group"], res["cand"], res["points"], cand)
         cand.close()
         if max_order >= 2:
             self.solved_receivers = receivers  # the reference only gets here for max_order >= 2 (:352-353, 390)
+
+    def store_paths(self, rx, group, cand_index, points, cand):
+        """Appends solved paths to ``reflections`` / ``diffractions`` in the reference's container shapes
+        (ray_tracing.py:314, 350, 376).  ``rx``: receiver index of each path, ``group`` / ``cand_index``: its candidate
+        (lines of sight, group -1, are skipped: precompute stored them), ``points`` [P, RT_MAX_ORDER, 3]; the paths must
+        come sorted by (receiver, group, candidate), which is the reference's visiting order.  The point arrays of all
+        paths of a kind are put together at once; per path only the tuple is made."""
+        rx = np.asarray(rx, dtype=np.int64)
+        group = np.asarray(group, dtype=np.int64)
+        cand_index = np.asarray(cand_index, dtype=np.int64)
+        points = np.asarray(points, dtype=float).reshape(len(rx), _lib.RT_MAX_ORDER, 3)
+        emitter = np.asarray(self.emitter, dtype=float).reshape(1, 3)
+        receivers = np.asarray(self.receivers, dtype=float).reshape(-1, 3)
+        edge_keys = [tuple(int(v) for v in k) for k in self._edge_pairs]
+        items = [None] * len(rx)
+        for g in np.unique(group):
+            if g < 0:
+                continue
+            sel = np.flatnonzero(group == g)
+            n_refl, has_edge = cand.group_kind(int(g))
+            chains, edge_ids = cand.group(int(g))
+            n_pts = n_refl + (1 if has_edge else 0)
+            lines = np.empty((len(sel), n_pts + 2, 3))
+            lines[:, 0] = emitter
+            lines[:, 1:n_pts + 1] = points[sel, :n_pts]
+            lines[:, n_pts + 1] = receivers[rx[sel]]
+            chain_lists = chains[cand_index[sel]].tolist() if n_refl else [[] for _ in sel]
+            if has_edge:
+                e = edge_ids[cand_index[sel]]
+                edge_points = self._edge_array[e]  # a copy per path, as the reference's containers hold
+                for k, i in enumerate(sel):
+                    items[i] = (lines[k], chain_lists[k], edge_keys[e[k]], edge_points[k])
+            else:
+                for k, i in enumerate(sel):
+                    items[i] = (lines[k], chain_lists[k])
+        orders = np.where(group >= cand.max_order, group - cand.max_order + 1, group + 1)
+        for i in np.flatnonzero(group >= 0):  # in the given order
+            container = self.diffractions if group[i] >= cand.max_order else self.reflections
+            container[int(rx[i])][int(orders[i])].append(items[i])
 
     # ------------------------------------------------------------------------------------------------
     def path_set(self):

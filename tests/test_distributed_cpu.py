@@ -1,7 +1,7 @@
-"""The receiver-sharding path under a real 2-rank process group (gloo, CPU): block bounds, variable-length all-gather,
-path record round trip.  The solve itself needs a GPU and is covered by the gpu tests."""
+"""The receiver-sharding path under a real 2-rank process group (gloo, CPU): block bounds, variable-length all-gather of
+the per-path rows, all-gather of the fixed-size receiver records, failure propagation, visibility rows.  The solve
+itself needs a GPU and is covered by the gpu tests."""
 import os
-from collections import defaultdict
 
 import numpy as np
 import pytest
@@ -19,51 +19,77 @@ def test_shard_bounds_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-class FakeProblem:
-    def __init__(self, n_rx):
-        self.receivers = np.zeros((n_rx, 3))
-        self.reflections = {r: defaultdict(list) for r in range(n_rx)}
-        self.diffractions = {r: defaultdict(list) for r in range(n_rx)}
+def fake_block(begin, end):
+    """Per-path arrays as PathBlock.to_host() gives them for receivers [begin, end): a receiver r has r % 4 paths."""
+    from raytracing_amd import _lib
+
+    rx = np.concatenate([np.full(r % 4, r - begin) for r in range(begin, end)] + [np.zeros(0)]).astype(np.int32)
+    n = len(rx)
+    rng = np.random.default_rng(begin * 1000 + end)
+    return dict(rx=rx, group=rng.integers(-1, 4, n).astype(np.int32), cand=rng.integers(0, 1 << 30, n).astype(np.int32),
+                points=rng.normal(size=(n, _lib.RT_MAX_ORDER, 3)), kind=rng.integers(0, 260, n).astype(np.int32),
+                chain=rng.integers(-1, 7000, (n, _lib.RT_MAX_ORDER)).astype(np.int32),
+                edge_polys=rng.integers(-1, 7000, (n, 2)).astype(np.int32), edge_points=rng.normal(size=(n, 6)),
+                field=rng.normal(size=(n, 1, 6)), power=rng.random((n, 1)), angles=rng.normal(size=(n, 4)),
+                time=rng.random(n), status=rng.integers(0, 11, n).astype(np.int32))
 
 
-def make_paths(problem, rx_ids):
-    for r in rx_ids:
-        rng = np.random.default_rng(r)
-        for k in range(r % 3):
-            problem.reflections[r][1].append((rng.normal(size=(3, 3)), [int(rng.integers(0, 50))]))
-        if r % 2:
-            problem.reflections[r][2].append((rng.normal(size=(4, 3)), [3, 7]))
-            problem.diffractions[r][2].append((rng.normal(size=(4, 3)), [5], (2, 9), rng.normal(size=(2, 3))))
-        problem.diffractions[r][1].append((rng.normal(size=(3, 3)), [], (1, r + 2), rng.normal(size=(2, 3))))
+def check_rows(arrays, n_rx, world):
+    """The gathered rows are the blocks of all ranks one after the other, receiver indices global."""
+    from raytracing_amd import multithread_solve as mts
+
+    ok, at = True, 0
+    for r in range(world):
+        begin, end = mts.shard_bounds(n_rx, world, r)
+        want = fake_block(begin, end)
+        k = len(want["rx"])
+        ok = ok and np.array_equal(arrays["rx"][at:at + k], want["rx"] + begin)
+        for name in ("group", "cand", "kind", "chain", "edge_polys", "status"):
+            ok = ok and np.array_equal(arrays[name][at:at + k], want[name].reshape(arrays[name][at:at + k].shape))
+        for name in ("points", "edge_points", "angles", "time"):
+            ok = ok and np.array_equal(arrays[name][at:at + k], want[name])
+        ok = ok and np.array_equal(arrays["power"][at:at + k], want["power"][:, 0])
+        f = want["field"][:, 0]
+        ok = ok and np.array_equal(arrays["field"][at:at + k], f[:, 0::2] + 1j * f[:, 1::2])
+        at += k
+    return ok and at == len(arrays["rx"])
 
 
 def _worker(rank, world, port, n_rx, out_dir):
+    import torch
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracing_amd import device_pipeline as dp
     from raytracing_amd import multithread_solve as mts
 
     begin, end = mts.shard_bounds(n_rx, world, rank)
-    problem = FakeProblem(n_rx)
-    make_paths(problem, range(begin, end))
-    rows = mts.all_gather_rows(mts._encode_paths(problem, range(begin, end)))
-    merged = FakeProblem(n_rx)
-    mts._decode_paths(merged, rows)
+    rows = mts.all_gather_rows(mts.pack_path_rows(fake_block(begin, end), begin))
+    ok = check_rows(mts.unpack_path_rows(rows), n_rx, world)
     counts = mts.all_gather_rows(np.array([[float(end - begin)]]))
+    ok = ok and counts.sum() == n_rx
     np.save(os.path.join(out_dir, f"rows_{rank}.npy"), rows)
-    ok = counts.sum() == n_rx
-    want = FakeProblem(n_rx)
-    make_paths(want, range(n_rx))
-    for r in range(n_rx):
-        for order in want.reflections[r]:
-            a, b = merged.reflections[r][order], want.reflections[r][order]
-            ok = ok and len(a) == len(b) and all(np.array_equal(x[0], y[0]) and x[1] == y[1] for x, y in zip(a, b))
-        for order in want.diffractions[r]:
-            a, b = merged.diffractions[r][order], want.diffractions[r][order]
-            ok = ok and len(a) == len(b) and all(np.array_equal(x[0], y[0]) and x[1] == y[1] and x[2] == y[2] and
-                                                 np.array_equal(x[3], y[3]) for x, y in zip(a, b))
+    # the fixed-size receiver records: every rank ends with the records of all receivers, in receiver order
+    n_freq = 3
+    width = dp.record_bytes(n_freq)
+    local = np.zeros((end - begin, width), dtype=np.uint8)
+    db = np.arange(begin, end, dtype=np.float64)[:, None] * 10.0 - np.arange(n_freq)[None, :]
+    db[::3] = -np.inf
+    ints = (np.arange(begin, end, dtype=np.int32)[:, None] * 100 + np.arange(dp.N_INT_COLUMNS, dtype=np.int32)[None, :])
+    local[:, :8 * n_freq] = db.view(np.uint8).reshape(end - begin, -1)
+    local[:, 8 * n_freq:8 * n_freq + 4 * dp.N_INT_COLUMNS] = np.ascontiguousarray(ints).view(np.uint8).reshape(end - begin, -1)
+    gathered = dp.all_gather_records(torch.from_numpy(local), n_rx, dist)
+    rec = dp.unpack_records(gathered.numpy(), n_freq)
+    want_db = np.arange(n_rx, dtype=np.float64)[:, None] * 10.0 - np.arange(n_freq)[None, :]
+    for r in range(world):
+        b, _ = mts.shard_bounds(n_rx, world, r)
+        want_db[b::3][: len(range(b, mts.shard_bounds(n_rx, world, r)[1], 3))] = -np.inf
+    ok = ok and np.array_equal(rec["power_db"], want_db)
+    ok = ok and np.array_equal(rec["counts"][:, 2], np.arange(n_rx) * 100 + 2)
+    ok = ok and np.array_equal(rec["n_paths"], np.arange(n_rx) * 100 + dp.N_TYPES)
+    ok = ok and np.array_equal(rec["worst_status"], np.arange(n_rx) * 100 + dp.N_TYPES + 2)
     with open(os.path.join(out_dir, f"ok_{rank}"), "w") as f:
         f.write("1" if ok else "0")
     dist.barrier()
@@ -71,13 +97,46 @@ def _worker(rank, world, port, n_rx, out_dir):
 
 
 @pytest.mark.parametrize("n_rx", [5, 16])
-def test_two_rank_gather_of_path_records(tmp_path, n_rx):
+def test_two_rank_gather_of_path_rows_and_receiver_records(tmp_path, n_rx):
     import torch.multiprocessing as mp
 
     port = 29500 + (os.getpid() % 2000) + n_rx
     mp.spawn(_worker, args=(2, port, n_rx, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "ok_0").read() == "1" and open(tmp_path / "ok_1").read() == "1"
     np.testing.assert_array_equal(np.load(tmp_path / "rows_0.npy"), np.load(tmp_path / "rows_1.npy"))
+
+
+def _failing_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracing_amd import multithread_solve as mts
+
+    mts.raise_together(None)  # nobody failed: nobody raises
+    outcome = "none"
+    try:
+        mts.raise_together(AssertionError("incident angle should be in 0,90 deg") if rank == 0 else None)
+    except AssertionError as err:
+        outcome = "own:" + str(err)
+    except RuntimeError as err:
+        outcome = "other:" + str(err)
+    with open(os.path.join(out_dir, f"outcome_{rank}"), "w") as f:
+        f.write(outcome)
+    dist.barrier()  # reached by both: the failure did not leave anyone behind in a collective
+    dist.destroy_process_group()
+
+
+def test_a_failure_on_one_rank_raises_on_every_rank(tmp_path):
+    """Rank 0 fails in its part (as when the field step meets one of the reference's physics assertions): it raises its
+    own error, the other rank raises too instead of waiting at a barrier for ever."""
+    import torch.multiprocessing as mp
+
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_failing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "outcome_0").read().startswith("own:incident angle")
+    assert open(tmp_path / "outcome_1").read().startswith("other:") and "rank [0]" in open(tmp_path / "outcome_1").read()
 
 
 def test_single_process_gather_is_identity():
