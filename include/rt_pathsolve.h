@@ -101,6 +101,12 @@ int rt_debug_set_path_queue_capacity(rt_scene *scene, int64_t n_paths);
  * events around every launch; a small solve is bound by the latency of its few dependent launches and runs a little
  * faster without them.  rt_solve_last_timing reports zeros while it is off (no reference counterpart). */
 int rt_scene_set_timing(rt_scene *scene, int on);
+/* The painter cuts a face that has at least min_candidates candidate polygons into azimuth sectors of about per_tile
+ * candidates each, painted by different workgroups (a polygon is visible iff it shows in some sector); per_tile = 0
+ * paints every face whole; min_candidates = -1 (the default) lets each call choose: sectors when it paints at most 256
+ * faces (the emitter's screens), whole faces when it paints many (a matrix).  Same vectors either way; the switch exists so that tests can check one against the other
+ * on small scenes (no reference counterpart). */
+int rt_debug_set_visibility_tiling(rt_scene *scene, int32_t min_candidates, int32_t per_tile);
 /* Device time, in milliseconds, of the last visibility call on this scene (HIP events on the stream the kernels ran on,
  * while rt_scene_set_timing is on): ms[0] mapping to (azimuth, polar) and ring validity, ms[1] sorting by the painter's
  * key, ms[2] painting, ms[3] all of it, for the rows / the matrix; ms[4..7] the same for the extra faces of

@@ -46,6 +46,7 @@ _SIGNATURES = {
                                          c_void_p, c_int, c_void_p]),
     "rt_debug_visibility_stats": (c_int, [c_void_p]),
     "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
+    "rt_debug_set_visibility_tiling": (c_int, [c_void_p, c_int32, c_int32]),
     "rt_scene_set_timing": (c_int, [c_void_p, c_int]),
     "rt_debug_set_reflect_mode": (c_int, [c_void_p, c_int]),
     "rt_debug_set_path_queue_capacity": (c_int, [c_void_p, c_int64]),
@@ -273,6 +274,12 @@ class Scene:
     def set_occlusion_mode(self, mode):
         """0: obstruction kernel chosen by scene size (default); 1: every-polygon walk; 2: grid walk."""
         _check(load().rt_debug_set_occlusion_mode(self.handle, int(mode)), "rt_debug_set_occlusion_mode")
+
+    def set_visibility_tiling(self, min_candidates, per_tile):
+        """Faces with at least ``min_candidates`` candidates are painted in azimuth sectors of about ``per_tile``
+        candidates (``per_tile`` 0: every face whole)."""
+        _check(load().rt_debug_set_visibility_tiling(self.handle, int(min_candidates), int(per_tile)),
+               "rt_debug_set_visibility_tiling")
 
     def set_reflect_mode(self, mode):
         """0: reflection kernel chosen by batch size (default); 1: receivers one by one; 2: receivers in spatial tiles."""

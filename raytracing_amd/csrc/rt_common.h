@@ -118,6 +118,10 @@ struct rt_scene {
     size_t late_cap = 0;
     int64_t queue_capacity_override = 0;  // > 0: first size of the path queue (tests of the grow-and-redo route)
     int occlusion_mode = 0;  // 0 = by scene size, 1 = every-polygon walk, 2 = grid walk
+    // painter: a face with at least vis_tile_min candidates is painted in azimuth sectors of about vis_tile_size
+    // candidates each, by different workgroups (vis_tile_size 0: never)
+    // vis_tile_min -1 (the default): chosen per call, sectors only when a call paints few faces
+    int vis_tile_min = -1, vis_tile_size = 0;
     // timing of the last solve
     double last_ms[4] = {0, 0, 0, 0};
     int64_t last_launches[4] = {0, 0, 0, 0};

@@ -228,6 +228,7 @@ struct PaintScratch {
     double *splits;   // per wave [split_cap]
     int64_t split_cap;
     int32_t *work;    // per wave [2 * vtot]: (entry, vertex) of canvas edges that enter the current polygon
+    int32_t *tlist;   // per workgroup [n]: candidates of the tile being painted
 };
 
 // The polygons one coverage decision works on: entry 0 = the polygon B being decided, entries 1..count-1 = the canvas
@@ -330,16 +331,29 @@ struct CanvasSet {
     __device__ int sgn(int i) const { return st->sgns[slot(i)]; }
 };
 
-// Is the witness next to the middle of piece (t0, t1) of edge a->b, on side `side` (+1 = left of a->b), inside B and
-// outside every listed polygon?
+// A face with very many candidates is painted in tiles: azimuth sectors (x0, x1), each by its own workgroup, with the
+// candidates whose box reaches into the sector and a canvas of the polygons found visible INSIDE the sector.  A polygon
+// is visible iff part of it shows in some sector.  Inside a sector the uncovered part of B is bounded by pieces of B's
+// edges, of canvas edges and of the sector's two borders, so: every edge is also cut where it crosses a border, a
+// witness only counts inside the sector, and the borders themselves are examined like edges (witness on the sector's
+// inner side, inside B, outside every canvas polygon).  An unbounded span is the whole face.
+struct TileSpan {
+    double x0, x1;
+    __device__ bool bounded() const { return x0 > -INFINITY || x1 < INFINITY; }
+    __device__ bool holds(double x) const { return x > x0 && x < x1; }
+};
+
+// Is the witness next to the middle of piece (t0, t1) of edge a->b, on side `side` (+1 = left of a->b), inside the
+// tile, inside B and outside every listed polygon?
 template <typename Set>
 __device__ inline bool witness_uncovered(const Set &ps, double ax, double ay, double bx, double by, double t0, double t1,
-                                         double side, bool need_in_b) {
+                                         double side, bool need_in_b, const TileSpan &tile) {
     const double ex = bx - ax, ey = by - ay;
     const double len = sqrt(ex * ex + ey * ey);
     const double tm = 0.5 * (t0 + t1);
     const double wx = ax + tm * ex - side * VIS_DELTA * (ey / len);
     const double wy = ay + tm * ey + side * VIS_DELTA * (ex / len);
+    if (!tile.holds(wx)) return false;
     if (need_in_b) {
         if (!pip_ring(ps.x(0), ps.y(0), ps.nv(0), wx, wy)) return false;
     }
@@ -399,15 +413,22 @@ struct SplitBuf {
 // proves B visible.
 template <typename Set>
 __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay, double bx, double by, double side,
-                                 bool need_in_b, const SplitBuf &splits, int *lds_count) {
+                                 bool need_in_b, const SplitBuf &splits, int *lds_count, const TileSpan &tile) {
     const int lane = threadIdx.x & 63;
     const double ex = bx - ax, ey = by - ay;
     const double len = sqrt(ex * ex + ey * ey);
     if (!(len > VIS_MIN_PIECE)) return false;
     // ---- gather the cuts: lanes = entries, each walks its own ring
     if (lane == 0) {
-        *lds_count = 1;
+        int k = 1;
         splits.put(0, 0.0);
+        // the tile's borders cut the edge too (a piece must not straddle a border: its witness stands for all of it)
+        if (ex != 0.0) {
+            const double ta = (tile.x0 - ax) / ex, tb = (tile.x1 - ax) / ex;
+            if (ta > 0.0 && ta < 1.0) splits.put(k++, ta);
+            if (tb > 0.0 && tb < 1.0) splits.put(k++, tb);
+        }
+        *lds_count = k;
     }
     __builtin_amdgcn_wave_barrier();
     const int n = ps.count();
@@ -484,9 +505,10 @@ __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay,
                 if (ti > t0 && ti < t1) t1 = ti;
             }
             const double tm = 0.5 * (t0 + t1);
-            splits.px[lane] = ax + tm * ex - side * VIS_DELTA * (ey / len);
+            const double wx = ax + tm * ex - side * VIS_DELTA * (ey / len);
+            splits.px[lane] = wx;
             splits.py[lane] = ay + tm * ey + side * VIS_DELTA * (ex / len);
-            splits.pstate[lane] = (t1 - t0) * len > VIS_MIN_PIECE ? 1 : 0;
+            splits.pstate[lane] = ((t1 - t0) * len > VIS_MIN_PIECE && tile.holds(wx)) ? 1 : 0;
         }
         __builtin_amdgcn_wave_barrier();
         const int first = need_in_b ? 0 : 1;
@@ -523,7 +545,7 @@ __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay,
                 const double ti = splits.get(i);
                 if (ti > t0 && ti < t1) t1 = ti;
             }
-            if ((t1 - t0) * len > VIS_MIN_PIECE) mine = witness_uncovered(ps, ax, ay, bx, by, t0, t1, side, need_in_b);
+            if ((t1 - t0) * len > VIS_MIN_PIECE) mine = witness_uncovered(ps, ax, ay, bx, by, t0, t1, side, need_in_b, tile);
         }
         found = __any(mine);
     }
@@ -534,7 +556,8 @@ __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay,
 // Called by all waves of the workgroup with identical arguments (the result is uniform over the workgroup): the cheap
 // shortcuts are computed by every wave, the edge examinations are dealt out to the waves and joined through `flag`.
 template <typename Set>
-__device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *lds_count, int32_t *work, int *flag) {
+__device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *lds_count, int32_t *work, int *flag,
+                                  const TileSpan &tile) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int n = ps.count();
     const int nv = ps.nv(0);
@@ -569,11 +592,14 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
         const int n_samples = nv < 8 ? nv + 1 : 9;
         // lanes = samples: the point, and whether it is inside B; then lanes = (sample, entry) pairs
         if (lane < n_samples) {
-            const double px = lane == 0 ? gx : 0.5 * (gx + x[(lane - 1) * nv / (n_samples - 1)]);
+            double px = lane == 0 ? gx : 0.5 * (gx + x[(lane - 1) * nv / (n_samples - 1)]);
             const double py = lane == 0 ? gy : 0.5 * (gy + y[(lane - 1) * nv / (n_samples - 1)]);
+            // a sample outside the tile proves nothing there: it is moved onto the middle line of the part of the tile
+            // that B's box reaches (and then has to be inside B like any other)
+            if (!tile.holds(px)) px = 0.5 * (fmax(tile.x0, bx0) + fmin(tile.x1, bx1));
             splits.px[lane] = px;
             splits.py[lane] = py;
-            splits.pstate[lane] = pip_ring(x, y, nv, px, py) ? 1 : 0;
+            splits.pstate[lane] = (tile.holds(px) && pip_ring(x, y, nv, px, py)) ? 1 : 0;
         }
         __builtin_amdgcn_wave_barrier();
         const int per_sample = n - 1;
@@ -652,7 +678,7 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
     for (int v = wave; v < nv; v += n_waves) {
         if (*(volatile int *)flag) break;
         const int u = v == 0 ? nv - 1 : v - 1;
-        if (edge_has_witness(ps, 0, x[u], y[u], x[v], y[v], sgn_b, false, splits, lds_count) && lane == 0) *flag = 1;
+        if (edge_has_witness(ps, 0, x[u], y[u], x[v], y[v], sgn_b, false, splits, lds_count, tile) && lane == 0) *flag = 1;
     }
     __syncthreads();
     PHASE(2);
@@ -721,15 +747,29 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
     __threadfence_block();
     PHASE(3);
     if (lane == 0 && wave == 0) VIS_STAT(2, n_work);
-    for (int w = wave; w < n_work; w += n_waves) {
+    // (the tile's two borders, where they pass through B's box, are examined with them: witness on the tile's inner
+    // side, inside B like the others; a->b upwards, so side +1 is the side of smaller azimuth)
+    const int n_border = tile.bounded() ? 2 : 0;
+    for (int w = wave; w < n_work + n_border; w += n_waves) {
         if (*(volatile int *)flag) break;
-        const int li = work[2 * w], v = work[2 * w + 1];
-        const int cn = ps.nv(li);
-        const double *cx = ps.x(li), *cy = ps.y(li);
-        const int u = v == 0 ? cn - 1 : v - 1;
+        int li = -1;
+        double ax, ay, ex_, ey_, side;
+        if (w < n_work) {
+            li = work[2 * w];
+            const int v = work[2 * w + 1];
+            const int cn = ps.nv(li);
+            const double *cx = ps.x(li), *cy = ps.y(li);
+            const int u = v == 0 ? cn - 1 : v - 1;
+            ax = cx[u]; ay = cy[u]; ex_ = cx[v]; ey_ = cy[v];
+            side = -(double)ps.sgn(li);
+        } else {
+            const double t = w == n_work ? tile.x0 : tile.x1;
+            if (!(t > bx0 && t < bx1)) continue;
+            ax = t; ay = by0 - 1e-6; ex_ = t; ey_ = by1 + 1e-6;
+            side = w == n_work ? -1.0 : 1.0;
+        }
         if (lane == 0) VIS_STAT(6, 1);
-        if (edge_has_witness(ps, li, cx[u], cy[u], cx[v], cy[v], -(double)ps.sgn(li), true, splits, lds_count) && lane == 0)
-            *flag = 1;
+        if (edge_has_witness(ps, li, ax, ay, ex_, ey_, side, true, splits, lds_count, tile) && lane == 0) *flag = 1;
     }
     __syncthreads();
     PHASE(4);
@@ -823,6 +863,89 @@ __global__ __launch_bounds__(1024) void k_face_queue(const int32_t *__restrict__
     }
 }
 
+#define VIS_MAX_TILES 128
+#define VIS_TILE_BINS 1024
+
+// Azimuth sectors of every face: a face with fewer than min_candidates candidates is one unbounded tile; a larger one
+// gets ceil(m / per_tile) sectors (at most VIS_MAX_TILES) holding about the same number of candidate centres each
+// (quantiles of a 1 024-bin histogram of the centres' azimuth).  bounds[f * (VIS_MAX_TILES + 1) + t] .. [+ t + 1] is
+// sector t; the first and last sectors are open-ended.  One workgroup per face.
+__global__ __launch_bounds__(256) void k_vis_tiles(int n, const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
+                                                    int m_stride, const int32_t *__restrict__ counts, int min_candidates,
+                                                    int per_tile, double *__restrict__ bounds, int32_t *__restrict__ n_tiles) {
+    __shared__ int hist[VIS_TILE_BINS];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int m = counts[f];
+    double *b = bounds + (size_t)f * (VIS_MAX_TILES + 1);
+    int T = 1;
+    if (m >= min_candidates && per_tile > 0) T = min(VIS_MAX_TILES, (m + per_tile - 1) / per_tile);
+    if (T <= 1) {
+        if (tid == 0) {
+            b[0] = -INFINITY;
+            b[1] = INFINITY;
+            n_tiles[f] = 1;
+        }
+        return;
+    }
+    for (int i = tid; i < VIS_TILE_BINS; i += 256) hist[i] = 0;
+    __syncthreads();
+    const PolyMeta *meta_f = meta + (size_t)f * n;
+    const int32_t *ord = order + (size_t)f * m_stride;
+    const double scale = VIS_TILE_BINS / (2.0 * M_PI);
+    for (int k = tid; k < m; k += 256) {
+        const PolyMeta &mb = meta_f[ord[k]];
+        int bin = (int)((0.5 * (mb.xmin + mb.xmax) + M_PI) * scale);
+        bin = bin < 0 ? 0 : (bin >= VIS_TILE_BINS ? VIS_TILE_BINS - 1 : bin);
+        atomicAdd(&hist[bin], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int cum = 0, t = 1, used = 1;
+        b[0] = -INFINITY;
+        for (int bin = 0; bin < VIS_TILE_BINS && t < T; ++bin) {
+            cum += hist[bin];
+            bool placed = false;
+            while (t < T && (long long)cum * T >= (long long)t * m) {
+                // a border at the upper end of this bin, nudged off the round value so that it does not run along a
+                // polygon edge that sits exactly on a bin's end; one border per bin at most
+                if (!placed && bin + 1 < VIS_TILE_BINS) {
+                    b[used++] = -M_PI + (bin + 1) / scale + 1.234567e-7;
+                    placed = true;
+                }
+                ++t;
+            }
+        }
+        b[used] = INFINITY;
+        n_tiles[f] = used;
+    }
+}
+
+// item_off[q] = tiles of the faces before place q of the queue (queue null: face order); item_off[n_faces] = all
+__global__ __launch_bounds__(1024) void k_vis_item_offsets(const int32_t *__restrict__ n_tiles, const int32_t *__restrict__ queue,
+                                                            int n_faces, int32_t *__restrict__ item_off) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_faces; base += 1024) {
+        const int q = base + threadIdx.x;
+        const int v = q < n_faces ? n_tiles[queue ? queue[q] : q] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (q < n_faces) item_off[q] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) item_off[n_faces] = carry;
+}
+
 // One workgroup (NW waves: four when many faces are painted at once, sixteen for a handful) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
 // polygons whose box meets it and stages them in LDS; all waves then decide coverage together.
 template <typename Store, int NW>
@@ -830,8 +953,13 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                                                     const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
                                                     int m_stride, const int32_t *__restrict__ counts, PaintScratch ps,
                                                     int strict, unsigned long long *work_counter,
-                                                    const int32_t *__restrict__ face_queue, uint8_t *__restrict__ out) {
+                                                    const int32_t *__restrict__ face_queue,
+                                                    const double *__restrict__ tile_bounds,
+                                                    const int32_t *__restrict__ item_off, uint8_t *__restrict__ out) {
     __shared__ int lds_counts[NW];
+    __shared__ int s_wcnt[NW];
+    __shared__ int s_tile, s_mt;
+    __shared__ TileSpan s_span;
     __shared__ union {
         LocalStore staged;   // used once the face's canvas no longer fits the resident store
         Store canvas;        // used until then
@@ -845,6 +973,7 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
     LocalStore *store = &stores.staged;
     Store *cs = &stores.canvas;
     int32_t *list = ps.list + (int64_t)blockIdx.x * sc.n;
+    int32_t *tlist = ps.tlist + (int64_t)blockIdx.x * sc.n;  // the candidates of the tile being painted, in painter's order
     int32_t *canvas = ps.canvas + (int64_t)blockIdx.x * sc.n;
     double *cbox = ps.cbox + (int64_t)blockIdx.x * sc.n * 4;
     const int64_t wave_id = (int64_t)blockIdx.x * NW + wave;
@@ -856,11 +985,36 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned long long fq = atomicAdd(work_counter, 1ull);
-            s_face = fq < (unsigned long long)fb.n_faces ? (face_queue ? face_queue[fq] : (int)fq) : -1;
+            if (item_off) {
+                // work item = (face, tile): place q of the queue holds items item_off[q] .. item_off[q + 1]
+                const unsigned long long n_items = (unsigned long long)item_off[fb.n_faces];
+                if (fq < n_items) {
+                    int lo = 0, hi = fb.n_faces - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if ((unsigned long long)item_off[mid] <= fq) lo = mid; else hi = mid - 1;
+                    }
+                    s_face = face_queue ? face_queue[lo] : lo;
+                    s_tile = (int)fq - item_off[lo];
+                } else {
+                    s_face = -1;
+                }
+            } else {
+                s_face = fq < (unsigned long long)fb.n_faces ? (face_queue ? face_queue[fq] : (int)fq) : -1;
+                s_tile = 0;
+            }
         }
         __syncthreads();
         const int f = s_face;
         if (f < 0) break;
+        // the sector lives in LDS and is read where it is needed: held in registers through the whole decision it
+        // pushed the kernel from 138 to 219 vector registers and into scratch memory
+        if (threadIdx.x == 0) {
+            s_span.x0 = tile_bounds ? tile_bounds[(size_t)f * (VIS_MAX_TILES + 1) + s_tile] : -INFINITY;
+            s_span.x1 = tile_bounds ? tile_bounds[(size_t)f * (VIS_MAX_TILES + 1) + s_tile + 1] : INFINITY;
+        }
+        __syncthreads();
+        const TileSpan &span = s_span;
         const PolyMeta *meta_f = meta + (size_t)f * sc.n;
         const double *sph_f = sph + (size_t)f * sc.vtot * 2;
         uint8_t *out_f = out + (size_t)f * sc.n;
@@ -871,7 +1025,37 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
             continue;
         }
         const int32_t *ord = order + (size_t)f * m_stride;
-        const int m = counts[f];
+        int m = counts[f];
+        if (span.bounded()) {
+            // the tile's candidates: those whose box reaches into the sector, kept in painter's order
+            if (threadIdx.x == 0) s_mt = 0;
+            __syncthreads();
+            for (int base = 0; base < m; base += 64 * NW) {
+                const int k = base + (int)threadIdx.x;
+                int B = -1;
+                bool take = false;
+                if (k < m) {
+                    B = ord[k];
+                    take = meta_f[B].xmax > span.x0 && meta_f[B].xmin < span.x1;
+                }
+                const unsigned long long mk = __ballot(take);
+                if (lane == 0) s_wcnt[wave] = __popcll(mk);
+                __syncthreads();
+                int at = s_mt + __popcll(mk & ((1ull << lane) - 1));
+                for (int w = 0; w < wave; ++w) at += s_wcnt[w];
+                if (take) tlist[at] = B;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    int tot = 0;
+                    for (int w = 0; w < NW; ++w) tot += s_wcnt[w];
+                    s_mt += tot;
+                }
+                __syncthreads();
+            }
+            __threadfence_block();
+            m = s_mt;
+            ord = tlist;
+        }
         int n_canvas = 0;
         bool resident = true;  // wave 0's view; the others read s_resident after the barrier
         int n_cs = 0, used = 0;
@@ -884,6 +1068,8 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
 #endif
             const int B = ord[k];  // uniform over the workgroup
             const PolyMeta mb = meta_f[B];
+            // what of B can show in this tile lies in B's box cut to the sector: only canvas polygons reaching there matter
+            const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
             if (wave == 0 && resident) {
                 const int v0 = sc.vert_off[B], nvb = sc.vert_off[B + 1] - v0;
                 if (n_cs >= Store::max_poly - 1 || used + 2 * nvb > Store::max_coord) resident = false;
@@ -896,7 +1082,7 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                     bool take = false;
                     if (ci < n_cs) {
                         const double *cb = cs->boxes + 4 * ci;
-                        take = !(cb[1] < mb.xmin || cb[0] > mb.xmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
                     }
                     const unsigned long long mk = __ballot(take);
                     if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = ci;
@@ -951,7 +1137,7 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                     int C = -1;
                     if (ci < n_canvas) {
                         const double *cb = cbox + 4 * (size_t)ci;
-                        take = !(cb[1] < mb.xmin || cb[0] > mb.xmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
                         C = canvas[ci];
                     }
                     const unsigned long long mk = __ballot(take);
@@ -967,7 +1153,7 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                 // ---- stage B and the listed polygons in LDS when they fit
                 const int n_entries = n_list + 1;
                 int total = 0;
-                bool fits = n_list > 0 && n_entries <= LS_MAX_POLY;
+                bool fits = (n_list > 0 || span.bounded()) && n_entries <= LS_MAX_POLY;
                 if (fits) {
                     for (int base = 0; base < n_entries; base += 64) {
                         const int li = base + lane;
@@ -1019,18 +1205,20 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
             const unsigned long long t_b = wall_clock64();
 #endif
             const int n_list = s_nlist;
-            bool visible = n_list == 0;
+            // nothing of the canvas near B: B shows (a valid ring has area); in a tile it still has to be shown that B
+            // reaches into the sector at all (its box does, its ring may not)
+            bool visible = n_list == 0 && !span.bounded();
             const bool res_now = s_resident != 0;
             if (!visible) {
                 if (res_now) {
                     CanvasSet<Store> cv{cs, s_ncs, n_list + 1};
-                    visible = polygon_uncovered(cv, splits, lds_count, work, &s_flag);
+                    visible = polygon_uncovered(cv, splits, lds_count, work, &s_flag, span);
                 } else if (s_fits) {
                     LocalSet ls{store, n_list + 1};
-                    visible = polygon_uncovered(ls, splits, lds_count, work, &s_flag);
+                    visible = polygon_uncovered(ls, splits, lds_count, work, &s_flag, span);
                 } else {
                     GlobalSet gs{&sc, sph_f, meta_f, list, B, n_list + 1};
-                    visible = polygon_uncovered(gs, splits, lds_count, work, &s_flag);
+                    visible = polygon_uncovered(gs, splits, lds_count, work, &s_flag, span);
                 }
             }
 #ifdef RT_VIS_STAMPS
@@ -1091,7 +1279,7 @@ struct DevBuf {
 // Device buffers of one batch of faces: they live until the batch's kernels have run.
 struct RowsJob {
     DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work,
-        b_queue;
+        b_queue, b_tlist, b_bounds, b_ntiles, b_itemoff;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, mapped, sorted, painted
     ~RowsJob() {
         for (hipEvent_t e : ev)
@@ -1120,7 +1308,9 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
            &b_meta = job.b_meta, &b_list = job.b_list, &b_canvas = job.b_canvas, &b_cbox = job.b_cbox, &b_splits = job.b_splits,
            &b_counter = job.b_counter, &b_order = job.b_order, &b_counts = job.b_counts, &b_work = job.b_work;
     // persistent workgroups of 4 waves, one face per workgroup at a time
-    int n_blocks = n_faces > 1024 ? 1024 : n_faces;
+    // (a face may be painted as up to VIS_MAX_TILES work items)
+    const int64_t max_items = strict ? n_faces : (int64_t)n_faces * VIS_MAX_TILES;
+    int n_blocks = (int)std::min<int64_t>(n_faces > 256 ? 1024 : 256, max_items);
     const int64_t split_cap = 3 * (int64_t)sc.vtot + 8;
     int m_stride = 1;
     while (m_stride < sc.n) m_stride <<= 1;
@@ -1134,7 +1324,9 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         b_cbox.alloc(sizeof(double) * 4 * (size_t)sc.n * n_blocks) || b_splits.alloc(sizeof(double) * (size_t)split_cap * n_waves) ||
         b_counter.alloc(sizeof(unsigned long long)) || b_order.alloc(sizeof(int32_t) * (size_t)m_stride * n_faces) ||
         b_counts.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_queue.alloc(sizeof(int32_t) * (size_t)n_faces) ||
-        b_work.alloc(sizeof(int32_t) * 2 * (size_t)sc.vtot * n_waves))
+        b_work.alloc(sizeof(int32_t) * 2 * (size_t)sc.vtot * n_waves) || job.b_tlist.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) ||
+        job.b_bounds.alloc(sizeof(double) * (VIS_MAX_TILES + 1) * (size_t)n_faces) ||
+        job.b_ntiles.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_itemoff.alloc(sizeof(int32_t) * ((size_t)n_faces + 1)))
         RT_FAIL("visibility: out of device memory");
     RT_HIP(hipMemcpyAsync(b_off.p, a_off.data(), sizeof(int32_t) * a_off.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(b_verts.p, a_verts.data(), sizeof(double) * a_verts.size(), hipMemcpyHostToDevice, st));
@@ -1154,24 +1346,45 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     if (!strict)
         hipLaunchKernelGGL(k_vis_sort, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,
                            (int32_t *)b_order.p, m_stride, (int32_t *)b_counts.p);
-    const int32_t *face_queue = nullptr;
-    if (!strict && n_faces > n_blocks) {  // with a workgroup per face there is nothing to order
+    const int32_t *face_queue = nullptr, *item_off = nullptr;
+    const double *tile_bounds = nullptr;
+    if (!strict) {
+        // faces in order of their candidate count, most first; each cut into azimuth sectors when it has very many
+        // candidates; the persistent workgroups take (face, sector) items from a counter
         hipLaunchKernelGGL(k_face_queue, dim3(1), dim3(1024), 0, st, (const int32_t *)b_counts.p, n_faces, sc.n,
                            (int32_t *)job.b_queue.p);
         face_queue = (const int32_t *)job.b_queue.p;
+        // Sectors pay when there are too few faces to fill the chip (the emitter's six screens: one workgroup each
+        // would paint for as long as the whole matrix takes everybody else).  With hundreds of faces in flight they
+        // only add work: a polygon is decided again in every sector it reaches into (lln's matrix: 0.64 s whole,
+        // 3.1 s in sectors of 192).
+        int tile_min = scene->vis_tile_min, tile_size = scene->vis_tile_size;
+        if (tile_min < 0) {
+            tile_min = n_faces <= 256 ? 512 : 0;
+            tile_size = n_faces <= 256 ? 48 : 0;
+        }
+        hipLaunchKernelGGL(k_vis_tiles, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,
+                           (const int32_t *)b_order.p, m_stride, (const int32_t *)b_counts.p, tile_min, tile_size,
+                           (double *)job.b_bounds.p, (int32_t *)job.b_ntiles.p);
+        hipLaunchKernelGGL(k_vis_item_offsets, dim3(1), dim3(1024), 0, st, (const int32_t *)job.b_ntiles.p, face_queue, n_faces,
+                           (int32_t *)job.b_itemoff.p);
+        tile_bounds = (const double *)job.b_bounds.p;
+        item_off = (const int32_t *)job.b_itemoff.p;
     }
     if (job.ev[2]) RT_HIP(hipEventRecord(job.ev[2], st));
     PaintScratch ps{(int32_t *)b_list.p, (int32_t *)b_canvas.p, (double *)b_cbox.p, (double *)b_splits.p, split_cap,
-                    (int32_t *)b_work.p};
+                    (int32_t *)b_work.p, (int32_t *)job.b_tlist.p};
     // at most one face per CU: the large canvas store (one workgroup per CU) costs no parallelism
     if (n_faces <= 256)
         hipLaunchKernelGGL((k_vis_paint<LargeCanvasStore, 16>), dim3(n_blocks), dim3(1024), 0, st, sc, fb,
                            (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
-                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, face_queue, d_out);
+                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, face_queue, tile_bounds,
+                           item_off, d_out);
     else
         hipLaunchKernelGGL((k_vis_paint<SmallCanvasStore, 4>), dim3(n_blocks), dim3(256), 0, st, sc, fb,
                            (const double *)b_sph.p, (const PolyMeta *)b_meta.p, (const int32_t *)b_order.p, m_stride,
-                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, face_queue, d_out);
+                           (const int32_t *)b_counts.p, ps, strict, (unsigned long long *)b_counter.p, face_queue, tile_bounds,
+                           item_off, d_out);
     if (job.ev[3]) RT_HIP(hipEventRecord(job.ev[3], st));
     RT_HIP(hipGetLastError());
     return 0;
@@ -1346,6 +1559,13 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
     if (rc) return -1;
     if (e != hipSuccess) RT_FAIL(std::string("rt_visibility_with_faces: ") + hipGetErrorString(e));
     RT_HIP(hipMemcpy(faces_out, d_faces.p, n * n_faces, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int rt_debug_set_visibility_tiling(rt_scene *scene, int32_t min_candidates, int32_t per_tile) {
+    if (!scene || min_candidates < -1 || per_tile < 0) RT_FAIL("rt_debug_set_visibility_tiling: bad argument");
+    scene->vis_tile_min = min_candidates;
+    scene->vis_tile_size = per_tile;
     return 0;
 }
 

@@ -127,15 +127,54 @@ def test_contains_point_matches_oracle(places):
         dist = pts @ p.normal + p.parametric[3]
         pts = pts - np.outer(dist, p.normal)
         pts[::10] += 1e-3 * p.normal
-        pts = np.vstack([pts, p.points, (p.points + np.roll(p.points, 1, axis=0)) / 2])
+        # (the ring's own vertices and side middles are left to test_contains_point_includes_the_boundary, which builds
+        # them where they are exact: on these polygons, whose frames are not axis-aligned, a point meant to lie on the
+        # ring lands a rounding error to one side or the other of it, differently in a matrix product and in three
+        # dot products, and 6 of 242 such points got different answers from the two sides)
         for check in (False, True):
             got = scene.contains_points(idx, pts, check, 1e-8)
             want = np.array([go.contains_point(p, q, check) for q in pts])
-            # vertices and edge midpoints sit exactly on the boundary up to rounding: both answers are noise there
-            interior = np.ones(len(pts), dtype=bool)
-            interior[-2 * len(p.points):] = False
-            np.testing.assert_array_equal(got[interior], want[interior])
-            assert got[interior].sum() > 5
+            np.testing.assert_array_equal(got, want)
+            assert got.sum() > 5
+
+
+def test_contains_point_includes_the_boundary(places):
+    """The reference's test is shapely's Polygon.intersects(Point) (geometry.py:1803): a point ON the ring is inside.
+    Boundary points are built in the polygon's own frame, where they are exact: rings whose in-plane coordinates are
+    small integers and halves (every product and difference of the crossing test is then exact in binary64), the
+    vertices themselves and the middles of the sides.  Outside points a hair off the sides stay outside."""
+    from oracle import geometry_oracle as go
+    from raytracing_amd import geometry as geom
+
+    rings = [np.array([[0, 0], [8, 0], [8, 4], [0, 4]], dtype=float),
+             np.array([[0, 0], [6, 0], [6, 2], [2, 2], [2, 6], [0, 6]], dtype=float),          # L shape (not convex)
+             np.array([[-4, -2], [4, -2], [6, 2], [0, 6], [-6, 2]], dtype=float)]  # first side along an axis: exact frame
+    planes = [("z", 2.0), ("x", -3.0), ("y", 0.0)]  # horizontal, and two walls: exact axis-aligned frames
+    for ring in rings:
+        for axis, level in planes:
+            pts3 = {"z": np.column_stack([ring[:, 0], ring[:, 1], np.full(len(ring), level)]),
+                    "x": np.column_stack([np.full(len(ring), level), ring[:, 0], ring[:, 1]]),
+                    "y": np.column_stack([ring[:, 1], np.full(len(ring), level), ring[:, 0]])}[axis]
+            polygon = geom.OrientedPolygon(pts3)
+            oracle_poly = go.Poly(pts3)
+            oracle_poly.parametric = polygon.get_parametric().copy()
+            scene = geom.scene_arrays_of([polygon]).device_scene()
+            mids = (pts3 + np.roll(pts3, -1, axis=0)) / 2
+            quarter = pts3 + (np.roll(pts3, -1, axis=0) - pts3) / 4
+            on_boundary = np.vstack([pts3, mids, quarter])
+            for check in (False, True):
+                got = scene.contains_points(0, on_boundary, check, 1e-8)
+                assert got.all(), f"boundary points reported outside: {on_boundary[~got][:4].tolist()}"
+                want = np.array([go.contains_point(oracle_poly, q, check) for q in on_boundary])
+                assert want.all()
+            # a hair outside each side (outward normal of a counter-clockwise / clockwise ring found from the centroid)
+            centre = pts3.mean(axis=0)
+            outward = mids - centre
+            outside = mids + 1e-6 * outward / np.linalg.norm(outward, axis=1)[:, None]
+            got = scene.contains_points(0, outside, False, 1e-8)
+            want = np.array([go.contains_point(oracle_poly, q, False) for q in outside])
+            np.testing.assert_array_equal(got, want)
+            scene.close()
 
 
 @pytest.mark.parametrize("name", ["small", "ny", "place_levant", "place_saint_jean/place_saint_jean"])
@@ -307,4 +346,33 @@ def test_matrix_and_screens_in_one_call_equal_the_separate_calls(places, name):
     r0, v4 = scene.visibility_with_faces(screens, row_ids=np.zeros(0, np.int32))
     assert r0.shape == (0, len(polygons))
     np.testing.assert_array_equal(v4, vectors)
+    scene.close()
+
+
+@pytest.mark.parametrize("name,per_tile", [("small", 3), ("ny", 5), ("place_levant", 7), ("place_levant", 40),
+                                            ("place_saint_jean/place_saint_jean", 24)])
+def test_faces_painted_in_sectors_see_what_faces_painted_whole_see(places, name, per_tile):
+    """A face with very many candidates is painted in azimuth sectors by different workgroups (a polygon is visible iff
+    it shows in some sector).  With the threshold forced down every face of these scenes is cut into sectors of a few
+    candidates each: the matrix and the emitter's screens must be those of faces painted whole."""
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import scenarios
+
+    place = places(name)
+    polygons = place.get_polygons_list()
+    lo, hi = place.get_domain()
+    tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 20.0)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    screens = [(s.points, s.get_parametric(), -1) for s in cube.polygons]
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    scene.set_visibility_tiling(0, 0)
+    whole_matrix, whole_screens = scene.visibility_with_faces(screens)
+    scene.set_visibility_tiling(2 * per_tile, per_tile)
+    matrix, vectors = scene.visibility_with_faces(screens)
+    bad = np.argwhere(matrix != whole_matrix)
+    assert len(bad) == 0, f"{len(bad)} matrix entries differ, first {bad[:10].tolist()}"
+    bad = np.argwhere(vectors != whole_screens)
+    assert len(bad) == 0, f"{len(bad)} screen entries differ, first {bad[:10].tolist()}"
+    assert whole_matrix.sum() > 50 and whole_screens.sum() > 10
     scene.close()
