@@ -84,12 +84,14 @@ __device__ inline bool segments_meet(double ax, double ay, double bx, double by,
 }
 
 // Valid ring: finite, >= 3 distinct vertices after dropping repeats, non-zero area, edges meet only at shared ends.
+// (Index arithmetic wraps with a comparison, not a remainder: an integer division costs tens of instructions and this
+// runs for every (face, polygon) pair.)
 __device__ bool ring_is_valid(const double *x, const double *y, int n_in, int *sgn) {
     for (int i = 0; i < n_in; ++i)
         if (!isfinite(x[i]) || !isfinite(y[i])) return false;
     // a vertex equal to its predecessor is a repeat and is skipped (repeated points are accepted)
     auto kept = [&](int i) {
-        const int p = (i + n_in - 1) % n_in;
+        const int p = i == 0 ? n_in - 1 : i - 1;
         return !(x[i] == x[p] && y[i] == y[p]);
     };
     int n = 0;
@@ -97,14 +99,14 @@ __device__ bool ring_is_valid(const double *x, const double *y, int n_in, int *s
     if (n < 3) return false;
     double area2 = 0;
     for (int i = 0; i < n_in; ++i) {
-        const int j = (i + 1) % n_in;
+        const int j = i + 1 == n_in ? 0 : i + 1;
         area2 += x[i] * y[j] - x[j] * y[i];
     }
     if (area2 == 0) return false;
     *sgn = area2 > 0 ? 1 : -1;
     auto next_kept = [&](int i) {
-        int j = (i + 1) % n_in;
-        while (!kept(j)) j = (j + 1) % n_in;
+        int j = i + 1 == n_in ? 0 : i + 1;
+        while (!kept(j)) j = j + 1 == n_in ? 0 : j + 1;
         return j;
     };
     for (int i = 0; i < n_in; ++i) {
@@ -128,6 +130,66 @@ __device__ bool ring_is_valid(const double *x, const double *y, int n_in, int *s
     return true;
 }
 
+// The same predicate decided by one wave: lanes take vertices, then edge pairs (i uniform, lanes over j > i).  x, y may
+// be in LDS or global memory; kept and nxt are per-wave scratch of n_in ints each.  Wave-uniform result.
+__device__ bool ring_is_valid_wave(const double *x, const double *y, int n_in, int *sgn, int *kept, int *nxt) {
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    int n = 0;
+    for (int base = 0; base < n_in; base += 64) {
+        const int i = base + lane;
+        bool k = false;
+        if (i < n_in) {
+            if (!isfinite(x[i]) || !isfinite(y[i])) bad = true;
+            const int p = i == 0 ? n_in - 1 : i - 1;
+            k = !(x[i] == x[p] && y[i] == y[p]);
+            kept[i] = k ? 1 : 0;
+        }
+        n += __popcll(__ballot(k));
+    }
+    if (__any(bad)) return false;
+    if (n < 3) return false;
+    __builtin_amdgcn_wave_barrier();
+    double area2 = 0;  // summed in ring order by every lane alike: its sign and its being zero are what matter
+    for (int i = 0; i < n_in; ++i) {
+        const int j = i + 1 == n_in ? 0 : i + 1;
+        area2 += x[i] * y[j] - x[j] * y[i];
+    }
+    if (area2 == 0) return false;
+    *sgn = area2 > 0 ? 1 : -1;
+    for (int base = 0; base < n_in; base += 64) {
+        const int i = base + lane;
+        if (i < n_in) {
+            int j = i + 1 == n_in ? 0 : i + 1;
+            while (!kept[j]) j = j + 1 == n_in ? 0 : j + 1;
+            nxt[i] = j;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < n_in; ++i) {
+        if (!kept[i]) continue;  // uniform
+        const int i2 = nxt[i];
+        for (int base = i + 1; base < n_in; base += 64) {
+            const int j = base + lane;
+            bool meet = false;
+            if (j < n_in && kept[j]) {
+                const int j2 = nxt[j];
+                if (j == i2 || j2 == i) {
+                    int a, b, c;
+                    if (j == i2) { a = i; b = i2; c = j2; } else { a = j; b = j2; c = i2; }
+                    const double cr = orient2(x[a], y[a], x[b], y[b], x[c], y[c]);
+                    const double dt = (x[b] - x[a]) * (x[c] - x[b]) + (y[b] - y[a]) * (y[c] - y[b]);
+                    meet = cr == 0 && dt < 0;
+                } else {
+                    meet = segments_meet(x[i], y[i], x[i2], y[i2], x[j], y[j], x[j2], y[j2]);
+                }
+            }
+            if (__any(meet)) return false;
+        }
+    }
+    return true;
+}
+
 __device__ inline void face_frame(const FaceBatch &fb, int f, d3 &fx, d3 &fy, d3 &fz, d3 &c) {
     const int v0 = fb.a_off[f], nv = fb.a_off[f + 1] - v0;
     const double *p = fb.a_verts + 3 * (size_t)v0;
@@ -145,12 +207,20 @@ __device__ inline void face_frame(const FaceBatch &fb, int f, d3 &fx, d3 &fy, d3
     fy = divs(fy, norm3(fy));
 }
 
+// Polygons of up to VIS_SMALL_POLY vertices (walls are quads: most of a scene) are prepared one per thread; the others
+// (roofs, up to a hundred vertices and more) one per wave, in k_vis_prepare_big: in a wave of 64 polygons one such roof
+// used to keep 63 quads waiting through its vertex loop and its ring check, which is quadratic in the vertices.
+#define VIS_SMALL_POLY 4
+#define VIS_BIG_LDS 256 /* vertices of a polygon whose mapped ring is staged in LDS for the wave's ring check */
+
 // one thread per (face, polygon)
 __global__ __launch_bounds__(256) void k_vis_prepare(SceneView sc, FaceBatch fb, double *__restrict__ sph,
                                                       PolyMeta *__restrict__ meta) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
     if (b >= sc.n) return;
+    const int v0 = sc.vert_off[b], nv = sc.vert_off[b + 1] - v0;
+    if (nv > VIS_SMALL_POLY) return;  // k_vis_prepare_big writes its record
     PolyMeta m;
     m.state = 0;
     m.sgn = 1;
@@ -163,39 +233,135 @@ __global__ __launch_bounds__(256) void k_vis_prepare(SceneView sc, FaceBatch fb,
     }
     d3 fx, fy, fz, c;
     face_frame(fb, f, fx, fy, fz, c);
-    const int v0 = sc.vert_off[b], nv = sc.vert_off[b + 1] - v0;
     double *az = sph + ((size_t)f * sc.vtot + v0) * 2;
     double *pol = az + nv;
     double zmax = -INFINITY, rmin = INFINITY;
     double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
     // the z filter first (geometry.py:967-970): about half of a scene lies behind a face, and those polygons are not
     // mapped (nobody reads the mapped vertices of a polygon that is not a candidate)
-    for (int v = 0; v < nv; ++v) zmax = fmax(zmax, dot(ld3(sc.verts + 3 * (size_t)(v0 + v)) - c, fz));
+    d3 q[VIS_SMALL_POLY];
+#pragma unroll
+    for (int v = 0; v < VIS_SMALL_POLY; ++v) {
+        q[v] = ld3(sc.verts + 3 * (size_t)(v0 + (v < nv ? v : 0))) - c;
+        if (v < nv) zmax = fmax(zmax, dot(q[v], fz));
+    }
     if (!(zmax > TOL_DZ)) {
         *out = m;
         return;
     }
-    for (int v = 0; v < nv; ++v) {
-        const d3 q = ld3(sc.verts + 3 * (size_t)(v0 + v)) - c;
-        const double qx = dot(q, fx), qy = dot(q, fy), qz = dot(q, fz);
+    double xs[VIS_SMALL_POLY], ys[VIS_SMALL_POLY];
+#pragma unroll
+    for (int v = 0; v < VIS_SMALL_POLY; ++v) {
+        const double qx = dot(q[v], fx), qy = dot(q[v], fy), qz = dot(q[v], fz);
         const double r = sqrt(qx * qx + qy * qy + qz * qz);  // geometry.py:302-306
         const double a = atan2(qy, qx);
         const double p = acos(qz / r);
-        az[v] = a;
-        pol[v] = p;
-        rmin = fmin(rmin, r);
-        lo0 = fmin(lo0, a); hi0 = fmax(hi0, a);
-        lo1 = fmin(lo1, p); hi1 = fmax(hi1, p);
-        lo2 = fmin(lo2, r); hi2 = fmax(hi2, r);
+        xs[v] = a;
+        ys[v] = p;
+        if (v < nv) {
+            az[v] = a;
+            pol[v] = p;
+            rmin = fmin(rmin, r);
+            lo0 = fmin(lo0, a); hi0 = fmax(hi0, a);
+            lo1 = fmin(lo1, p); hi1 = fmax(hi1, p);
+            lo2 = fmin(lo2, r); hi2 = fmax(hi2, r);
+        }
     }
     const double cx = (lo0 + hi0) / 2, cy = (lo1 + hi1) / 2, cz = (lo2 + hi2) / 2;
     m.key1 = rmin;  // geometry.py:980-984
     m.key2 = sqrt(cx * cx + cy * cy + cz * cz);
     m.xmin = lo0; m.xmax = hi0; m.ymin = lo1; m.ymax = hi1;
     int sgn = 1;
-    m.state = ring_is_valid(az, pol, nv, &sgn) ? 2 : 1;
+    m.state = ring_is_valid(xs, ys, nv, &sgn) ? 2 : 1;
     m.sgn = sgn;
     *out = m;
+}
+
+// one wave per (face, polygon of more than VIS_SMALL_POLY vertices): big[] lists those polygons
+__global__ __launch_bounds__(256) void k_vis_prepare_big(SceneView sc, FaceBatch fb, const int32_t *__restrict__ big, int n_big,
+                                                          double *__restrict__ sph, PolyMeta *__restrict__ meta) {
+    __shared__ double s_xy[4][2 * VIS_BIG_LDS];
+    __shared__ int s_kept[4][VIS_BIG_LDS], s_nxt[4][VIS_BIG_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wave;
+    const int f = blockIdx.y;
+    if (k >= n_big) return;
+    const int b = big[k];
+    PolyMeta m;
+    m.state = 0;
+    m.sgn = 1;
+    m.key1 = m.key2 = 0;
+    m.xmin = m.xmax = m.ymin = m.ymax = 0;
+    PolyMeta *out = meta + (size_t)f * sc.n + b;
+    if (b == fb.a_self[f]) {
+        if (lane == 0) *out = m;
+        return;
+    }
+    d3 fx, fy, fz, c;
+    face_frame(fb, f, fx, fy, fz, c);
+    const int v0 = sc.vert_off[b], nv = sc.vert_off[b + 1] - v0;
+    double zmax = -INFINITY;
+    for (int base = 0; base < nv; base += 64) {
+        const int v = base + lane;
+        if (v < nv) zmax = fmax(zmax, dot(ld3(sc.verts + 3 * (size_t)(v0 + v)) - c, fz));
+    }
+    for (int off = 32; off > 0; off >>= 1) zmax = fmax(zmax, __shfl_xor(zmax, off));
+    if (!(zmax > TOL_DZ)) {
+        if (lane == 0) *out = m;
+        return;
+    }
+    double *az = sph + ((size_t)f * sc.vtot + v0) * 2;
+    double *pol = az + nv;
+    const bool staged = nv <= VIS_BIG_LDS;
+    double *xs = staged ? s_xy[wave] : az, *ys = staged ? s_xy[wave] + nv : pol;
+    double rmin = INFINITY;
+    double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+    for (int base = 0; base < nv; base += 64) {
+        const int v = base + lane;
+        if (v < nv) {
+            const d3 q = ld3(sc.verts + 3 * (size_t)(v0 + v)) - c;
+            const double qx = dot(q, fx), qy = dot(q, fy), qz = dot(q, fz);
+            const double r = sqrt(qx * qx + qy * qy + qz * qz);
+            const double a = atan2(qy, qx);
+            const double p = acos(qz / r);
+            az[v] = a;
+            pol[v] = p;
+            if (staged) {
+                xs[v] = a;
+                ys[v] = p;
+            }
+            rmin = fmin(rmin, r);
+            lo0 = fmin(lo0, a); hi0 = fmax(hi0, a);
+            lo1 = fmin(lo1, p); hi1 = fmax(hi1, p);
+            lo2 = fmin(lo2, r); hi2 = fmax(hi2, r);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        rmin = fmin(rmin, __shfl_xor(rmin, off));
+        lo0 = fmin(lo0, __shfl_xor(lo0, off)); hi0 = fmax(hi0, __shfl_xor(hi0, off));
+        lo1 = fmin(lo1, __shfl_xor(lo1, off)); hi1 = fmax(hi1, __shfl_xor(hi1, off));
+        lo2 = fmin(lo2, __shfl_xor(lo2, off)); hi2 = fmax(hi2, __shfl_xor(hi2, off));
+    }
+    const double cx = (lo0 + hi0) / 2, cy = (lo1 + hi1) / 2, cz = (lo2 + hi2) / 2;
+    m.key1 = rmin;
+    m.key2 = sqrt(cx * cx + cy * cy + cz * cz);
+    m.xmin = lo0; m.xmax = hi0; m.ymin = lo1; m.ymax = hi1;
+    int sgn = 1;
+    bool valid;
+    if (staged) {
+        __builtin_amdgcn_wave_barrier();
+        valid = ring_is_valid_wave(xs, ys, nv, &sgn, s_kept[wave], s_nxt[wave]);
+    } else {
+        // a ring too long for the wave's LDS scratch: one lane walks it, reading the mapped vertices back
+        __threadfence_block();
+        int ok = 0;
+        if (lane == 0) ok = ring_is_valid(az, pol, nv, &sgn) ? 1 : 0;
+        valid = __shfl(ok, 0) != 0;
+        sgn = __shfl(sgn, 0);
+    }
+    m.state = valid ? 2 : 1;
+    m.sgn = sgn;
+    if (lane == 0) *out = m;
 }
 
 __device__ inline bool painted_before(const PolyMeta &c, int ci, const PolyMeta &b, int bi) {
@@ -1279,7 +1445,8 @@ struct DevBuf {
 // Device buffers of one batch of faces: they live until the batch's kernels have run.
 struct RowsJob {
     DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work,
-        b_queue, b_tlist, b_bounds, b_ntiles, b_itemoff;
+        b_queue, b_tlist, b_bounds, b_ntiles, b_itemoff, b_big;
+    std::vector<int32_t> h_big;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, mapped, sorted, painted
     ~RowsJob() {
         for (hipEvent_t e : ev)
@@ -1332,6 +1499,13 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     RT_HIP(hipMemcpyAsync(b_verts.p, a_verts.data(), sizeof(double) * a_verts.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(b_normal.p, a_normal.data(), sizeof(double) * a_normal.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(b_self.p, a_self.data(), sizeof(int32_t) * a_self.size(), hipMemcpyHostToDevice, st));
+    // the polygons that are prepared one per wave
+    std::vector<int32_t> &big = job.h_big;  // lives until the stream has been waited for
+    big.clear();
+    for (int i = 0; i < sc.n; ++i)
+        if (scene->h_vert_off[i + 1] - scene->h_vert_off[i] > VIS_SMALL_POLY) big.push_back(i);
+    if (job.b_big.alloc(sizeof(int32_t) * big.size())) RT_FAIL("visibility: out of device memory");
+    if (!big.empty()) RT_HIP(hipMemcpyAsync(job.b_big.p, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemsetAsync(b_counter.p, 0, sizeof(unsigned long long), st));
     RT_HIP(hipMemsetAsync(d_out, 0, (size_t)sc.n * n_faces, st));
     FaceBatch fb{n_faces, (const int32_t *)b_off.p, (const double *)b_verts.p, (const double *)b_normal.p,
@@ -1342,6 +1516,9 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     }
     hipLaunchKernelGGL(k_vis_prepare, dim3((sc.n + 255) / 256, n_faces), dim3(256), 0, st, sc, fb, (double *)b_sph.p,
                        (PolyMeta *)b_meta.p);
+    if (!big.empty())
+        hipLaunchKernelGGL(k_vis_prepare_big, dim3(((unsigned)big.size() + 3) / 4, n_faces), dim3(256), 0, st, sc, fb,
+                           (const int32_t *)job.b_big.p, (int)big.size(), (double *)b_sph.p, (PolyMeta *)b_meta.p);
     if (job.ev[1]) RT_HIP(hipEventRecord(job.ev[1], st));
     if (!strict)
         hipLaunchKernelGGL(k_vis_sort, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,

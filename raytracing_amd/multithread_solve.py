@@ -112,6 +112,10 @@ def sharded_visibility(scene, screens, strict=False, dist=None):
     all-gather.  A screen of a large scene costs as much as hundreds of matrix rows, so the screens must not be
     repeated on every rank.  Returns (matrix bool [N, N], screen vectors bool [len(screens), N])."""
     n = scene.n
+    dist = dist or _dist()
+    if dist is None or dist.get_world_size() == 1:
+        # one rank paints everything: matrix (symmetrised on the device) and screens side by side
+        return scene.visibility_with_faces(screens, strict=strict)
 
     def rows_of(ids):
         ids = np.asarray(ids, dtype=np.int64)
