@@ -162,6 +162,13 @@ int rt_candidates_group(const rt_candidates *cand, int32_t group, int32_t *chain
 int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double *tx, const double *rx, int64_t n_rx,
                    int32_t *out_rx, int32_t *out_group, int32_t *out_cand, double *out_points, int64_t capacity,
                    int64_t *n_found, int64_t *n_attempted, int on_device);
+/* Reference-compatible mode of rt_solve_paths (off by default).  The reference keeps a candidate only when SciPy's hybr
+ * reports success on its system (ray_tracing.py:309, 345, 371 with geometry.py:682, 744, 823), and hybr misses some
+ * roots; the kernels find every root in closed form.  With the mode on, every path found is put through a restatement
+ * of that solver (MINPACK hybrd / hybrj on the reference's zero functions, first guess, tolerances and arithmetic, on
+ * the GPU) and kept only when it reports success and its points pass the reference's checks; the points returned are
+ * then the solver's.  n_found counts the kept paths. */
+int rt_scene_set_reference_solver(rt_scene *scene, int on);
 /* Device time, in milliseconds, and launch count of each kernel family during the last rt_solve_paths call on this
  * scene (measured with HIP events on the scene's stream): [0] reflection candidates, [1] diffraction candidates,
  * [2] segment obstruction, [3] finalisation.  ms[4], launches[4].  *segments_tested = segments the obstruction kernels

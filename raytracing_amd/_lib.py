@@ -48,6 +48,7 @@ _SIGNATURES = {
     "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
     "rt_debug_set_visibility_tiling": (c_int, [c_void_p, c_int32, c_int32]),
     "rt_scene_set_timing": (c_int, [c_void_p, c_int]),
+    "rt_scene_set_reference_solver": (c_int, [c_void_p, c_int]),
     "rt_debug_set_reflect_mode": (c_int, [c_void_p, c_int]),
     "rt_debug_set_path_queue_capacity": (c_int, [c_void_p, c_int64]),
     "rt_visibility_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int]),
@@ -274,6 +275,11 @@ class Scene:
     def set_occlusion_mode(self, mode):
         """0: obstruction kernel chosen by scene size (default); 1: every-polygon walk; 2: grid walk."""
         _check(load().rt_debug_set_occlusion_mode(self.handle, int(mode)), "rt_debug_set_occlusion_mode")
+
+    def set_reference_solver(self, on):
+        """Reference-compatible mode of the solve: every found path is re-judged with a restatement of SciPy's hybr on
+        the reference's own systems and dropped when the reference's solver would not have reported it."""
+        _check(load().rt_scene_set_reference_solver(self.handle, int(bool(on))), "rt_scene_set_reference_solver")
 
     def set_visibility_tiling(self, min_candidates, per_tile):
         """Faces with at least ``min_candidates`` candidates are painted in azimuth sectors of about ``per_tile``

@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libraytracing_amd.so")
 SOURCES = ["scene.hip", "occlusion.hip", "solve.hip", "visibility.hip", "sharp_edges.hip", "fields.hip", "channel_stats.hip",
-           "radiomap.hip"]
-HEADERS = ["rt_common.h", "rt_candidates.h", "rt_fresnel.h", os.path.join("..", "..", "include", "rt_pathsolve.h")]
+           "radiomap.hip", "reference_solver.hip"]
+HEADERS = ["rt_common.h", "rt_candidates.h", "rt_fresnel.h", "rt_hybrd.h", os.path.join("..", "..", "include", "rt_pathsolve.h")]
 # packed-fp32 instructions are switched off: the compiler forms them by itself from ordinary float code and some of
 # their forms have given wrong results on this hardware (the host pass warns that it does not know the feature)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",

@@ -1,0 +1,590 @@
+// The reference's solver, restated: MINPACK's hybrd / hybrj (Powell's hybrid method, the default method "hybr" of
+// scipy.optimize.root, which the reference calls at raytracing/geometry.py:682, 744, 823) applied to the reference's own
+// zero functions (geometry.py:635-657 reflections, :690-715 diffraction with its hand-written derivative, :751-797
+// reflections + diffraction), with SciPy's defaults (xtol 1.49012e-8, maxfev 200 (n + 1) resp. 100 (n + 1), factor 100,
+// forward differences with step sqrt(machine epsilon), diag from the column norms).
+//
+// Why it exists: the reference keeps a candidate path only when this solver reports success (ray_tracing.py:309, 345,
+// 371), and the solver does not always report the root of these systems when one exists.  The library's kernels find
+// the roots in closed form; in "reference-compatible" mode every path they found is put through this routine, started
+// where the reference starts it, and is dropped when the reference's solver would not have reported it.
+//
+// The arithmetic follows the reference's as it runs on the machine its fixtures were made on, operation by operation:
+// MINPACK's loops without fused multiply-adds (SciPy's build has none); NumPy's three-element dot product, norm and
+// small matrix products as OpenBLAS computes them there (fused chains in the orders noted at dot3 / times_matrix /
+// times_matrix_t).  The iterates then agree with SciPy's bit for bit (tests/golden/solvers.json: x, success, nfev).
+//
+// Compiles for the device (hipcc) and for the host (a plain C++ compiler, for the CPU test of the restatement).
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__
+#pragma clang fp contract(off)
+#else
+#define RT_HD
+#endif
+
+namespace rt_hybr {
+
+#define RT_HYBR_MAX_N 13 /* 3 unknowns per reflection (RT_MAX_ORDER = 4) + 1 */
+
+RT_HD inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// numpy.dot of two 3-vectors (OpenBLAS ddot, n = 3): the first product rounded, then two fused steps
+RT_HD inline double dot3(const double *a, const double *b) { return fma_(a[2], b[2], fma_(a[1], b[1], a[0] * b[0])); }
+// numpy.linalg.norm of a 3-vector: sqrt(x.dot(x))
+RT_HD inline double norm3(const double *a) { return sqrt(dot3(a, a)); }
+// (1,3) @ M for a C-contiguous 3x3 M (row-major m[3*k + j]): out[j] = sum_k a[k] M[k][j], fused in the order k = 0, 1, 2
+RT_HD inline void times_matrix(const double *a, const double *m, double *out) {
+    for (int j = 0; j < 3; ++j) out[j] = fma_(a[2], m[6 + j], fma_(a[1], m[3 + j], a[0] * m[j]));
+}
+// (1,3) @ M.T for the same M given as a transposed view: out[j] = sum_k a[k] M[j][k], fused in the order k = 1, 0, 2
+RT_HD inline void times_matrix_t(const double *a, const double *m, double *out) {
+    for (int j = 0; j < 3; ++j) out[j] = fma_(a[2], m[3 * j + 2], fma_(a[0], m[3 * j], a[1] * m[3 * j + 1]));
+}
+
+// projection_matrix_from_vector (geometry.py:414-435): columns x, y, z of the returned matrix, row-major m[3*i + j]
+RT_HD inline void projection_matrix(const double *v, double *m) {
+    const double nv = norm3(v);
+    double z[3], y[3], x[3];
+    for (int i = 0; i < 3; ++i) z[i] = v[i] / nv;
+    const double ones[3] = {1.0, 1.0, 1.0};
+    const double s = dot3(ones, z);
+    for (int i = 0; i < 3; ++i) y[i] = 1.0 - s * z[i];
+    const double ny = norm3(y);
+    for (int i = 0; i < 3; ++i) y[i] = y[i] / ny;
+    x[0] = y[1] * z[2] - y[2] * z[1];
+    x[1] = y[2] * z[0] - y[0] * z[2];
+    x[2] = y[0] * z[1] - y[1] * z[0];
+    for (int i = 0; i < 3; ++i) {
+        m[3 * i + 0] = x[i];
+        m[3 * i + 1] = y[i];
+        m[3 * i + 2] = z[i];
+    }
+}
+
+// One of the reference's three systems.  n_refl planes (normal, d), the fixed end points, and for a diffracting edge the
+// edge-aligned frame with what the reference precomputes in it.
+struct System {
+    int n_refl;        // reflections
+    int has_edge;      // ends with a diffraction
+    double normal[4][3], d[4];
+    double points[6][3];  // origin, the reflection points being iterated, then the destination (or the edge's first end)
+    double matrix[9];     // projection_matrix(edge[1] - edge[0]), row-major
+    double ze, Xe[3], projected_A[3], projected_B[3];
+    RT_HD int n_unknowns() const { return 3 * n_refl + (has_edge ? 1 : 0); }
+};
+
+// __generate__ (geometry.py:608-632) and the set-up of the three solvers (:676-687, :733-748, :802-833): fills the
+// system and the first guess x0.
+RT_HD inline void setup(System &s, const double *origin, const double *destination, const double *planes, int n_refl,
+                        const double *edge, double *x0) {
+    s.n_refl = n_refl;
+    s.has_edge = edge != nullptr;
+    for (int k = 0; k < 3; ++k) {
+        s.points[0][k] = origin[k];
+        s.points[n_refl + 1][k] = destination[k];
+    }
+    for (int i = 0; i < n_refl; ++i) {
+        for (int k = 0; k < 3; ++k) s.normal[i][k] = planes[4 * i + k];
+        s.d[i] = planes[4 * i + 3];
+        const double t = 2 * (s.d[i] + dot3(s.points[i], s.normal[i]));
+        for (int k = 0; k < 3; ++k) s.points[i + 1][k] = 0.5 * ((s.points[i][k] + destination[k]) - t * s.normal[i][k]);
+    }
+    if (edge) {
+        double v[3] = {edge[3] - edge[0], edge[4] - edge[1], edge[5] - edge[2]};
+        projection_matrix(v, s.matrix);
+        times_matrix(edge, s.matrix, s.Xe);
+        s.ze = s.Xe[2];
+        times_matrix(destination, s.matrix, s.projected_B);
+        if (n_refl == 0) {
+            times_matrix(origin, s.matrix, s.projected_A);
+            x0[0] = s.ze;
+            return;
+        }
+        for (int k = 0; k < 3; ++k) s.points[n_refl + 1][k] = edge[k];  // geometry.py:821: stays there for the whole solve
+    }
+    for (int i = 0; i < n_refl; ++i)
+        for (int k = 0; k < 3; ++k) x0[3 * i + k] = s.points[i + 1][k];
+    if (edge) x0[3 * n_refl] = edge[0];  // geometry.py:824: points[1:].flat[:-2] ends with the world x of the edge's first end
+}
+
+// residual of the diffraction equation for the point of the edge at height z1 (in the edge frame) seen from pA
+RT_HD inline double keller(const System &s, const double *pA, double x_last, double *jac) {
+    const double t = x_last - s.ze;
+    double xn[3] = {s.Xe[0], s.Xe[1], s.Xe[2] + t};
+    double i_[3], d_[3];
+    for (int k = 0; k < 3; ++k) {
+        i_[k] = xn[k] - pA[k];
+        d_[k] = s.projected_B[k] - xn[k];
+    }
+    const double num1 = (s.ze - pA[2]) + t;
+    const double num2 = (s.projected_B[2] - s.ze) - t;
+    const double den1 = norm3(i_), den2 = norm3(d_);
+    if (jac) {
+        const double den1_prime = num1 / den1, den2_prime = -num2 / den2;
+        *jac = (-num1 - den1_prime) / (den1 * den1) - (num2 - den2_prime) / (den2 * den2);
+    }
+    return num1 / den1 - num2 / den2;
+}
+
+// the zero functions: f = F(x); jac only for the pure diffraction (n = 1), where the reference hands its own derivative
+RT_HD inline void evaluate(System &s, const double *x, double *f, double *jac) {
+    const int n = s.n_refl;
+    if (n == 0) {
+        f[0] = keller(s, s.projected_A, x[0], jac);
+        return;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) s.points[i + 1][k] = x[3 * i + k];
+    double v[5][3], norms[5];
+    for (int i = 0; i <= n; ++i) {
+        for (int k = 0; k < 3; ++k) v[i][k] = s.points[i + 1][k] - s.points[i][k];
+        norms[i] = norm3(v[i]);
+    }
+    for (int i = 0; i < n; ++i) {
+        const double g = norms[i] / norms[i + 1];
+        const double t = 2 * (s.d[i] + dot3(s.points[i], s.normal[i]));
+        for (int k = 0; k < 3; ++k) f[3 * i + k] = (g * v[i + 1][k] - v[i][k]) - t * s.normal[i][k];
+    }
+    if (s.has_edge) {
+        double pA[3];
+        times_matrix(s.points[n], s.matrix, pA);
+        f[3 * n] = keller(s, pA, x[3 * n], nullptr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MINPACK
+// ---------------------------------------------------------------------------------------------------------------
+#define RT_EPSMCH 2.220446049250313e-16
+#define RT_GIANT 1.7976931348623157e308
+
+RT_HD inline double enorm(int n, const double *x, int stride = 1) {
+    const double rdwarf = 3.834e-20, rgiant = 1.304e19;
+    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
+    const double agiant = rgiant / (double)n;
+    for (int i = 0; i < n; ++i) {
+        const double xabs = fabs(x[i * stride]);
+        if (xabs > rdwarf && xabs < agiant) {
+            s2 += xabs * xabs;
+        } else if (xabs <= rdwarf) {
+            if (xabs > x3max) {
+                const double r = x3max / xabs;
+                s3 = 1 + s3 * (r * r);
+                x3max = xabs;
+            } else if (xabs != 0) {
+                const double r = xabs / x3max;
+                s3 += r * r;
+            }
+        } else {
+            if (xabs > x1max) {
+                const double r = x1max / xabs;
+                s1 = 1 + s1 * (r * r);
+                x1max = xabs;
+            } else {
+                const double r = xabs / x1max;
+                s1 += r * r;
+            }
+        }
+    }
+    if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
+    if (s2 != 0) {
+        if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
+        return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+    }
+    return x3max * sqrt(s3);
+}
+
+// matrices are column-major with leading dimension RT_HYBR_MAX_N, as MINPACK holds them: a(i, j) = a[i + LD * j]
+#define RT_LD RT_HYBR_MAX_N
+#define A_(a, i, j) (a)[(i) + RT_LD * (j)]
+
+RT_HD inline void qrfac(int n, double *a, double *rdiag, double *acnorm, double *wa) {
+    for (int j = 0; j < n; ++j) {
+        acnorm[j] = enorm(n, &A_(a, 0, j));
+        rdiag[j] = acnorm[j];
+        wa[j] = rdiag[j];
+    }
+    for (int j = 0; j < n; ++j) {
+        double ajnorm = enorm(n - j, &A_(a, j, j));
+        if (ajnorm != 0) {
+            if (A_(a, j, j) < 0) ajnorm = -ajnorm;
+            for (int i = j; i < n; ++i) A_(a, i, j) /= ajnorm;
+            A_(a, j, j) += 1;
+            for (int k = j + 1; k < n; ++k) {
+                double sum = 0;
+                for (int i = j; i < n; ++i) sum += A_(a, i, j) * A_(a, i, k);
+                const double temp = sum / A_(a, j, j);
+                for (int i = j; i < n; ++i) A_(a, i, k) -= temp * A_(a, i, j);
+            }
+        }
+        rdiag[j] = -ajnorm;
+    }
+}
+
+RT_HD inline void qform(int n, double *q, double *wa) {
+    for (int j = 1; j < n; ++j)
+        for (int i = 0; i < j; ++i) A_(q, i, j) = 0;
+    for (int l = 0; l < n; ++l) {
+        const int k = n - l - 1;
+        for (int i = k; i < n; ++i) {
+            wa[i] = A_(q, i, k);
+            A_(q, i, k) = 0;
+        }
+        A_(q, k, k) = 1;
+        if (wa[k] != 0) {
+            for (int j = k; j < n; ++j) {
+                double sum = 0;
+                for (int i = k; i < n; ++i) sum += A_(q, i, j) * wa[i];
+                const double temp = sum / wa[k];
+                for (int i = k; i < n; ++i) A_(q, i, j) -= temp * wa[i];
+            }
+        }
+    }
+}
+
+// r: upper triangle stored by rows (r[0] = r11, r12 ... r1n, r22 ...)
+RT_HD inline void dogleg(int n, const double *r, const double *diag, const double *qtb, double delta, double *x, double *wa1,
+                         double *wa2) {
+    int jj = (n * (n + 1)) / 2;  // one past the last element (0-based)
+    for (int k = 1; k <= n; ++k) {
+        const int j = n - k;  // 0-based row
+        jj -= k;
+        int l = jj + 1;
+        double sum = 0;
+        for (int i = j + 1; i < n; ++i) {
+            sum += r[l] * x[i];
+            ++l;
+        }
+        double temp = r[jj];
+        if (temp == 0) {
+            l = j;
+            for (int i = 0; i <= j; ++i) {
+                temp = fmax(temp, fabs(r[l]));
+                l += n - i - 1;
+            }
+            temp = RT_EPSMCH * temp;
+            if (temp == 0) temp = RT_EPSMCH;
+        }
+        x[j] = (qtb[j] - sum) / temp;
+    }
+    for (int j = 0; j < n; ++j) {
+        wa1[j] = 0;
+        wa2[j] = diag[j] * x[j];
+    }
+    const double qnorm = enorm(n, wa2);
+    if (qnorm <= delta) return;
+    int l = 0;
+    for (int j = 0; j < n; ++j) {
+        const double temp = qtb[j];
+        for (int i = j; i < n; ++i) {
+            wa1[i] += r[l] * temp;
+            ++l;
+        }
+        wa1[j] /= diag[j];
+    }
+    const double gnorm = enorm(n, wa1);
+    double sgnorm = 0;
+    double alpha = delta / qnorm;
+    if (gnorm != 0) {
+        for (int j = 0; j < n; ++j) wa1[j] = (wa1[j] / gnorm) / diag[j];
+        l = 0;
+        for (int j = 0; j < n; ++j) {
+            double sum = 0;
+            for (int i = j; i < n; ++i) {
+                sum += r[l] * wa1[i];
+                ++l;
+            }
+            wa2[j] = sum;
+        }
+        double temp = enorm(n, wa2);
+        sgnorm = (gnorm / temp) / temp;
+        alpha = 0;
+        if (sgnorm < delta) {
+            const double bnorm = enorm(n, qtb);
+            temp = (bnorm / gnorm) * (bnorm / qnorm) * (sgnorm / delta);
+            const double d1 = sgnorm / delta, d2 = temp - delta / qnorm, d3 = delta / qnorm, d4 = sgnorm / delta;
+            temp = temp - delta / qnorm * (d1 * d1) + sqrt(d2 * d2 + (1 - d3 * d3) * (1 - d4 * d4));
+            const double d5 = sgnorm / delta;
+            alpha = delta / qnorm * (1 - d5 * d5) / temp;
+        }
+    }
+    const double temp = (1 - alpha) * fmin(sgnorm, delta);
+    for (int j = 0; j < n; ++j) x[j] = temp * wa1[j] + alpha * x[j];
+}
+
+RT_HD inline void r1updt(int n, double *s, const double *u, double *v, double *w, bool *sing) {
+    const double p5 = 0.5, p25 = 0.25;
+    int jj = (n * (n + 1)) / 2 - 1;  // 0-based index of the last diagonal element (m = n)
+    w[n - 1] = s[jj];
+    for (int j = n - 2; j >= 0; --j) {
+        jj -= n - j;
+        w[j] = 0;
+        if (v[j] != 0) {
+            double cos_, sin_, tau;
+            if (fabs(v[n - 1]) < fabs(v[j])) {
+                const double cotan = v[n - 1] / v[j];
+                sin_ = p5 / sqrt(p25 + p25 * (cotan * cotan));
+                cos_ = sin_ * cotan;
+                tau = 1;
+                if (fabs(cos_) * RT_GIANT > 1) tau = 1 / cos_;
+            } else {
+                const double tan_ = v[j] / v[n - 1];
+                cos_ = p5 / sqrt(p25 + p25 * (tan_ * tan_));
+                sin_ = cos_ * tan_;
+                tau = sin_;
+            }
+            v[n - 1] = sin_ * v[j] + cos_ * v[n - 1];
+            v[j] = tau;
+            int l = jj;
+            for (int i = j; i < n; ++i) {
+                const double temp = cos_ * s[l] - sin_ * w[i];
+                w[i] = sin_ * s[l] + cos_ * w[i];
+                s[l] = temp;
+                ++l;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) w[i] += v[n - 1] * u[i];
+    *sing = false;
+    for (int j = 0; j < n - 1; ++j) {
+        if (w[j] != 0) {
+            double cos_, sin_, tau;
+            if (fabs(s[jj]) < fabs(w[j])) {
+                const double cotan = s[jj] / w[j];
+                sin_ = p5 / sqrt(p25 + p25 * (cotan * cotan));
+                cos_ = sin_ * cotan;
+                tau = 1;
+                if (fabs(cos_) * RT_GIANT > 1) tau = 1 / cos_;
+            } else {
+                const double tan_ = w[j] / s[jj];
+                cos_ = p5 / sqrt(p25 + p25 * (tan_ * tan_));
+                sin_ = cos_ * tan_;
+                tau = sin_;
+            }
+            int l = jj;
+            for (int i = j; i < n; ++i) {
+                const double temp = cos_ * s[l] + sin_ * w[i];
+                w[i] = -sin_ * s[l] + cos_ * w[i];
+                s[l] = temp;
+                ++l;
+            }
+            w[j] = tau;
+        }
+        if (s[jj] == 0) *sing = true;
+        jj += n - j;
+    }
+    s[jj] = w[n - 1];
+    if (s[jj] == 0) *sing = true;
+}
+
+// a: m rows (row stride rs, column stride cs), n columns
+RT_HD inline void r1mpyq(int m, int n, double *a, int rs, int cs, const double *v, const double *w) {
+    for (int j = n - 2; j >= 0; --j) {
+        double cos_, sin_;
+        if (fabs(v[j]) > 1) {
+            cos_ = 1 / v[j];
+            sin_ = sqrt(1 - cos_ * cos_);
+        } else {
+            sin_ = v[j];
+            cos_ = sqrt(1 - sin_ * sin_);
+        }
+        for (int i = 0; i < m; ++i) {
+            const double temp = cos_ * a[i * rs + j * cs] - sin_ * a[i * rs + (n - 1) * cs];
+            a[i * rs + (n - 1) * cs] = sin_ * a[i * rs + j * cs] + cos_ * a[i * rs + (n - 1) * cs];
+            a[i * rs + j * cs] = temp;
+        }
+    }
+    for (int j = 0; j < n - 1; ++j) {
+        double cos_, sin_;
+        if (fabs(w[j]) > 1) {
+            cos_ = 1 / w[j];
+            sin_ = sqrt(1 - cos_ * cos_);
+        } else {
+            sin_ = w[j];
+            cos_ = sqrt(1 - sin_ * sin_);
+        }
+        for (int i = 0; i < m; ++i) {
+            const double temp = cos_ * a[i * rs + j * cs] + sin_ * a[i * rs + (n - 1) * cs];
+            a[i * rs + (n - 1) * cs] = -sin_ * a[i * rs + j * cs] + cos_ * a[i * rs + (n - 1) * cs];
+            a[i * rs + j * cs] = temp;
+        }
+    }
+}
+
+struct Result {
+    int info;  // 1 = converged (what SciPy reports as success)
+    int nfev;
+};
+
+// hybrd (finite-difference Jacobian) or, with user_jac, hybrj (the system hands its own Jacobian; n = 1 here)
+RT_HD inline Result hybr(System &sys, double *x, bool user_jac) {
+    const int n = sys.n_unknowns();
+    const double xtol = 1.49012e-08, factor = 100.0;
+    const double p1 = 0.1, p5 = 0.5, p001 = 1e-3, p0001 = 1e-4;
+    const int maxfev = (user_jac ? 100 : 200) * (n + 1);
+    double fvec[RT_HYBR_MAX_N], diag[RT_HYBR_MAX_N], qtf[RT_HYBR_MAX_N], wa1[RT_HYBR_MAX_N], wa2[RT_HYBR_MAX_N],
+        wa3[RT_HYBR_MAX_N], wa4[RT_HYBR_MAX_N];
+    double fjac[RT_HYBR_MAX_N * RT_HYBR_MAX_N], r[(RT_HYBR_MAX_N * (RT_HYBR_MAX_N + 1)) / 2];
+    Result res{0, 0};
+    double jac1 = 0;
+    evaluate(sys, x, fvec, user_jac ? &jac1 : nullptr);
+    res.nfev = 1;
+    double fnorm = enorm(n, fvec);
+    int iter = 1, ncsuc = 0, ncfail = 0, nslow1 = 0, nslow2 = 0;
+    double delta = 0, xnorm = 0;
+    const double eps = sqrt(RT_EPSMCH);
+    while (true) {
+        bool jeval = true;
+        if (user_jac) {
+            evaluate(sys, x, wa1, &jac1);  // n = 1: the Jacobian is the one number
+            A_(fjac, 0, 0) = jac1;
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const double temp = x[j];
+                double h = eps * fabs(temp);
+                if (h == 0) h = eps;
+                x[j] = temp + h;
+                evaluate(sys, x, wa1, nullptr);
+                x[j] = temp;
+                for (int i = 0; i < n; ++i) A_(fjac, i, j) = (wa1[i] - fvec[i]) / h;
+            }
+            res.nfev += n;
+        }
+        qrfac(n, fjac, wa1, wa2, wa3);
+        if (iter == 1) {
+            for (int j = 0; j < n; ++j) {
+                diag[j] = wa2[j];
+                if (wa2[j] == 0) diag[j] = 1;
+            }
+            for (int j = 0; j < n; ++j) wa3[j] = diag[j] * x[j];
+            xnorm = enorm(n, wa3);
+            delta = factor * xnorm;
+            if (delta == 0) delta = factor;
+        }
+        for (int i = 0; i < n; ++i) qtf[i] = fvec[i];
+        for (int j = 0; j < n; ++j) {
+            if (A_(fjac, j, j) != 0) {
+                double sum = 0;
+                for (int i = j; i < n; ++i) sum += A_(fjac, i, j) * qtf[i];
+                const double temp = -sum / A_(fjac, j, j);
+                for (int i = j; i < n; ++i) qtf[i] += A_(fjac, i, j) * temp;
+            }
+        }
+        bool sing = false;
+        for (int j = 0; j < n; ++j) {
+            int l = j;
+            for (int i = 0; i < j; ++i) {
+                r[l] = A_(fjac, i, j);
+                l += n - i - 1;
+            }
+            r[l] = wa1[j];
+            if (wa1[j] == 0) sing = true;
+        }
+        qform(n, fjac, wa1);
+        for (int j = 0; j < n; ++j) diag[j] = fmax(diag[j], wa2[j]);
+        while (true) {
+            dogleg(n, r, diag, qtf, delta, wa1, wa2, wa3);
+            for (int j = 0; j < n; ++j) {
+                wa1[j] = -wa1[j];
+                wa2[j] = x[j] + wa1[j];
+                wa3[j] = diag[j] * wa1[j];
+            }
+            const double pnorm = enorm(n, wa3);
+            if (iter == 1) delta = fmin(delta, pnorm);
+            evaluate(sys, wa2, wa4, nullptr);
+            ++res.nfev;
+            const double fnorm1 = enorm(n, wa4);
+            double actred = -1;
+            if (fnorm1 < fnorm) {
+                const double q = fnorm1 / fnorm;
+                actred = 1 - q * q;
+            }
+            int l = 0;
+            for (int i = 0; i < n; ++i) {
+                double sum = 0;
+                for (int j = i; j < n; ++j) {
+                    sum += r[l] * wa1[j];
+                    ++l;
+                }
+                wa3[i] = qtf[i] + sum;
+            }
+            const double temp = enorm(n, wa3);
+            double prered = 0;
+            if (temp < fnorm) {
+                const double q = temp / fnorm;
+                prered = 1 - q * q;
+            }
+            double ratio = 0;
+            if (prered > 0) ratio = actred / prered;
+            if (ratio < p1) {
+                ncsuc = 0;
+                ++ncfail;
+                delta = p5 * delta;
+            } else {
+                ncfail = 0;
+                ++ncsuc;
+                if (ratio >= p5 || ncsuc > 1) delta = fmax(delta, pnorm / p5);
+                if (fabs(ratio - 1) <= p1) delta = pnorm / p5;
+            }
+            if (ratio >= p0001) {
+                for (int j = 0; j < n; ++j) {
+                    x[j] = wa2[j];
+                    wa2[j] = diag[j] * x[j];
+                    fvec[j] = wa4[j];
+                }
+                xnorm = enorm(n, wa2);
+                fnorm = fnorm1;
+                ++iter;
+            }
+            ++nslow1;
+            if (actred >= p001) nslow1 = 0;
+            if (jeval) ++nslow2;
+            if (actred >= p1) nslow2 = 0;
+            if (delta <= xtol * xnorm || fnorm == 0) res.info = 1;
+            if (res.info != 0) return res;
+            if (res.nfev >= maxfev) res.info = 2;
+            if (p1 * fmax(p1 * delta, pnorm) <= RT_EPSMCH * xnorm) res.info = 3;
+            if (nslow2 == 5) res.info = 4;
+            if (nslow1 == 10) res.info = 5;
+            if (res.info != 0) return res;
+            if (ncfail == 2) break;
+            for (int j = 0; j < n; ++j) {
+                double sum = 0;
+                for (int i = 0; i < n; ++i) sum += A_(fjac, i, j) * wa4[i];
+                wa2[j] = (sum - wa3[j]) / pnorm;
+                wa1[j] = diag[j] * ((diag[j] * wa1[j]) / pnorm);
+                if (ratio >= p0001) qtf[j] = sum;
+            }
+            r1updt(n, r, wa1, wa2, wa3, &sing);
+            r1mpyq(n, n, fjac, 1, RT_LD, wa2, wa3);
+            r1mpyq(1, n, qtf, 0, 1, wa2, wa3);
+            jeval = false;
+        }
+    }
+}
+
+// What the reference's solver call returns for one candidate: the solver's points (n_refl reflection points, then the
+// diffraction point) and whether SciPy would report success.
+RT_HD inline bool solve_like_reference(const double *origin, const double *destination, const double *planes, int n_refl,
+                                       const double *edge, double *out_points, int *nfev) {
+    System sys;
+    double x[RT_HYBR_MAX_N];
+    setup(sys, origin, destination, planes, n_refl, edge, x);
+    const Result res = hybr(sys, x, n_refl == 0);
+    if (nfev) *nfev = res.nfev;
+    for (int i = 0; i < n_refl; ++i)
+        for (int k = 0; k < 3; ++k) out_points[3 * i + k] = x[3 * i + k];
+    if (edge) {
+        const double xe[3] = {sys.Xe[0], sys.Xe[1], x[3 * n_refl]};
+        times_matrix_t(xe, sys.matrix, out_points + 3 * n_refl);
+    }
+    return res.info == 1;
+}
+
+#undef A_
+#undef RT_LD
+
+}  // namespace rt_hybr

@@ -1411,6 +1411,9 @@ __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ pa
 // solve host side
 // ---------------------------------------------------------------------------------------------------------------
 
+int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *tx, const double *d_rx, int32_t *d_out_rx,
+                     int32_t *d_out_group, int32_t *d_out_cand, double *d_out_pts, int64_t n, int64_t *n_kept);
+
 struct EventTimer {
     rt_scene *sc;
     std::vector<hipEvent_t> ev[4];
@@ -1855,7 +1858,15 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         scene->last_segments += by_rounds ? n_paths + (int64_t)h_counters[3] * std::max(0, max_nseg - 1) : n_segs;
         r0 = r1;
     }
-    const unsigned long long found = found_before;
+    unsigned long long found = found_before;
+    if (scene->reference_solver && found > 0 && (int64_t)found <= capacity) {
+        int64_t kept = 0;
+        if (rt_rejudge_paths(scene, cand, tx, d_rx, out.rx, out.group, out.cand, out.pts, (int64_t)found, &kept)) {
+            free_temps();
+            return -1;
+        }
+        found = (unsigned long long)kept;
+    }
     *n_found = (int64_t)found;
     if (!on_device) {
         const int64_t m = std::min<int64_t>((int64_t)found, capacity);

@@ -192,7 +192,7 @@ def solve_block_on_device(problem, order, begin, end, frequency=None):
 
     from .device_pipeline import DevicePipeline
 
-    scene = problem._device_scene()
+    scene = problem._solving_scene()
     cand = scene.enumerate(problem.visibility_matrix, problem.emitter_visibility, problem._edge_pairs,
                            problem._edge_array, order, with_diffraction=True)
     problem.place.add_tree_crowns()

@@ -16,7 +16,18 @@ from . import _lib
 from . import geometry as geom
 
 
+# Which candidates count as solved.  False (default): every candidate whose system has a root that passes the checks.
+# True: only those for which the reference's own solver, SciPy's hybr as it calls it (geometry.py:682, 744, 823), would
+# have reported that root — the reference loses a few valid paths to its solver, and with this switch on the solve
+# loses the same ones (every found path is re-judged on the GPU by a restatement of that solver).  Read by
+# ``RayTracingProblem.solve`` (and ``multithread_solve_place``) when they run; a problem's own ``reference_solver``
+# attribute, when set, takes precedence.
+REFERENCE_SOLVER = False
+
+
 class RayTracingProblem:
+    reference_solver = None
+
     def __init__(self, emitter, place, receivers=None, n_screens=6):
         assert 0 < n_screens <= 6
         self.emitter = emitter
@@ -54,6 +65,12 @@ class RayTracingProblem:
         if self._scene is None:
             self._scene = geom.scene_arrays_of(list(self.polygons)).device_scene()
         return self._scene
+
+    def _solving_scene(self):
+        """The device scene with the solver switch of this problem applied."""
+        scene = self._device_scene()
+        scene.set_reference_solver(REFERENCE_SOLVER if self.reference_solver is None else self.reference_solver)
+        return scene
 
     def precompute(self):
         """Visibility matrix, emitter visibility through the screens of a 0.2 m cube, sharp edges, lines of sight."""
@@ -131,7 +148,7 @@ class RayTracingProblem:
                 self.solved_receivers = receivers
             return
 
-        scene = self._device_scene()
+        scene = self._solving_scene()
         cand = scene.enumerate(self.visibility_matrix, self.emitter_visibility, self._edge_pairs, self._edge_array,
                                max_order, with_diffraction=True)
         rx = np.asarray([self.receivers[i] for i in rx_ids], dtype=float).reshape(-1, 3)

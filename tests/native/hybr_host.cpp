@@ -1,0 +1,9 @@
+// Host build of the library's restatement of the reference's solver (raytracing_amd/csrc/rt_hybrd.h), for the CPU test
+// that holds it against SciPy's hybr on the reference's own zero functions.  Test infrastructure: the product runs the
+// same header on the GPU.
+#include "../../raytracing_amd/csrc/rt_hybrd.h"
+
+extern "C" int rt_hybr_host_solve(const double *origin, const double *destination, const double *planes, int n_refl,
+                                  const double *edge, double *out_points, int *nfev) {
+    return rt_hybr::solve_like_reference(origin, destination, planes, n_refl, edge, out_points, nfev) ? 1 : 0;
+}
