@@ -192,8 +192,11 @@ def test_every_receiver_with_a_path_has_a_power_below_the_emitted(lln_map):
 
     total = np.bincount(m["res"]["rx"], weights=fields["power"][:, 0], minlength=len(m["rx"]))
     np.testing.assert_allclose(db[with_path], 10 * np.log10(total[with_path] / mat.P_IN), rtol=0, atol=1e-9)
-    ok = fields["status"] == 0
-    assert ok.mean() > 0.99 and (fields["power"][ok, 0] > 0).all()
+    # none of the reference's field assertions (electromagnetism.py:294, 342, 408-426, 470, 502) fires on any of the
+    # ~1.7e5 paths of this map: the reference would run through it without aborting
+    codes, counts = np.unique(fields["status"], return_counts=True)
+    assert codes.tolist() == [0], f"field status codes {dict(zip(codes.tolist(), counts.tolist()))}"
+    assert (fields["power"][:, 0] > 0).all()
 
 
 def test_config2_full_batch_against_the_exact_oracle_on_a_sample():
