@@ -374,6 +374,119 @@ __device__ inline double tree_factor(const SceneView &sc, d3 A, d3 B, double fre
     return factor;
 }
 
+// What tree_factor finds for a segment, kept apart from the carrier frequency: the lengths of the stretches inside
+// the groups of two crossed polygons of one building, in the order they are met, and whether a group of more than two
+// turned up (the reference's "Cannot handle concave geometries").
+#define TREE_MAX_GROUPS 4
+struct TreeHits {
+    double d[TREE_MAX_GROUPS];
+    int32_t n;        // stretches recorded
+    int32_t concave;  // 1 where the reference would raise
+};
+
+__device__ inline double tree_factor_of(const TreeHits &h, double freq) {
+    double factor = 1.0;
+    for (int q = 0; q < h.n; ++q) {
+        const double L_db = 0.39 * pow(freq / 1e6, 0.39) * pow(h.d[q], 0.25);
+        factor *= pow(10.0, -L_db / 10);
+    }
+    return factor;
+}
+
+// The paths of a batch by what the field kernel has to do for them: [0] lines of sight, [1] reflections only, [2] paths
+// ending with a diffraction.  One kernel per class works on its own list: full waves of like work, and the common
+// classes compile to small kernels (the all-in-one kernel needed 256 registers and scratch memory).  A block reserves
+// the room of its entries with one atomic per class.
+__global__ __launch_bounds__(256) void k_field_classes(PathArrays pa, int32_t *__restrict__ lists, unsigned long long *counts) {
+    __shared__ int s_n[3];
+    __shared__ unsigned long long s_base[3];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    int cls = -1, slot = 0;
+    if (i < pa.n) {
+        const int kind = pa.kind[i];
+        cls = (kind >> 8) ? 2 : ((kind & 255) ? 1 : 0);
+        slot = atomicAdd(&s_n[cls], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && s_n[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)s_n[threadIdx.x]);
+    __syncthreads();
+    if (cls >= 0) lists[(size_t)cls * pa.n + s_base[cls] + slot] = (int32_t)i;
+}
+
+// Lines of sight are only known to be clear of the polygons the emitter sees (ray_tracing.py:232-237), so the reference's
+// tree loss looks at every polygon of the scene for them (electromagnetism.py:669).  One wave per line of sight, lanes =
+// polygons, the crossed ones gathered in ascending order, then the grouping of geometry.py:886-895 by one lane.
+#define LOS_HIT_CAP 128
+__global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, d3 tx, const double *__restrict__ rx,
+                                                    const int32_t *__restrict__ los_list, const unsigned long long *los_count,
+                                                    TreeHits *__restrict__ out) {
+    __shared__ int32_t s_hits[4][LOS_HIT_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= (int64_t)*los_count) return;
+    const int64_t i = los_list[j];
+    const d3 A = pa.origin ? ld3(pa.origin + 3 * (size_t)i) : tx;
+    const d3 B = ld3(rx + 3 * (size_t)pa.rx[i]);
+    const d3 V = B - A;
+    const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
+    int n_hits = 0;  // wave-uniform
+    for (int base = 0; base < sc.n; base += 64) {
+        const int p = base + lane;
+        const bool hit = p < sc.n && occ_pretest(sc.poly_recs + p, sc, A, V, pad) && polygon_cuts_segment(sc, p, A, B);
+        const unsigned long long mk = __ballot(hit);
+        if (hit) {
+            const int at = n_hits + __popcll(mk & ((1ull << lane) - 1));
+            if (at < LOS_HIT_CAP) s_hits[wave][at] = p;
+        }
+        n_hits += __popcll(mk);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
+    TreeHits h;
+    h.n = 0;
+    h.concave = n_hits > LOS_HIT_CAP ? 1 : 0;  // (a segment through more than 128 polygons: not a line of sight of any scene)
+    int first = -1, second = -1, count = 0;
+    auto flush = [&]() {
+        if (count == 2) {
+            // geometry.py:89-106 for both polygons
+            const d3 dir = vv_normalize(B - A);
+            d3 pts[2];
+            const int idx[2] = {first, second};
+            for (int q = 0; q < 2; ++q) {
+                const d3 n = ld3(sc.planes + 4 * (size_t)idx[q]);
+                const d3 pp = ld3(sc.verts + 3 * ((size_t)sc.vert_off[idx[q]] + 1));
+                const d3 w = A - pp;
+                const double s = -dot(w, n) / dot(dir, n);
+                pts[q] = (w + s * dir) + pp;
+            }
+            const double d = norm3(pts[0] - pts[1]);
+            if (d > 0) {
+                if (h.n < TREE_MAX_GROUPS) h.d[h.n++] = d; else h.concave = 1;
+            }
+        } else if (count > 2) {
+            h.concave = 1;
+        }
+    };
+    const int m = n_hits < LOS_HIT_CAP ? n_hits : LOS_HIT_CAP;
+    for (int q = 0; q < m; ++q) {
+        const int p = s_hits[wave][q];
+        if (count == 0) {
+            first = p;
+            count = 1;
+        } else if (sc.building[first] == sc.building[p]) {
+            if (count == 1) second = p;
+            ++count;
+        } else {
+            flush();  // geometry.py:890-892: the group is closed and the polygon that closed it is dropped
+            count = 0;
+        }
+    }
+    flush();
+    out[j] = h;
+}
+
 struct FieldOut {
     double *field;    // [n_paths * n_freq * 6]
     double *power;    // [n_paths * n_freq]
@@ -383,13 +496,19 @@ struct FieldOut {
     double *power_sum;// [n_rx * n_freq]
 };
 
+// CLASS: 0 lines of sight, 1 reflections only, 2 paths ending with a diffraction (k_field_classes); a thread takes entry
+// blockIdx.x * blockDim.x + threadIdx.x of its class's list.
+template <int CLASS>
 __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, FreqTable ft, rt_antenna_params ap, d3 tx,
                                                  const double *__restrict__ rx,
-                                                 const unsigned long long *__restrict__ best_idx, FieldOut out) {
+                                                 const unsigned long long *__restrict__ best_idx,
+                                                 const int32_t *__restrict__ list, const unsigned long long *list_count,
+                                                 const TreeHits *__restrict__ los_trees, FieldOut out) {
     // one thread per (path, frequency): blockIdx.y is the frequency.  The frequency-independent set-up (antenna frames,
     // angles) is cheap beside the coefficients and is simply redone per frequency; what it writes, frequency 0 writes.
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pa.n) return;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (int64_t)*list_count) return;
+    const int64_t i = list[j];
     const int f = blockIdx.y;
     const int r = pa.rx[i];
     const int kind = pa.kind[i];
@@ -425,8 +544,8 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
         out.angles[4 * i + 3] = rx_az * deg;
     }
 
-    const int n_refl = kind & 255;
-    const bool has_edge = (kind >> 8) != 0;
+    const int n_refl = CLASS == 0 ? 0 : (kind & 255);
+    const bool has_edge = CLASS == 2;
     const int32_t *chain = pa.chain + (size_t)i * RT_MAX_ORDER;
 
     {
@@ -446,7 +565,12 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
             const double fac = tree_factor(sc, A, B, ft.freq[f], st, p_begin);
             E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
         };
-        if (kind == 0 && !pa.e_in) through_trees(P[0], P[1], 0);  // electromagnetism.py:669
+        if (CLASS == 0 && !pa.e_in) {  // electromagnetism.py:669: every polygon of the scene, found by k_los_trees
+            const TreeHits h = los_trees[j];
+            if (h.concave && st == ST_OK) st = ST_CONCAVE;
+            const double fac = tree_factor_of(h, ft.freq[f]);
+            E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
+        }
         for (int k = 0; k < n_refl; ++k) {
             through_trees(P[k], P[k + 1], late_begin);  // :338
             E = reflect_field(sc, E, P[k], P[k + 1], P[k + 2], chain[k], ft, f, st);
@@ -478,11 +602,90 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
         double *fo = out.field + ((size_t)i * ft.n_freq + f) * 6;
         fo[0] = E.x.re; fo[1] = E.x.im; fo[2] = E.y.re; fo[3] = E.y.im; fo[4] = E.z.re; fo[5] = E.z.im;
         out.power[(size_t)i * ft.n_freq + f] = power;
-        atomicAdd(&out.power_sum[(size_t)r * ft.n_freq + f], power);
         // the status of a path is that of the lowest frequency at which something went wrong (the order in which a
         // loop over the frequencies would have met it): keep the smallest (frequency, status) key
         if (st != ST_OK) atomicMin(&out.status[i], (f << 8) | st);
     }
+}
+
+// Per-receiver power: the powers of a receiver's paths added in the order of the reference's table (line of sight,
+// reflections by order and chain, diffractions by order, chain and edge; electromagnetism.py:776-778), whatever order
+// the paths arrive in: the same map gives the same dB to the last bit on every run and every split over GPUs.
+__global__ void k_rx_path_count(PathArrays pa, int32_t *__restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pa.n) atomicAdd(&counts[pa.rx[i]], 1);
+}
+__global__ __launch_bounds__(1024) void k_rx_offsets(const int32_t *__restrict__ counts, int64_t n_rx, int64_t *__restrict__ off) {
+    __shared__ long long part[1024];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_rx; base += 1024) {
+        const int64_t r = base + threadIdx.x;
+        const long long v = r < n_rx ? counts[r] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const long long add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (r < n_rx) off[r] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[n_rx] = carry;
+}
+__global__ void k_rx_path_fill(PathArrays pa, const int64_t *__restrict__ off, int32_t *__restrict__ cursor,
+                               int32_t *__restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pa.n) return;
+    const int r = pa.rx[i];
+    order[off[r] + atomicAdd(&cursor[r], 1)] = (int32_t)i;
+}
+// is path a before path b in the reference's row order?
+__device__ inline bool path_before(const PathArrays &pa, int a, int b) {
+    const int ka = pa.kind[a], kb = pa.kind[b];
+    if (ka != kb) return ka < kb;  // 0 line of sight, 1.. reflections, 256.. diffractions by reflections before them
+    const int n_refl = ka & 255;
+    for (int k = 0; k < n_refl; ++k) {
+        const int ca = pa.chain[(size_t)a * RT_MAX_ORDER + k], cb = pa.chain[(size_t)b * RT_MAX_ORDER + k];
+        if (ca != cb) return ca < cb;
+    }
+    if (ka >> 8) {
+        for (int k = 0; k < 2; ++k) {
+            const int ea = pa.edge_polys[2 * (size_t)a + k], eb = pa.edge_polys[2 * (size_t)b + k];
+            if (ea != eb) return ea < eb;
+        }
+    }
+    return a < b;
+}
+// place of every path among its receiver's paths in that order: one thread per path counts the paths before it (a
+// receiver has a handful to a few hundred), instead of one thread per receiver sorting its list
+__global__ void k_rx_path_rank(PathArrays pa, const int64_t *__restrict__ off, const int32_t *__restrict__ unordered,
+                               int32_t *__restrict__ ordered) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pa.n) return;
+    const int r = pa.rx[i];
+    const int64_t b = off[r], e = off[r + 1];
+    int rank = 0;
+    for (int64_t q = b; q < e; ++q) {
+        const int other = unordered[q];
+        if (other != (int)i && path_before(pa, other, (int)i)) ++rank;
+    }
+    ordered[b + rank] = (int32_t)i;
+}
+__global__ void k_rx_power_sum(const int64_t *__restrict__ off, const int32_t *__restrict__ ordered, int64_t n_rx, int n_freq,
+                               const double *__restrict__ power, double *__restrict__ power_sum) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rx * n_freq) return;
+    const int64_t r = t / n_freq;
+    const int f = (int)(t - r * n_freq);
+    double sum = 0.0;
+    for (int64_t q = off[r]; q < off[r + 1]; ++q) sum += power[(size_t)ordered[q] * n_freq + f];
+    power_sum[t] = sum;
 }
 
 #define STATUS_UNSET 0x7f7f7f7f /* what hipMemset(0x7f) leaves: larger than any (frequency, status) key */
@@ -759,21 +962,48 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
     fo.power_sum = (double *)dalloc(sizeof(double) * n_rx * nf);
     unsigned long long *best_len = (unsigned long long *)dalloc(sizeof(unsigned long long) * n_rx);
     unsigned long long *best_idx = (unsigned long long *)dalloc(sizeof(unsigned long long) * n_rx);
-    F_PTR(fo.power_sum); F_PTR(best_len); F_PTR(best_idx);
+    // per-receiver path lists (counts and cursors, offsets, the paths in receiver order), class lists, tree hits
+    int32_t *rx_counts = (int32_t *)dalloc(sizeof(int32_t) * 2 * n_rx);
+    int64_t *rx_off = (int64_t *)dalloc(sizeof(int64_t) * (n_rx + 1));
+    int32_t *rx_order = (int32_t *)dalloc(sizeof(int32_t) * 2 * np_);  // as filled, then in the reference's order
+    int32_t *cls_lists = (int32_t *)dalloc(sizeof(int32_t) * 3 * np_);
+    TreeHits *los_trees = (TreeHits *)dalloc(sizeof(TreeHits) * np_);
+    unsigned long long *cls_counts = scene->d_counters + 13;  // [13], [14], [15]
+    F_PTR(fo.power_sum); F_PTR(best_len); F_PTR(best_idx); F_PTR(rx_counts); F_PTR(rx_off); F_PTR(rx_order);
+    F_PTR(cls_lists); F_PTR(los_trees);
     F_HIP(hipMemsetAsync(fo.power_sum, 0, sizeof(double) * n_rx * nf, st));
     F_HIP(hipMemsetAsync(best_len, 0xff, sizeof(unsigned long long) * n_rx, st));
     F_HIP(hipMemsetAsync(best_idx, 0xff, sizeof(unsigned long long) * n_rx, st));
+    F_HIP(hipMemsetAsync(rx_counts, 0, sizeof(int32_t) * 2 * n_rx, st));
+    F_HIP(hipMemsetAsync(cls_counts, 0, sizeof(unsigned long long) * 3, st));
     const d3 TX = ld3(tx);
     if (n_paths > 0) {
         const unsigned grid = (unsigned)((n_paths + 255) / 256);
         hipLaunchKernelGGL(k_best_length, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len);
         hipLaunchKernelGGL(k_best_index, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len, best_idx);
         F_HIP(hipMemsetAsync(fo.status, 0x7f, sizeof(int32_t) * np_, st));
+        hipLaunchKernelGGL(k_field_classes, dim3(grid), dim3(256), 0, st, pa, cls_lists, cls_counts);
         if (ev[1]) F_HIP(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(k_fields, dim3((unsigned)((n_paths + 127) / 128), (unsigned)n_freq), dim3(128), 0, st, scene->view,
-                           pa, ft, *antenna, TX, d_rx, best_idx, fo);
+        // the class kernels read their list's length on the device: the grids are sized for the whole batch and the
+        // blocks past the end of a list leave at once
+        const dim3 fgrid((unsigned)((n_paths + 127) / 128), (unsigned)n_freq);
+        if (!pa.e_in)
+            hipLaunchKernelGGL(k_los_trees, dim3((unsigned)((n_paths + 3) / 4)), dim3(256), 0, st, scene->view, pa, TX, d_rx,
+                               cls_lists, cls_counts, los_trees);
+        hipLaunchKernelGGL(k_fields<0>, fgrid, dim3(128), 0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx, cls_lists,
+                           cls_counts, los_trees, fo);
+        hipLaunchKernelGGL(k_fields<1>, fgrid, dim3(128), 0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx,
+                           cls_lists + np_, cls_counts + 1, los_trees, fo);
+        hipLaunchKernelGGL(k_fields<2>, fgrid, dim3(128), 0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx,
+                           cls_lists + 2 * np_, cls_counts + 2, los_trees, fo);
         if (ev[2]) F_HIP(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k_status_final, dim3(grid), dim3(256), 0, st, fo.status, (int64_t)n_paths);
+        hipLaunchKernelGGL(k_rx_path_count, dim3(grid), dim3(256), 0, st, pa, rx_counts);
+        hipLaunchKernelGGL(k_rx_offsets, dim3(1), dim3(1024), 0, st, rx_counts, (int64_t)n_rx, rx_off);
+        hipLaunchKernelGGL(k_rx_path_fill, dim3(grid), dim3(256), 0, st, pa, rx_off, rx_counts + n_rx, rx_order);
+        hipLaunchKernelGGL(k_rx_path_rank, dim3(grid), dim3(256), 0, st, pa, rx_off, rx_order, rx_order + np_);
+        hipLaunchKernelGGL(k_rx_power_sum, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, rx_off, rx_order + np_,
+                           (int64_t)n_rx, n_freq, fo.power, fo.power_sum);
     }
     hipLaunchKernelGGL(k_power_db, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, fo.power_sum,
                        (int64_t)(n_rx * nf), antenna->p_in, d_db);
