@@ -39,8 +39,8 @@ FREQUENCY_HZ = 12.5e9  # materials_properties.py:23 of the reference
 
 
 def committed_counters():
-    """Per-kernel counter figures of the committed rocprofv3 --pmc passes of this script (scripts/pmc_summary.py writes
-    the file): HBM bytes per launch with FETCH_SIZE doubled as gfx950 needs, and VALU issue utilisation."""
+    """Per-kernel counter figures of the committed rocprofv3 --pmc passes of this script (scripts/counters_json.py writes
+    the file): HBM bytes per launch with FETCH_SIZE doubled as gfx950 needs, and where the waves' cycles go."""
     try:
         with open(os.path.join(ROOT, "profiles", "r2_counters.json")) as f:
             return json.load(f)
@@ -151,7 +151,11 @@ def kernel_rooflines(n_rx, counts, max_order, n_poly, n_vert, ms, launches, segm
         c = counters.get(kernel.split("<")[0].split(" ")[0])
         if c:
             e["traffic"] = c.get("hbm_bytes_per_launch")
-            e["valu_issue_utilisation"] = c.get("valu_issue_utilisation")
+            e["traffic_note"] = "HBM bytes per launch from the committed counter passes: 2 x FETCH_SIZE + WRITE_SIZE"
+            for k in ("wave_cycles_issuing_valu_share", "wave_cycles_issuing_share", "wave_cycles_waiting_share",
+                      "wave_cycles_issue_stalled_share", "valu_instructions_per_wave", "fp64_share_of_valu_instructions"):
+                if k in c:
+                    e[k] = c[k]
             e["counter_source"] = c.get("source")
         if extra:
             e.update(extra)

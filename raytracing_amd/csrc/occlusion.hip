@@ -288,8 +288,11 @@ __device__ inline unsigned long long wave_sum(unsigned long long v) {
 }
 #endif
 
+#ifndef OBS_GRID_MIN_WAVES
+#define OBS_GRID_MIN_WAVES 4
+#endif
 template <bool MASKED>
-__global__ __launch_bounds__(256) void k_obstruct_grid(SceneView sc, ObstructItems items, int64_t n_cap,
+__global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(SceneView sc, ObstructItems items, int64_t n_cap,
                                                         const unsigned long long *__restrict__ n_dev,
                                                         const uint8_t *__restrict__ mask, uint8_t *out, int max_trips,
                                                         unsigned long long *late_count, int32_t *late_items) {

@@ -949,26 +949,71 @@ __device__ inline bool order_less(const PolyMeta *meta_f, int a, int b) {
     return painted_before(meta_f[a], a, meta_f[b], b);
 }
 
-// one workgroup per face: candidates (valid rings in front of the face) sorted by the painter's key
-__global__ __launch_bounds__(256) void k_vis_sort(int n, const PolyMeta *__restrict__ meta, int32_t *__restrict__ order,
-                                                   int m_stride, int32_t *__restrict__ counts) {
+// one workgroup per face: candidates (valid rings in front of the face) sorted by the painter's key.  Up to
+// VIS_SORT_LDS candidates the keys are brought into LDS once and the bitonic network runs there (a compare used to read
+// two 64-byte records from global memory); a face with more candidates sorts through global memory as before.
+#define VIS_SORT_LDS 4096
+#define VIS_SORT_THREADS 1024
+__global__ __launch_bounds__(VIS_SORT_THREADS) void k_vis_sort(int n, const PolyMeta *__restrict__ meta,
+                                                               int32_t *__restrict__ order, int m_stride,
+                                                               int32_t *__restrict__ counts) {
     __shared__ int cnt;
+    __shared__ double s_k1[VIS_SORT_LDS], s_k2[VIS_SORT_LDS];
+    __shared__ int32_t s_id[VIS_SORT_LDS];
     const int f = blockIdx.x, tid = threadIdx.x;
     const PolyMeta *meta_f = meta + (size_t)f * n;
     int32_t *ord = order + (size_t)f * m_stride;
     if (tid == 0) cnt = 0;
     __syncthreads();
-    for (int b = tid; b < n; b += 256)
+    for (int b = tid; b < n; b += VIS_SORT_THREADS)
         if (meta_f[b].state == 2) ord[atomicAdd(&cnt, 1)] = b;
     __syncthreads();
     const int m = cnt;
     int m_pad = 1;
     while (m_pad < m) m_pad <<= 1;
-    for (int i = m + tid; i < m_pad; i += 256) ord[i] = -1;
+    if (m_pad <= VIS_SORT_LDS) {
+        // -1 (padding) sorts last: key1 = +infinity, and among equals the larger index loses
+        for (int i = tid; i < m_pad; i += VIS_SORT_THREADS) {
+            const int b = i < m ? ord[i] : -1;
+            s_id[i] = b;
+            s_k1[i] = b >= 0 ? meta_f[b].key1 : INFINITY;
+            s_k2[i] = b >= 0 ? meta_f[b].key2 : INFINITY;
+        }
+        __syncthreads();
+        auto less = [&](int i, int l) {  // entry i before entry l?
+            const int a = s_id[i], b = s_id[l];
+            if (a < 0) return false;
+            if (b < 0) return true;
+            if (s_k1[i] != s_k1[l]) return s_k1[i] < s_k1[l];
+            if (s_k2[i] != s_k2[l]) return s_k2[i] < s_k2[l];
+            return a < b;
+        };
+        for (int k = 2; k <= m_pad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < m_pad; i += VIS_SORT_THREADS) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const bool up = (i & k) == 0;
+                        if (up ? less(l, i) : less(i, l)) {
+                            const int ti = s_id[i];
+                            const double t1 = s_k1[i], t2 = s_k2[i];
+                            s_id[i] = s_id[l]; s_k1[i] = s_k1[l]; s_k2[i] = s_k2[l];
+                            s_id[l] = ti; s_k1[l] = t1; s_k2[l] = t2;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < m_pad; i += VIS_SORT_THREADS) ord[i] = s_id[i];
+        if (tid == 0) counts[f] = m;
+        return;
+    }
+    for (int i = m + tid; i < m_pad; i += VIS_SORT_THREADS) ord[i] = -1;
     __syncthreads();
     for (int k = 2; k <= m_pad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < m_pad; i += 256) {
+            for (int i = tid; i < m_pad; i += VIS_SORT_THREADS) {
                 const int l = i ^ j;
                 if (l > i) {
                     const int a = ord[i], b = ord[l];
@@ -1521,7 +1566,7 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
                            (const int32_t *)job.b_big.p, (int)big.size(), (double *)b_sph.p, (PolyMeta *)b_meta.p);
     if (job.ev[1]) RT_HIP(hipEventRecord(job.ev[1], st));
     if (!strict)
-        hipLaunchKernelGGL(k_vis_sort, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,
+        hipLaunchKernelGGL(k_vis_sort, dim3(n_faces), dim3(VIS_SORT_THREADS), 0, st, sc.n, (const PolyMeta *)b_meta.p,
                            (int32_t *)b_order.p, m_stride, (int32_t *)b_counts.p);
     const int32_t *face_queue = nullptr, *item_off = nullptr;
     const double *tile_bounds = nullptr;
