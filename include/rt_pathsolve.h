@@ -230,6 +230,14 @@ int rt_fields(rt_scene *scene, const double *tx, const double *rx, int64_t n_rx,
               int on_device);
 
 
+/* ---- text encoding of the result table's array columns (electromagnetism_utils.py:104-117 / :217-269: the CSV holds
+ * each small array as numpy.array2string(a, separator=",") without spaces).  values[n_rows*n_cols] real or
+ * [n_rows*n_cols*2] complex (re, im interleaved), n_cols <= 16; the rows' strings are written one after the other, each
+ * followed by '\n', into out[capacity] (64 bytes per real value always suffice); a row holding a non-finite value gets
+ * an empty string.  Returns the bytes written or -1.  Host code, no GPU involved. */
+int64_t rt_format_array_rows(const double *values, int64_t n_rows, int32_t n_cols, int32_t is_complex, char *out,
+                             int64_t capacity);
+
 /* ---- channel statistics of the result table (electromagnetism_fun/electromagnetism_plots.py:287-460) -----------------
  * Per receiver g, over its paths [group_off[g], group_off[g+1]) (rows of the table in their order, receivers without
  * a path have an empty range): compute_RMS_delay_spreads (:389-400), compute_RMS_angular_spreads (:403-431),

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "rt_fields_last_timing": (c_int, [c_void_p, c_void_p]),
     "rt_visibility_last_timing": (c_int, [c_void_p, c_void_p]),
     "rt_describe_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "rt_format_array_rows": (c_int64, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64]),
     "rt_channel_stats": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int32, c_double, c_void_p, c_int]),
     "rt_radiomap": (c_int, [c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_double, c_void_p,
@@ -522,6 +523,25 @@ def solve_reflections_and_diffraction(origin, destinations, planes, edge, device
                                                 _ptr(dests), len(dests), _ptr(planes) if k else None, k, _ptr(edge),
                                                 _ptr(out), _ptr(ok)), "rt_solve_reflections_diffraction")
     return out, ok.astype(bool)
+
+
+def format_array_rows(values):
+    """Strings of the rows of a 2-D real or complex array as the reference's CSV holds small arrays
+    (``numpy.array2string(row, separator=",")`` without spaces); None for a row with a non-finite value."""
+    a = np.asarray(values)
+    if a.ndim != 2 or not 1 <= a.shape[1] <= 16:
+        raise ValueError("format_array_rows: a 2-D array with 1 to 16 columns")
+    is_complex = a.dtype.kind == "c"
+    a = np.ascontiguousarray(a, dtype=np.complex128 if is_complex else np.float64)
+    if len(a) == 0:
+        return []
+    capacity = 64 * a.shape[0] * a.shape[1] * (2 if is_complex else 1) + 8 * a.shape[0]
+    buf = ctypes.create_string_buffer(capacity)
+    n = load().rt_format_array_rows(a.ctypes.data, a.shape[0], a.shape[1], int(is_complex), buf, capacity)
+    if n < 0:
+        raise RtError("rt_format_array_rows failed")
+    rows = buf.raw[:n].decode("ascii").split("\n")[:-1]
+    return [r if r else None for r in rows]
 
 
 def channel_stats(group_off, power, time, el_deg, az_deg, xyz, is_los, n_strongest=1, power_percent=0.99, device=None):

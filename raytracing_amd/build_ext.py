@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libraytracing_amd.so")
 SOURCES = ["scene.hip", "occlusion.hip", "solve.hip", "visibility.hip", "sharp_edges.hip", "fields.hip", "channel_stats.hip",
-           "radiomap.hip", "reference_solver.hip"]
+           "radiomap.hip", "reference_solver.hip", "table_format.hip"]
 HEADERS = ["rt_common.h", "rt_candidates.h", "rt_fresnel.h", "rt_hybrd.h", os.path.join("..", "..", "include", "rt_pathsolve.h")]
 # packed-fp32 instructions are switched off: the compiler forms them by itself from ordinary float code and some of
 # their forms have given wrong results on this hardware (the host pass warns that it does not know the feature)

@@ -116,13 +116,47 @@ def array_to_string(a):
     return np.array2string(a, separator=",", max_line_width=999).replace(" ", "")
 
 
+def _format_rows(block):
+    from . import _lib
+
+    return _lib.format_array_rows(block)
+
+
+def _is_missing(v):
+    return isinstance(v, float) and np.isnan(v)
+
+
 def save_df(df, save_name):
     """CSV with the reference's column encoding (arrays as bracketed, comma-separated strings without spaces)."""
     if not save_name.endswith(".csv"):
         save_name += ".csv"
     out = df.copy(deep=False).astype(object)
     possible = [t != "Impossible" for t in df["path_type"]]
-    out["field_strength"] = [array_to_string(v) for v in df["field_strength"]]
+    rows_with_path = [i for i, ok in enumerate(possible) if ok]
+
+    def array_column(values, fallback):
+        """The column's strings: the rows that hold a path through the library's formatter, all at once (the same
+        strings as ``array_to_string``, which the other rows and anything unusual still go through)."""
+        values = list(values)
+        out_col = [fallback(v) for v in values] if not rows_with_path else [None] * len(values)
+        if rows_with_path:
+            try:
+                block = np.array([values[i] for i in rows_with_path])
+                strings = _format_rows(block) if block.ndim == 2 and block.dtype.kind in "fc" else None
+            except (ValueError, TypeError):
+                strings = None
+            done = set()
+            if strings is not None:
+                for i, text in zip(rows_with_path, strings):
+                    if text is not None:
+                        out_col[i] = text
+                        done.add(i)
+            for i in range(len(values)):
+                if i not in done:
+                    out_col[i] = fallback(values[i])
+        return out_col
+
+    out["field_strength"] = array_column(df["field_strength"], array_to_string)
     seen = {}  # a receiver has many rows: its position is formatted once
 
     def receiver_string(v):
@@ -133,7 +167,7 @@ def save_df(df, save_name):
 
     out["receiver"] = [receiver_string(v) for v in df["receiver"]]
     for col in ("tx_angles", "rx_angles"):
-        out[col] = [array_to_string(v) if ok else v for v, ok in zip(df[col], possible)]
+        out[col] = array_column(df[col], lambda v: array_to_string(v) if v is not None and not _is_missing(v) else v)
     path = save_name if os.path.isabs(save_name) else os.path.join(results_dir(), save_name)
     out.to_csv(path, index=False)
     return path

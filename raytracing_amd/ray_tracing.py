@@ -51,6 +51,7 @@ class RayTracingProblem:
         self.sharp_edges = None
         self.path_solves_attempted = 0
         self._scene = None
+        self._plain = None  # JSON-ready mirror of reflections / diffractions, kept by store_paths for to_json
         self._edge_pairs = None
         self._edge_array = None
         n = self.receivers.shape[0]
@@ -173,6 +174,7 @@ class RayTracingProblem:
         receivers = np.asarray(self.receivers, dtype=float).reshape(-1, 3)
         edge_keys = [tuple(int(v) for v in k) for k in self._edge_pairs]
         items = [None] * len(rx)
+        plain_items = [None] * len(rx)  # the same items as nested lists, for to_json (one tolist() per group of paths)
         for g in np.unique(group):
             if g < 0:
                 continue
@@ -185,18 +187,35 @@ class RayTracingProblem:
             lines[:, 1:n_pts + 1] = points[sel, :n_pts]
             lines[:, n_pts + 1] = receivers[rx[sel]]
             chain_lists = chains[cand_index[sel]].tolist() if n_refl else [[] for _ in sel]
+            lines_plain = lines.tolist()
             if has_edge:
                 e = edge_ids[cand_index[sel]]
                 edge_points = self._edge_array[e]  # a copy per path, as the reference's containers hold
+                edges_plain = edge_points.tolist()
                 for k, i in enumerate(sel):
                     items[i] = (lines[k], chain_lists[k], edge_keys[e[k]], edge_points[k])
+                    plain_items[i] = [lines_plain[k], chain_lists[k], list(edge_keys[e[k]]), edges_plain[k]]
             else:
                 for k, i in enumerate(sel):
                     items[i] = (lines[k], chain_lists[k])
+                    plain_items[i] = [lines_plain[k], chain_lists[k]]
         orders = np.where(group >= cand.max_order, group - cand.max_order + 1, group + 1)
+        if self._plain is None:
+            # a mirror only makes sense when it sees every item go in: started on empty containers, or never
+            self._plain = {"reflections": {r: defaultdict(list) for r in self.reflections},
+                           "diffractions": {r: defaultdict(list) for r in self.diffractions},
+                           "count": 0} if self._count_items() == 0 else False
         for i in np.flatnonzero(group >= 0):  # in the given order
-            container = self.diffractions if group[i] >= cand.max_order else self.reflections
-            container[int(rx[i])][int(orders[i])].append(items[i])
+            which = "diffractions" if group[i] >= cand.max_order else "reflections"
+            getattr(self, which)[int(rx[i])][int(orders[i])].append(items[i])
+            if self._plain:
+                self._plain[which][int(rx[i])][int(orders[i])].append(plain_items[i])
+        if self._plain:
+            self._plain["count"] += int(np.count_nonzero(group >= 0))
+
+    def _count_items(self):
+        return sum(len(lst) for c in (self.reflections, self.diffractions) for by_order in c.values()
+                   for lst in by_order.values())
 
     # ------------------------------------------------------------------------------------------------
     def path_set(self):
@@ -258,6 +277,9 @@ class RayTracingProblem:
                 return float(obj)
             return obj
 
+        # the mirror store_paths keeps is used when it still describes the containers (nobody appended by hand, and the
+        # containers were empty when it was started); otherwise the containers are walked
+        mirror = self._plain if self._plain and self._plain["count"] == self._count_items() else None
         data = {
             "place": self.place.to_json(),
             "receivers": plain(self.receivers),
@@ -265,8 +287,8 @@ class RayTracingProblem:
             "emitter": plain(self.emitter),
             "n_screens": self.n_screens,
             "los": plain(self.los),
-            "reflections": plain(self.reflections),
-            "diffractions": plain(self.diffractions),
+            "reflections": mirror["reflections"] if mirror else plain(self.reflections),
+            "diffractions": mirror["diffractions"] if mirror else plain(self.diffractions),
         }
         filename = filename if ".json" in filename else f"{filename}.json"
         with open(filename, "w") as f:
