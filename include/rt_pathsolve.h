@@ -11,7 +11,11 @@
  *   - all arrays are dense, row-major, caller-owned; doubles are IEEE binary64, indices int32 unless stated;
  *   - `on_device` = 0: the array pointers of that call are host memory (the library copies);
  *     `on_device` = 1: they are device memory of the scene's GPU (nothing is copied, work is queued on the
- *     scene's stream and the call returns after the stream has been synchronised);
+ *     scene's stream and the call returns after the stream has been synchronised).  The scene's stream is a
+ *     non-blocking stream of its own: it is NOT ordered after the caller's streams, the null stream included.
+ *     Inputs that kernels or copies of the caller are still producing must be complete first: synchronise the
+ *     producing stream, or call rt_scene_wait_for_stream(scene, producing_stream) before the entry point.  Outputs
+ *     are complete, for every stream, when the call returns;
  *   - a handle may be used by one host thread at a time; handles of different GPUs are independent.
  */
 #ifndef RT_PATHSOLVE_H
@@ -41,6 +45,10 @@ rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *vert_off, c
                           const double *planes, const int32_t *material_id, const int32_t *building_id);
 void rt_scene_destroy(rt_scene *scene);
 int32_t rt_scene_polygon_count(const rt_scene *scene);
+/* Orders the scene's stream after everything queued so far on `stream` (a hipStream_t of the scene's GPU; NULL = the
+ * null stream): an event recorded there, which the scene's stream waits for on the device; the host does not wait.
+ * For on_device = 1 calls whose inputs the caller's own kernels produce.  No reference counterpart. */
+int rt_scene_wait_for_stream(rt_scene *scene, void *stream);
 
 /* ---- obstruction: polygons_obstruct_line_path (geometry.py:836-898) ----------------------------------------------
  * segs[n_seg*6] = (A, B) per segment; mask[N] or NULL restricts the test to polygons with mask != 0 (the LOS step

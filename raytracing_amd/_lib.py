@@ -48,6 +48,7 @@ _SIGNATURES = {
     "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
     "rt_debug_set_visibility_tiling": (c_int, [c_void_p, c_int32, c_int32]),
     "rt_scene_set_timing": (c_int, [c_void_p, c_int]),
+    "rt_scene_wait_for_stream": (c_int, [c_void_p, c_void_p]),
     "rt_scene_set_reference_solver": (c_int, [c_void_p, c_int]),
     "rt_debug_set_reflect_mode": (c_int, [c_void_p, c_int]),
     "rt_debug_set_path_queue_capacity": (c_int, [c_void_p, c_int64]),
@@ -291,6 +292,11 @@ class Scene:
     def set_reflect_mode(self, mode):
         """0: reflection kernel chosen by batch size (default); 1: receivers one by one; 2: receivers in spatial tiles."""
         _check(load().rt_debug_set_reflect_mode(self.handle, int(mode)), "rt_debug_set_reflect_mode")
+
+    def wait_for_stream(self, stream_handle):
+        """Orders the scene's stream after what is queued on the caller's stream (a hipStream_t as an integer, e.g.
+        ``torch.cuda.current_stream().cuda_stream``; 0 = the null stream), on the device: the host does not wait."""
+        _check(load().rt_scene_wait_for_stream(self.handle, c_void_p(int(stream_handle))), "rt_scene_wait_for_stream")
 
     def set_timing(self, on):
         """Per-kernel-family timing of the solves on (default) or off; ``last_timing`` reports zeros while off."""

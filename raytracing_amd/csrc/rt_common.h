@@ -95,6 +95,7 @@ struct SceneView {
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t caller_event = nullptr;  // rt_scene_wait_for_stream: marks the caller's stream, created on first use
     hipStream_t side_stream = nullptr;  // created on first use: work that runs beside the main stream's (emitter screens)
     SceneView view{};
     std::vector<void *> allocations;

@@ -208,6 +208,15 @@ extern "C" int rt_scene_set_timing(rt_scene *s, int on) {
     return 0;
 }
 
+extern "C" int rt_scene_wait_for_stream(rt_scene *s, void *stream) {
+    if (!s) RT_FAIL("rt_scene_wait_for_stream: null scene");
+    RT_HIP(hipSetDevice(s->device));
+    if (!s->caller_event) RT_HIP(hipEventCreateWithFlags(&s->caller_event, hipEventDisableTiming));
+    RT_HIP(hipEventRecord(s->caller_event, static_cast<hipStream_t>(stream)));
+    RT_HIP(hipStreamWaitEvent(s->stream, s->caller_event, 0));
+    return 0;
+}
+
 extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *vert_off, const double *verts,
                                      const double *planes, const int32_t *material_id, const int32_t *building_id) {
     if (n_poly <= 0 || !vert_off || !verts || !planes) {
@@ -319,6 +328,7 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
 extern "C" void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    if (s->caller_event) (void)hipEventDestroy(s->caller_event);
     if (s->side_stream) {
         (void)hipStreamSynchronize(s->side_stream);
         (void)hipStreamDestroy(s->side_stream);

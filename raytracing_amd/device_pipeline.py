@@ -95,8 +95,11 @@ class DevicePipeline:
         n_rx = int(d_rx.shape[0])
         if len(freqs) != self.n_freq:
             self._grow(self.capacity, len(freqs))
-        # the library works on a stream of its own: what torch has queued for d_rx must have happened
-        torch.cuda.current_stream(self.device).synchronize()
+        # the library works on a stream of its own: it waits, on the device, for what torch has queued for d_rx
+        handle = torch.cuda.current_stream(self.device).cuda_stream
+        self.scene.wait_for_stream(handle)
+        if self.field_scene is not self.scene:
+            self.field_scene.wait_for_stream(handle)
         while True:
             b = self.b
             found, attempted = self.scene.solve_paths_device(self.cand, self.tx, d_rx.data_ptr(), n_rx, b["rx"].data_ptr(),

@@ -328,3 +328,43 @@ def test_device_pointer_route_equals_host_array_route(places):
     np.testing.assert_allclose(d_db.cpu().numpy(), want["power_db"], rtol=0, atol=1e-9)
     cand.close()
     scene.close()
+
+
+@pytest.mark.gpu
+def test_pipeline_waits_on_the_device_for_the_callers_stream(places):
+    """Receivers that the caller's own kernels are still writing when the pipeline is called: the scene's stream is
+    ordered after the caller's stream on the device (rt_scene_wait_for_stream), so the result is the one of receivers
+    that were complete beforehand."""
+    import torch
+
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+    from raytracing_amd.device_pipeline import DevicePipeline
+
+    place = places("small")
+    tx, rx = small_tx_rx(16)
+    scene = _lib.Scene(geom.scene_arrays_of(place.get_polygons_list()))
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+    dev = torch.device("cuda", 0)
+    pipe = DevicePipeline(scene, cand, tx)
+    ready = torch.tensor(rx, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    want = pipe.run(ready, [3.6e9]).to_host()
+    assert len(want["rx"]) > 100
+    # the same receivers, produced on a side stream of torch behind a second of queued work
+    stream = torch.cuda.Stream(device=dev)
+    big = torch.randn((8192, 8192), device=dev)
+    late = torch.full_like(ready, 1.0e6)  # far outside the scene until the producer has run
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for _ in range(20):
+            big = torch.tanh(big @ big)
+        late.copy_(ready)
+        got = pipe.run(late, [3.6e9]).to_host()
+    torch.cuda.synchronize()
+    for name in ("rx", "group", "cand", "points", "power", "power_db"):
+        np.testing.assert_array_equal(got[name], want[name])
