@@ -109,6 +109,11 @@ int rt_debug_set_path_queue_capacity(rt_scene *scene, int64_t n_paths);
  * events around every launch; a small solve is bound by the latency of its few dependent launches and runs a little
  * faster without them.  rt_solve_last_timing reports zeros while it is off (no reference counterpart). */
 int rt_scene_set_timing(rt_scene *scene, int on);
+/* rt_enumerate stores the polygon chains of every candidate group except, when it would take more than this many bytes
+ * (default 256 MiB), the deepest reflection level: that level's chains are then formed inside the kernels from the level
+ * before it (same candidates, same order, same indices).  0 = never store the deepest level.  For tests of that route.
+ * No reference counterpart. */
+int rt_debug_set_stored_chain_limit(rt_scene *scene, int64_t bytes);
 /* The painter cuts a face that has at least min_candidates candidate polygons into azimuth sectors of about per_tile
  * candidates each, painted by different workgroups (a polygon is visible iff it shows in some sector); per_tile = 0
  * paints every face whole; min_candidates = -1 (the default) lets each call choose: sectors when it paints at most 256

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "rt_debug_set_visibility_tiling": (c_int, [c_void_p, c_int32, c_int32]),
     "rt_scene_set_timing": (c_int, [c_void_p, c_int]),
     "rt_scene_wait_for_stream": (c_int, [c_void_p, c_void_p]),
+    "rt_debug_set_stored_chain_limit": (c_int, [c_void_p, c_int64]),
     "rt_scene_set_reference_solver": (c_int, [c_void_p, c_int]),
     "rt_debug_set_reflect_mode": (c_int, [c_void_p, c_int]),
     "rt_debug_set_path_queue_capacity": (c_int, [c_void_p, c_int64]),
@@ -297,6 +298,11 @@ class Scene:
         """Orders the scene's stream after what is queued on the caller's stream (a hipStream_t as an integer, e.g.
         ``torch.cuda.current_stream().cuda_stream``; 0 = the null stream), on the device: the host does not wait."""
         _check(load().rt_scene_wait_for_stream(self.handle, c_void_p(int(stream_handle))), "rt_scene_wait_for_stream")
+
+    def set_stored_chain_limit(self, n_bytes):
+        """Largest deepest reflection level (bytes of its chains) that ``enumerate`` stores; above it the level's
+        chains are formed in the kernels from the level before (same candidates and indices)."""
+        _check(load().rt_debug_set_stored_chain_limit(self.handle, int(n_bytes)), "rt_debug_set_stored_chain_limit")
 
     def set_timing(self, on):
         """Per-kernel-family timing of the solves on (default) or off; ``last_timing`` reports zeros while off."""

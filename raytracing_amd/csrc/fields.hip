@@ -723,7 +723,7 @@ static void fill_materials(FreqTable &ft, int f, double freq) {
 // Per-path description arrays from the (group, candidate) pairs rt_solve_paths returns.
 __global__ void k_describe(const int32_t *__restrict__ group, const int32_t *__restrict__ cand, int64_t n, int n_groups,
                            const int *__restrict__ g_refl, const int *__restrict__ g_edge,
-                           const int32_t *const *__restrict__ g_chains, const int32_t *const *__restrict__ g_edge_ids,
+                           const ChainSource *__restrict__ g_chains, const int32_t *const *__restrict__ g_edge_ids,
                            const int32_t *__restrict__ edge_pairs, const double *__restrict__ edges,
                            int32_t *__restrict__ kind, int32_t *__restrict__ chain, int32_t *__restrict__ edge_polys,
                            double *__restrict__ edge_pts) {
@@ -739,7 +739,7 @@ __global__ void k_describe(const int32_t *__restrict__ group, const int32_t *__r
     }
     const int nr = g_refl[g];
     kind[i] = nr + (g_edge[g] ? 256 : 0);
-    for (int k = 0; k < nr; ++k) chain[i * RT_MAX_ORDER + k] = g_chains[g][(size_t)cand[i] * nr + k];
+    if (nr > 0) chain_load(g_chains[g], nr, cand[i], chain + i * RT_MAX_ORDER);
     if (g_edge[g]) {
         const int e = g_edge_ids[g][cand[i]];
         edge_polys[2 * i] = edge_pairs[2 * e];
@@ -761,11 +761,12 @@ extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group,
     hipStream_t st = scene->stream;
     const int ng = (int)cand->groups.size();
     std::vector<int> h_refl(ng ? ng : 1), h_edge(ng ? ng : 1);
-    std::vector<const int32_t *> h_chains(ng ? ng : 1), h_eids(ng ? ng : 1);
+    std::vector<ChainSource> h_chains(ng ? ng : 1);
+    std::vector<const int32_t *> h_eids(ng ? ng : 1);
     for (int g = 0; g < ng; ++g) {
         h_refl[g] = cand->groups[g].n_refl;
         h_edge[g] = cand->groups[g].has_edge;
-        h_chains[g] = cand->groups[g].chains;
+        h_chains[g] = cand->groups[g].source;
         h_eids[g] = cand->groups[g].edge_ids;
     }
     if (!on_device) {
@@ -780,12 +781,12 @@ extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group,
     int rc = -1;
     do {
         int *d_refl = (int *)dalloc(sizeof(int) * h_refl.size()), *d_edge = (int *)dalloc(sizeof(int) * h_edge.size());
-        const int32_t **d_chains = (const int32_t **)dalloc(sizeof(void *) * h_chains.size());
+        ChainSource *d_chains = (ChainSource *)dalloc(sizeof(ChainSource) * h_chains.size());
         const int32_t **d_eids = (const int32_t **)dalloc(sizeof(void *) * h_eids.size());
         if (!d_refl || !d_edge || !d_chains || !d_eids) break;
         if (hipMemcpyAsync(d_refl, h_refl.data(), sizeof(int) * h_refl.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
         if (hipMemcpyAsync(d_edge, h_edge.data(), sizeof(int) * h_edge.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
-        if (hipMemcpyAsync(d_chains, h_chains.data(), sizeof(void *) * h_chains.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (hipMemcpyAsync(d_chains, h_chains.data(), sizeof(ChainSource) * h_chains.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
         if (hipMemcpyAsync(d_eids, h_eids.data(), sizeof(void *) * h_eids.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
         const int32_t *d_group = path_group, *d_cand = path_cand;
         int32_t *d_kind = out_kind, *d_chain = out_chain, *d_ep = out_edge_polys;

@@ -15,7 +15,8 @@
 struct RejudgeGroups {
     int n_groups;
     int n_refl[REJ_MAX_GROUPS], has_edge[REJ_MAX_GROUPS];
-    const int32_t *chains[REJ_MAX_GROUPS], *edge_ids[REJ_MAX_GROUPS];
+    ChainSource chains[REJ_MAX_GROUPS];
+    const int32_t *edge_ids[REJ_MAX_GROUPS];
 };
 
 // every polygon against one segment, as the reference's check does (geometry.py:857-884)
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(64) void k_rejudge(SceneView sc, RejudgeGroups G, c
     const int64_t c = p_cand[i];
     int32_t poly[RT_MAX_ORDER];
     double planes[4 * RT_MAX_ORDER];
+    if (n_refl > 0) chain_load(G.chains[g], n_refl, c, poly);
     for (int k = 0; k < n_refl; ++k) {
-        poly[k] = G.chains[g][c * n_refl + k];
         for (int q = 0; q < 4; ++q) planes[4 * k + q] = sc.planes[4 * (size_t)poly[k] + q];
     }
     double edge[6];
@@ -131,7 +132,7 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
     for (int g = 0; g < G.n_groups; ++g) {
         G.n_refl[g] = cand->groups[g].n_refl;
         G.has_edge[g] = cand->groups[g].has_edge;
-        G.chains[g] = cand->groups[g].chains;
+        G.chains[g] = cand->groups[g].source;
         G.edge_ids[g] = cand->groups[g].edge_ids;
     }
     const size_t np = (size_t)n;

@@ -117,6 +117,9 @@ struct rt_scene {
     int64_t hint_paths = 0, hint_segments = 0, hint_clear = 0;
     int32_t *late_items = nullptr;  // items handed from the first to the second obstruction pass (grows on demand)
     size_t late_cap = 0;
+    // a reflection level whose chains would take more bytes than this is not stored: its chains are formed from the
+    // level before when a kernel asks for them
+    int64_t stored_chain_bytes_limit = 256ll << 20;
     int64_t queue_capacity_override = 0;  // > 0: first size of the path queue (tests of the grow-and-redo route)
     int occlusion_mode = 0;  // 0 = by scene size, 1 = every-polygon walk, 2 = grid walk
     bool reference_solver = false;  // re-judge every found path with the reference's own solver (reference_solver.hip)

@@ -205,6 +205,20 @@ __global__ void k_expand_edges(const int32_t *__restrict__ parents, int64_t n_pa
     }
 }
 
+// coarse[b] = parent of candidate b * CHAIN_COARSE of a level that is not stored (last p with off[p] <= c)
+__global__ void k_coarse_parents(const int64_t *__restrict__ off, int64_t n_parents, int64_t n_children,
+                                 int32_t *__restrict__ coarse) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = b * CHAIN_COARSE;
+    if (c >= n_children) return;
+    int64_t lo = 0, hi = n_parents;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= c) lo = mid; else hi = mid;
+    }
+    coarse[b] = (int32_t)lo;
+}
+
 __global__ void k_iota(int32_t *out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int32_t)i;
@@ -329,6 +343,7 @@ extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, cons
         g.chains = cand_alloc<int32_t>(c, (size_t)total);
         CAND_CHECK(g.chains);
         hipLaunchKernelGGL(k_scatter_indices, dim3(blocks_for(n, 256)), dim3(256), 0, st, flags, off, (int64_t)n, g.chains);
+        g.source.chains = g.chains;
     }
     // deeper reflection levels (ray_tracing.py:316-322)
     for (int k = 2; k <= max_order; ++k) {
@@ -350,8 +365,20 @@ extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, cons
             return nullptr;
         }
         g.count = total;
+        // The deepest level is the large one (lln: 1 129, 9.0e5, ~4.5e7 chains at orders 1, 2, 3): above the limit it is
+        // not stored.  Every other level is a parent of something (the next reflection level, a diffraction level) and
+        // small beside it.
+        if (k == max_order && k >= 2 && (int64_t)sizeof(int32_t) * total * k > scene->stored_chain_bytes_limit) {
+            const int64_t n_coarse = (total + CHAIN_COARSE - 1) / CHAIN_COARSE;
+            int32_t *coarse = cand_alloc<int32_t>(c, (size_t)n_coarse);
+            CAND_CHECK(coarse);
+            hipLaunchKernelGGL(k_coarse_parents, dim3(blocks_for(n_coarse, 256)), dim3(256), 0, st, off, par.count, total, coarse);
+            g.source = ChainSource{nullptr, par.chains, off, row_off, col, par.count, coarse};
+            continue;
+        }
         g.chains = cand_alloc<int32_t>(c, (size_t)total * k);
         CAND_CHECK(g.chains);
+        g.source.chains = g.chains;
         if (total)
             hipLaunchKernelGGL(k_expand_reflect, dim3(blocks_for(total, 256)), dim3(256), 0, st, par.chains, par.count,
                                k - 1, off, row_off, col, total, g.chains);
@@ -409,6 +436,7 @@ extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, cons
                 g.edge_ids = cand_alloc<int32_t>(c, (size_t)total);
                 CAND_CHECK(g.chains);
                 CAND_CHECK(g.edge_ids);
+                g.source.chains = g.chains;
                 if (total)
                     hipLaunchKernelGGL(k_expand_edges, dim3(blocks_for(par.count, 4)), dim3(256), 0, st, par.chains,
                                        par.count, m, off, d_vis, n, c->d_edge_pairs, n_edges, g.chains, g.edge_ids);
@@ -440,8 +468,22 @@ extern "C" int rt_candidates_group(const rt_candidates *c, int32_t group, int32_
     if (group < 0 || group >= (int)c->groups.size()) RT_FAIL("rt_candidates_group: group out of range");
     const CandGroup &g = c->groups[group];
     RT_HIP(hipSetDevice(c->scene->device));
-    if (chains && g.n_refl > 0 && g.count > 0)
-        RT_HIP(hipMemcpy(chains, g.chains, sizeof(int32_t) * g.count * g.n_refl, hipMemcpyDeviceToHost));
+    if (chains && g.n_refl > 0 && g.count > 0) {
+        if (g.chains) {
+            RT_HIP(hipMemcpy(chains, g.chains, sizeof(int32_t) * g.count * g.n_refl, hipMemcpyDeviceToHost));
+        } else {
+            // a level that is not stored: written out for this call only
+            int32_t *tmp = nullptr;
+            RT_HIP(hipMalloc((void **)&tmp, sizeof(int32_t) * (size_t)g.count * g.n_refl));
+            const ChainSource &s = g.source;
+            hipLaunchKernelGGL(k_expand_reflect, dim3(blocks_for(g.count, 256)), dim3(256), 0, c->scene->stream, s.parents,
+                               s.n_parents, g.n_refl - 1, s.off, s.row_off, s.col, g.count, tmp);
+            hipError_t e = hipStreamSynchronize(c->scene->stream);
+            if (e == hipSuccess) e = hipMemcpy(chains, tmp, sizeof(int32_t) * g.count * g.n_refl, hipMemcpyDeviceToHost);
+            (void)hipFree(tmp);
+            RT_HIP(e);
+        }
+    }
     if (edge_ids) {
         if (g.has_edge && g.count > 0)
             RT_HIP(hipMemcpy(edge_ids, g.edge_ids, sizeof(int32_t) * g.count, hipMemcpyDeviceToHost));
@@ -501,15 +543,14 @@ __device__ inline bool unfold_exact(const d3 *nrm, const double *g, const d3 *im
 // Exact solve and checks of one (candidate, receiver) pair of a K-reflection group: true when the path survives them;
 // X = its reflection points.
 template <int K>
-__device__ inline bool reflect_exact(const SceneView &sc, const int32_t *__restrict__ chains, int64_t c, d3 tx, d3 R,
-                                     d3 *X) {
+__device__ inline bool reflect_exact(const SceneView &sc, const int32_t *chain, d3 tx, d3 R, d3 *X) {
     int32_t poly[K];
     d3 nrm[K], img[K];
     double g[K];
     d3 prev = tx;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        poly[i] = chains[c * K + i];
+        poly[i] = chain[i];
         const double *pl = sc.planes + 4 * (size_t)poly[i];
         nrm[i] = ld3(pl);
         const double s = pl[3] + dot(prev, nrm[i]);
@@ -547,14 +588,13 @@ __device__ inline bool reflect_exact(const SceneView &sc, const int32_t *__restr
 // The reflection points of a pair that reflect_exact has passed: its image construction alone (same arithmetic, same
 // points), without the checks.  For the lanes that write a survivor out, which are not the lanes that solved it.
 template <int K>
-__device__ inline void reflect_points(const SceneView &sc, const int32_t *__restrict__ chains, int64_t c, d3 tx, d3 R,
-                                      d3 *X) {
+__device__ inline void reflect_points(const SceneView &sc, const int32_t *chain, d3 tx, d3 R, d3 *X) {
     d3 nrm[K], img[K];
     double g[K];
     d3 prev = tx;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        const double *pl = sc.planes + 4 * (size_t)chains[c * K + i];
+        const double *pl = sc.planes + 4 * (size_t)chain[i];
         nrm[i] = ld3(pl);
         const double s = pl[3] + dot(prev, nrm[i]);
         img[i] = prev - (2.0 * s) * nrm[i];
@@ -606,21 +646,22 @@ struct ReflectShared {
     int n_survivors[4];
     long long base[2];
     double rx[3 * REFLECT_MAX_RX_TILE];  // the receivers of the block's tile
+    int32_t chain[4][64][RT_MAX_ORDER];  // the polygons of each lane's candidate, for the lanes that solve its pairs
 };
 
 template <int K>
-__device__ __forceinline__ void reflect_write(const SceneView &sc, const int32_t *__restrict__ chains, int group, d3 tx,
+__device__ __forceinline__ void reflect_write(const SceneView &sc, const int32_t (*wave_chain)[RT_MAX_ORDER], int group, d3 tx,
                                               const double *__restrict__ rx, int64_t c_base, int64_t r_begin,
                                               const Queues &q, uint32_t e, int64_t ps, int64_t ss) {
     const int64_t rr = r_begin + (e & 0xffffu);
     const d3 R = ld3(rx + 3 * rr);
     d3 X[K];
-    reflect_points<K>(sc, chains, c_base + (e >> 16), tx, R, X);
+    reflect_points<K>(sc, wave_chain[e >> 16], tx, R, X);
     reflect_emit<K>(q, ps, ss, group, c_base + (e >> 16), rr, tx, R, X);
 }
 
 template <int K>
-__device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t *__restrict__ chains, int64_t count,
+__device__ __forceinline__ void reflect_block(const SceneView &sc, const ChainSource &source, int64_t count,
                                               int group, d3 tx, const double *__restrict__ rx, int64_t rx0, int64_t rx1,
                                               int rx_tile, const Queues &q, unsigned block_x, ReflectShared &sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -636,9 +677,15 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
     d3 prev = tx, nk = mk3(0, 0, 1);
     double gk = 0;
     int32_t last = 0;
+    int32_t mine[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) mine[i] = 0;
+    if (active) chain_load(source, K, c, mine);
+    const int32_t(*wave_chain)[RT_MAX_ORDER] = sh.chain[wave];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        last = active ? chains[c * K + i] : 0;
+        last = mine[i];
+        sh.chain[wave][lane][i] = last;
         const double *pl = sc.planes + 4 * (size_t)last;
         nk = ld3(pl);
         const double s = pl[3] + dot(prev, nk);
@@ -661,7 +708,7 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
         bool ok = false;
         if (has) {
             d3 X[K];
-            ok = reflect_exact<K>(sc, chains, c_base + (e >> 16), tx, ld3(rx + 3 * (r_begin + (e & 0xffffu))), X);
+            ok = reflect_exact<K>(sc, wave_chain[e >> 16], tx, ld3(rx + 3 * (r_begin + (e & 0xffffu))), X);
         }
         const unsigned long long m = __ballot(ok);
         if (m == 0) return;
@@ -671,7 +718,7 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
         if (sn >= 64) {
             sn -= 64;
             int64_t ps, ss;
-            if (reserve(q, K + 1, ps, ss)) reflect_write<K>(sc, chains, group, tx, rx, c_base, r_begin, q, ws[sn + lane], ps, ss);
+            if (reserve(q, K + 1, ps, ss)) reflect_write<K>(sc, wave_chain, group, tx, rx, c_base, r_begin, q, ws[sn + lane], ps, ss);
             __builtin_amdgcn_wave_barrier();
         }
     };
@@ -718,7 +765,7 @@ __device__ __forceinline__ void reflect_block(const SceneView &sc, const int32_t
     int before = 0;
     for (int w = 0; w < wave; ++w) before += sh.n_survivors[w];
     if (lane < sn)
-        reflect_write<K>(sc, chains, group, tx, rx, c_base, r_begin, q, ws[lane], sh.base[0] + before + lane,
+        reflect_write<K>(sc, wave_chain, group, tx, rx, c_base, r_begin, q, ws[lane], sh.base[0] + before + lane,
                          sh.base[1] + (int64_t)(before + lane) * (K + 1));
 }
 
@@ -750,12 +797,13 @@ struct ReflectTiledShared {
     uint32_t wave_queue[4][128];   // candidate lane << 26 | receiver within the chunk (sorted order)
     uint32_t survivors[4][128];    // same encoding
     double cand[4][64][19];        // per candidate lane: image, plane normal, g, frame axes and extent of the last polygon
+    int32_t chain[4][64][RT_MAX_ORDER];  // the polygons of each lane's candidate
     int n_survivors[4];
     long long base[2];
 };
 
 template <int K>
-__device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const int32_t *__restrict__ chains, int64_t count,
+__device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const ChainSource &source, int64_t count,
                                                     int group, d3 tx, const RxTiles &rt, int64_t r0, int64_t r1,
                                                     int tiles_per_block, const Queues &q, unsigned block_x,
                                                     ReflectTiledShared &sh) {
@@ -766,9 +814,15 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
     d3 prev = tx, nk = mk3(0, 0, 1);
     double gk = 0;
     int32_t last = 0;
+    int32_t mine[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) mine[i] = 0;
+    if (active) chain_load(source, K, c, mine);
+    const int32_t(*wave_chain)[RT_MAX_ORDER] = sh.chain[wave];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        last = active ? chains[c * K + i] : 0;
+        last = mine[i];
+        sh.chain[wave][lane][i] = last;
         const double *pl = sc.planes + 4 * (size_t)last;
         nk = ld3(pl);
         const double s = pl[3] + dot(prev, nk);
@@ -798,7 +852,7 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
         bool ok = false;
         if (has) {
             d3 X[K];
-            ok = reflect_exact<K>(sc, chains, c_base + (e >> 26), tx, ld3(rt.rxs + 3 * (r0 + (e & 0x3ffffffu))), X);
+            ok = reflect_exact<K>(sc, wave_chain[e >> 26], tx, ld3(rt.rxs + 3 * (r0 + (e & 0x3ffffffu))), X);
         }
         const unsigned long long m = __ballot(ok);
         if (m == 0) return;
@@ -813,7 +867,7 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
                 const int64_t rr = r0 + (w & 0x3ffffffu);
                 const d3 R = ld3(rt.rxs + 3 * rr);
                 d3 X[K];
-                reflect_points<K>(sc, chains, c_base + (w >> 26), tx, R, X);
+                reflect_points<K>(sc, wave_chain[w >> 26], tx, R, X);
                 reflect_emit<K>(q, ps, ss, group, c_base + (w >> 26), rt.perm[rr], tx, R, X);
             }
             __builtin_amdgcn_wave_barrier();
@@ -941,7 +995,7 @@ __device__ __forceinline__ void reflect_block_tiled(const SceneView &sc, const i
         const int64_t rr = r0 + (w & 0x3ffffffu);
         const d3 R = ld3(rt.rxs + 3 * rr);
         d3 X[K];
-        reflect_points<K>(sc, chains, c_base + (w >> 26), tx, R, X);
+        reflect_points<K>(sc, wave_chain[w >> 26], tx, R, X);
         reflect_emit<K>(q, sh.base[0] + before + lane, sh.base[1] + (int64_t)(before + lane) * (K + 1), group,
                         c_base + (w >> 26), rt.perm[rr], tx, R, X);
     }
@@ -969,7 +1023,7 @@ __device__ __forceinline__ void los_emit_one(d3 tx, const double *__restrict__ r
 // All reflection orders of a solve in ONE launch (a small step is bound by the number of dependent launches): the
 // blocks [first_block[k-1], first_block[k]) of grid.x work on the k-reflection group.
 struct ReflectGroups {
-    const int32_t *chains[RT_MAX_ORDER];
+    ChainSource source[RT_MAX_ORDER];
     int64_t count[RT_MAX_ORDER];
     unsigned first_block[RT_MAX_ORDER + 1];
 };
@@ -984,15 +1038,15 @@ __global__ __launch_bounds__(256) void k_reflect(SceneView sc, ReflectGroups g, 
         if ((int)threadIdx.x < rx_tile && r < rx1) los_emit_one(tx, rx, rx0, r - rx0, q);
     }
     if (b < g.first_block[1]) {
-        reflect_block<1>(sc, g.chains[0], g.count[0], 0, tx, rx, rx0, rx1, rx_tile, q, b, wave_queue);
+        reflect_block<1>(sc, g.source[0], g.count[0], 0, tx, rx, rx0, rx1, rx_tile, q, b, wave_queue);
     } else if (MO >= 2 && b < g.first_block[2]) {
-        reflect_block<(MO >= 2 ? 2 : 1)>(sc, g.chains[1], g.count[1], 1, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[1],
+        reflect_block<(MO >= 2 ? 2 : 1)>(sc, g.source[1], g.count[1], 1, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[1],
                                          wave_queue);
     } else if (MO >= 3 && b < g.first_block[3]) {
-        reflect_block<(MO >= 3 ? 3 : 1)>(sc, g.chains[2], g.count[2], 2, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[2],
+        reflect_block<(MO >= 3 ? 3 : 1)>(sc, g.source[2], g.count[2], 2, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[2],
                                          wave_queue);
     } else if (MO >= 4) {
-        reflect_block<(MO >= 4 ? 4 : 1)>(sc, g.chains[3], g.count[3], 3, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[3],
+        reflect_block<(MO >= 4 ? 4 : 1)>(sc, g.source[3], g.count[3], 3, tx, rx, rx0, rx1, rx_tile, q, b - g.first_block[3],
                                          wave_queue);
     }
 }
@@ -1003,15 +1057,15 @@ __global__ __launch_bounds__(256) void k_reflect_tiled(SceneView sc, ReflectGrou
     __shared__ ReflectTiledShared sh;
     const unsigned b = blockIdx.x;
     if (b < g.first_block[1]) {
-        reflect_block_tiled<1>(sc, g.chains[0], g.count[0], 0, tx, rt, r0, r1, tiles_per_block, q, b, sh);
+        reflect_block_tiled<1>(sc, g.source[0], g.count[0], 0, tx, rt, r0, r1, tiles_per_block, q, b, sh);
     } else if (MO >= 2 && b < g.first_block[2]) {
-        reflect_block_tiled<(MO >= 2 ? 2 : 1)>(sc, g.chains[1], g.count[1], 1, tx, rt, r0, r1, tiles_per_block, q,
+        reflect_block_tiled<(MO >= 2 ? 2 : 1)>(sc, g.source[1], g.count[1], 1, tx, rt, r0, r1, tiles_per_block, q,
                                                b - g.first_block[1], sh);
     } else if (MO >= 3 && b < g.first_block[3]) {
-        reflect_block_tiled<(MO >= 3 ? 3 : 1)>(sc, g.chains[2], g.count[2], 2, tx, rt, r0, r1, tiles_per_block, q,
+        reflect_block_tiled<(MO >= 3 ? 3 : 1)>(sc, g.source[2], g.count[2], 2, tx, rt, r0, r1, tiles_per_block, q,
                                                b - g.first_block[2], sh);
     } else if (MO >= 4) {
-        reflect_block_tiled<(MO >= 4 ? 4 : 1)>(sc, g.chains[3], g.count[3], 3, tx, rt, r0, r1, tiles_per_block, q,
+        reflect_block_tiled<(MO >= 4 ? 4 : 1)>(sc, g.source[3], g.count[3], 3, tx, rt, r0, r1, tiles_per_block, q,
                                                b - g.first_block[3], sh);
     }
 }
@@ -1461,7 +1515,7 @@ static bool launch_reflect(rt_scene *s, const rt_candidates *cand, d3 tx, const 
     for (int k = 1; k <= RT_MAX_ORDER; ++k) {
         g.first_block[k - 1] = blocks;
         if (k <= mo && cand->groups[k - 1].count > 0) {
-            g.chains[k - 1] = cand->groups[k - 1].chains;
+            g.source[k - 1] = cand->groups[k - 1].source;
             g.count[k - 1] = cand->groups[k - 1].count;
             blocks += blocks_for(g.count[k - 1], 256);
             top = k;
@@ -1488,7 +1542,7 @@ static bool launch_reflect_tiled(rt_scene *s, const rt_candidates *cand, d3 tx, 
     for (int k = 1; k <= RT_MAX_ORDER; ++k) {
         g.first_block[k - 1] = blocks;
         if (k <= mo && cand->groups[k - 1].count > 0) {
-            g.chains[k - 1] = cand->groups[k - 1].chains;
+            g.source[k - 1] = cand->groups[k - 1].source;
             g.count[k - 1] = cand->groups[k - 1].count;
             blocks += blocks_for(g.count[k - 1], 256);
             top = k;

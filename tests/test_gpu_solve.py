@@ -322,3 +322,65 @@ def test_tiled_reflection_kernel_finds_the_same_paths(places, name, order, n_sid
     assert as_set(again) == as_set(one_by_one)
     cand.close()
     scene.close()
+
+
+@pytest.mark.parametrize("name,order,n_side,diffraction,reference_solver",
+                         [("small", 3, 6, True, False), ("ny", 3, 12, False, False), ("place_levant", 2, 20, True, True),
+                          ("ny", 4, 5, False, False)])
+def test_deepest_level_formed_in_the_kernels_gives_the_stored_level(places, name, order, n_side, diffraction,
+                                                                    reference_solver):
+    """The deepest reflection level is the one whose chain list grows out of hand (ray_tracing.py:316-322 visits it by
+    recursion and never holds it).  Not stored, its chains are formed inside the kernels from the level before: the
+    candidates, their indices and order, the paths found (points bit for bit), their description and the paths the
+    reference-compatible mode keeps must all be those of the stored level.  Both kernels (one by one, tiled)."""
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import scenarios
+
+    place = places(name)
+    polygons = place.get_polygons_list()
+    lo, hi = place.get_domain()
+    tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 25.0)
+    rx = scenarios.lattice_receivers(place, n_side, 1.5)
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    scene.set_reference_solver(reference_solver)
+
+    def run(limit):
+        scene.set_stored_chain_limit(limit)
+        cand = scene.enumerate(vis, ev, pairs, edges, order, with_diffraction=diffraction)
+        out = []
+        for mode in (1, 2):
+            scene.set_reflect_mode(mode)
+            res = scene.solve_paths(cand, tx, rx)
+            keep = res["group"] >= 0
+            o = np.lexsort((res["cand"], res["group"], res["rx"]))
+            desc = cand.describe(res["group"][keep], res["cand"][keep])
+            # only the first (reflections + diffraction) points of a path are defined
+            n_pts = np.array([sum(cand.group_kind(int(g))) if g >= 0 else 0 for g in res["group"]])
+            pts = np.where(np.arange(_lib.RT_MAX_ORDER)[None, :, None] < n_pts[:, None, None], res["points"], 0.0)
+            out.append((res["n_attempted"], res["rx"][o], res["group"][o], res["cand"][o], pts[o], desc))
+        scene.set_reflect_mode(0)
+        top = cand.group(order - 1)[0].copy()
+        counts = list(cand.counts)
+        cand.close()
+        return out, top, counts
+
+    stored, top_stored, counts_stored = run(1 << 40)
+    formed, top_formed, counts_formed = run(0)
+    scene.set_stored_chain_limit(256 << 20)
+    assert counts_formed == counts_stored
+    assert top_formed.shape == top_stored.shape and top_formed.shape[1] == order and len(top_formed) > 500
+    np.testing.assert_array_equal(top_formed, top_stored)
+    for a, b in zip(stored, formed):
+        assert a[0] == b[0]
+        for x, y in zip(a[1:5], b[1:5]):
+            np.testing.assert_array_equal(x, y)
+        for x, y in zip(a[5], b[5]):
+            np.testing.assert_array_equal(x, y)
+    n_deep = int(np.sum(stored[0][2] == order - 1))
+    assert n_deep > 0, "no path of the deepest level: the test shows nothing"
+    scene.close()
