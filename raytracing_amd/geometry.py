@@ -82,6 +82,104 @@ def projection_matrix_from_vector(vector):
 # --------------------------------------------------------------------------------------------------
 
 
+def polygon_line_intersection(polygon, points):
+    """Point where the line through ``points[0]`` and ``points[1]`` meets the plane of ``polygon``; None when the line
+    runs along the plane (reference geometry.py:89-106: same operations in the same order)."""
+    normal = polygon.get_normal()
+    anchor = polygon.points[1, :]
+    start = np.asarray(points[0], dtype=float)
+    direction = np.asarray(points[1], dtype=float) - start
+    direction = direction / np.linalg.norm(direction)
+    along = np.dot(direction, normal)
+    if abs(along) < 1e-6:
+        return None
+    offset = start - anchor
+    return offset + (-np.dot(offset, normal) / along) * direction + anchor
+
+
+def ring_contains(ring, x, y):
+    """Boundary-inclusive point-in-polygon of the points (x, y) (arrays) in the 2-D ring (n, 2): crossing number plus an
+    on-edge test, the predicate ``contains_point`` evaluates on the GPU (reference geometry.py:1778-1803 goes through
+    Shapely's ``intersects``).  Host code, for the scene builders."""
+    ring = np.asarray(ring, dtype=float)
+    x = np.atleast_1d(np.asarray(x, dtype=float))
+    y = np.atleast_1d(np.asarray(y, dtype=float))
+    ax, ay = np.roll(ring[:, 0], 1)[:, None], np.roll(ring[:, 1], 1)[:, None]
+    bx, by = ring[:, 0][:, None], ring[:, 1][:, None]
+    cross = (bx - ax) * (y[None, :] - ay) - (by - ay) * (x[None, :] - ax)
+    on_edge = (cross == 0.0) & (np.minimum(ax, bx) <= x) & (x <= np.maximum(ax, bx)) & (np.minimum(ay, by) <= y) & \
+              (y <= np.maximum(ay, by))
+    crosses = ((ay > y) != (by > y)) & ((cross > 0.0) == (by > ay))
+    return on_edge.any(axis=0) | (crosses.sum(axis=0) % 2 == 1)
+
+
+def ring_distance(ring, x, y):
+    """Distance from the points (x, y) to the boundary of the 2-D ring."""
+    ring = np.asarray(ring, dtype=float)
+    pts = np.column_stack([np.atleast_1d(x), np.atleast_1d(y)]).astype(float)
+    a, b = np.roll(ring, 1, axis=0), ring
+    ab = b - a
+    t = np.einsum("pek,ek->pe", pts[:, None, :] - a[None], ab) / np.maximum(np.einsum("ek,ek->e", ab, ab), 1e-300)
+    nearest = a[None] + np.clip(t, 0.0, 1.0)[..., None] * ab[None]
+    return np.sqrt(((pts[:, None, :] - nearest) ** 2).sum(axis=2)).min(axis=1)
+
+
+def _drop_collinear(ring, tol=1e-12):
+    """The ring without repeated vertices and without vertices on the line through their neighbours."""
+    ring = [np.asarray(p, dtype=float) for p in ring]
+    changed = True
+    while changed and len(ring) > 3:
+        changed = False
+        for i in range(len(ring)):
+            a, b, c = ring[i - 1], ring[i], ring[(i + 1) % len(ring)]
+            scale = max(np.abs(b - a).max(), np.abs(c - b).max(), 1e-300)
+            if abs((b[0] - a[0]) * (c[1] - b[1]) - (b[1] - a[1]) * (c[0] - b[0])) <= tol * scale * scale:
+                del ring[i]
+                changed = True
+                break
+    return np.array(ring)
+
+
+def _clip_half_plane(ring, p, q, keep_left):
+    """Part of the 2-D ring on one side of the line p -> q (Sutherland-Hodgman step): the left side when
+    ``keep_left``, else the right.  Points on the line belong to both."""
+    def side(v):
+        s = (q[0] - p[0]) * (v[1] - p[1]) - (q[1] - p[1]) * (v[0] - p[0])
+        return s if keep_left else -s
+
+    out = []
+    for i in range(len(ring)):
+        a, b = ring[i - 1], ring[i]
+        sa, sb = side(a), side(b)
+        if sa >= 0:
+            out.append(a)
+        if (sa > 0 and sb < 0) or (sa < 0 and sb > 0):
+            out.append(a + (b - a) * (sa / (sa - sb)))
+    return out
+
+
+def ring_minus_convex(ring, convex):
+    """Pieces of the 2-D ring that lie outside the convex ring ``convex``: for each of its sides, what is beyond that
+    side and within the sides before it.  The pieces do not overlap; pieces without area are dropped."""
+    convex = np.asarray(convex, dtype=float)
+    if not is_ccw(convex):
+        convex = convex[::-1]  # counter-clockwise: inside is to the left of every side
+    pieces = []
+    inside_so_far = [np.asarray(v, dtype=float) for v in ring]
+    for i in range(len(convex)):
+        p, q = convex[i - 1], convex[i]
+        if len(inside_so_far) < 3:
+            break
+        beyond = _clip_half_plane(inside_so_far, p, q, keep_left=False)
+        if len(beyond) >= 3:
+            piece = _drop_collinear(beyond)
+            if len(piece) >= 3 and abs(enclosed_area(piece)) > 1e-9:
+                pieces.append(piece)
+        inside_so_far = _clip_half_plane(inside_so_far, p, q, keep_left=True)
+    return pieces
+
+
+
 def _json_save(filename, data):
     with open(filename, "w") as f:
         json.dump(data, f)
@@ -256,6 +354,36 @@ class OrientedPolygon(OrientedGeometry):
         self.parametric = self.matrix = self.domain = self.centroid = None
         return self
 
+    def contains_points_host(self, points):
+        """``contains_point`` without the plane check for many points, evaluated on the host: the points are dropped
+        into the polygon's own frame and tested against its ring there, boundary included."""
+        matrix = self.get_matrix()
+        own = np.asarray(points, dtype=float).reshape(-1, 3) @ matrix
+        ring = self.points @ matrix
+        return ring_contains(ring[:, :2], own[:, 0], own[:, 1])
+
+    def points_contained(self, polygon):
+        """1.0 for every vertex of ``polygon`` that this polygon contains, seen along this polygon's normal
+        (reference :1805-1817)."""
+        return self.contains_points_host(polygon.points).astype(float)
+
+    def split(self, conflicting_polygons):
+        """For each of the polygons in ``conflicting_polygons``: the part of this polygon's footprint (x, y) that none
+        of the OTHERS covers, i.e. where polygons tile the plane, the part that lies on it (reference :1922-1940).  An
+        entry is an ``OrientedPolygon`` at z = 0, or a list of them when the part is in several pieces.  The others
+        must have convex footprints (the grounds of the study scenes are rectangles); the reference subtracts with
+        GEOS, whose pieces can start at another vertex."""
+        parts = []
+        for keep in conflicting_polygons:
+            pieces = [self.points[:, :2]]
+            for other in conflicting_polygons:
+                if other is keep:
+                    continue
+                pieces = [q for piece in pieces for q in ring_minus_convex(piece, other.points[:, :2])]
+            polygons = [OrientedPolygon(np.column_stack([q, np.zeros(len(q))])) for q in pieces]
+            parts.append(polygons[0] if len(polygons) == 1 else polygons)
+        return parts
+
     def to_json(self, filename=None):
         data = dict(id=self.id, **self.attributes, geotype="polygon", properties=self.properties,
                     building_id=self.building_id, part=self.part, points=self.points.tolist())
@@ -282,38 +410,38 @@ class OrientedPolygon(OrientedGeometry):
 
 
 class Square(OrientedPolygon):
-    """Axis-parallel square given by two opposite corners or by centre and side (reference :1942-2002)."""
+    """Rectangle with sides along x and y, given by two opposite corners or by centre and side (what the reference's
+    ``Square`` builds, geometry.py:1942-2002: same vertices in the same order)."""
 
     @staticmethod
     def by_2_corner_points(points):
-        P1, P2 = points
-        assert not np.array_equal(P1, P2), "points must be different (P1=P2)"
-        assert P1[1] != P2[1] and P1[0] != P2[0], "points must be diagonally opposite"
-        points = array_utils.sort_by_columns(np.asarray(points, dtype=float))
-        p = np.empty((4, 3), dtype=float)
-        p[0, :] = points[0, :]
-        p[1, :] = [points[0, 0], points[1, 1], points[0, 2]]
-        p[2, :] = points[1, :]
-        p[3, :] = [points[1, 0], points[0, 1], points[1, 2]]
-        return Square(p)
+        corners = np.asarray(points, dtype=float)
+        if corners.shape != (2, 3):
+            raise ValueError("a square takes two corner points of three coordinates")
+        assert not np.array_equal(corners[0], corners[1]), "points must be different (P1=P2)"
+        assert corners[0, 1] != corners[1, 1] and corners[0, 0] != corners[1, 0], "points must be diagonally opposite"
+        low, high = array_utils.sort_by_columns(corners)  # the corner with the smaller x first
+        # round the ring from the low corner: along y at the low corner's height, across to the high corner, back
+        # along y at the high corner's height
+        ring = np.array([low, (low[0], high[1], low[2]), high, (high[0], low[1], high[2])], dtype=float)
+        return Square(ring)
 
     @staticmethod
     def by_center_and_side(center, side, rotate=False):
         """``rotate=True`` turns the square about z by ``random.randint(0, 90)`` degrees, as the reference does
         (seed Python's ``random`` for a reproducible scene)."""
-        P1 = np.array([center[0] + side / 2, center[1] + side / 2, center[2]])
-        P2 = np.array([center[0] - side / 2, center[1] - side / 2, center[2]])
-        square = Square.by_2_corner_points(np.array([P1, P2]))
+        center = np.asarray(center, dtype=float).reshape(3)
+        reach = np.array([side / 2, side / 2, 0.0])
+        square = Square.by_2_corner_points(np.stack([center + reach, center - reach]))
         if rotate:
-            square.rotate(axis=np.array([0, 0, 1]), angle_deg=random.randint(0, 90))
+            square.rotate(axis=np.array([0.0, 0.0, 1.0]), angle_deg=random.randint(0, 90))
         return square
 
     @staticmethod
     def center(points):
-        (x1, y1, z1), (x2, y2, z2), (x3, y3, z3), (x4, y4, z4) = points[0], points[1], points[2], points[3]
-        mid1 = ((x1 + x2) / 2, (y1 + y2) / 2, (z1 + z2) / 2)
-        mid2 = ((x3 + x4) / 2, (y3 + y4) / 2, (z3 + z4) / 2)
-        return np.array([(mid1[0] + mid2[0]) / 2, (mid1[1] + mid2[1]) / 2, (mid1[2] + mid2[2]) / 2])
+        """Mean of the mid-points of the sides 0-1 and 2-3."""
+        ring = np.asarray(points, dtype=float)
+        return ((ring[0] + ring[1]) / 2 + (ring[2] + ring[3]) / 2) / 2
 
 
 class OrientedSurface(OrientedGeometry):
@@ -403,6 +531,31 @@ class OrientedPolyhedron(OrientedGeometry):
     def apply_on_points(self, func, *args, **kwargs):
         return OrientedPolyhedron(self.aux_surface.apply_on_points(func, *args, **kwargs).polygons)
 
+    def overlap(self, polyhedron):
+        """True when the top faces of the two polyhedra, seen from above, share area; touching along a side or at a
+        corner does not count (reference :2239-2248)."""
+        a, b = self.get_top_face().points[:, :2], polyhedron.get_top_face().points[:, :2]
+        if np.any(a.max(axis=0) <= b.min(axis=0)) or np.any(b.max(axis=0) <= a.min(axis=0)):
+            return False
+        # sides that cross properly
+        for i in range(len(a)):
+            p, q = a[i - 1], a[i]
+            for j in range(len(b)):
+                r, t = b[j - 1], b[j]
+                d1 = (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0])
+                d2 = (q[0] - p[0]) * (t[1] - p[1]) - (q[1] - p[1]) * (t[0] - p[0])
+                d3 = (t[0] - r[0]) * (p[1] - r[1]) - (t[1] - r[1]) * (p[0] - r[0])
+                d4 = (t[0] - r[0]) * (q[1] - r[1]) - (t[1] - r[1]) * (q[0] - r[0])
+                if d1 * d2 < 0 and d3 * d4 < 0:
+                    return True
+        # one inside the other (or sharing sides only in part): a point well inside one of them lies inside the other
+        def strictly_inside(ring, other):
+            pts = np.concatenate([ring, (ring + np.roll(ring, 1, axis=0)) / 2, ring.mean(axis=0, keepdims=True)])
+            inside = ring_contains(other, pts[:, 0], pts[:, 1]) & (ring_distance(other, pts[:, 0], pts[:, 1]) > 1e-9)
+            return bool(inside.any())
+
+        return strictly_inside(a, b) or strictly_inside(b, a)
+
     def apply_properties_to_polygons(self):
         assert self.building_type is not None, f"building type for polyhedron {self} is not set"
         for polygon in self.polygons:
@@ -488,6 +641,36 @@ class Building(OrientedPolyhedron):
         return Building.by_polygon_and_height(OrientedPolygon(points_3d), height, id, make_ccw=make_ccw,
                                               keep_ground=keep_ground, flat_roof=flat_roof)
 
+    @staticmethod
+    def building_on_slope(polygon, ground, height, id=None):
+        """Building whose footprint vertices are dropped vertically onto the plane of ``ground`` and whose flat roof
+        stands ``height`` above the highest of them (reference :2418-2435)."""
+        feet = polygon.points.copy()
+        for i, vertex in enumerate(polygon.points):
+            below = vertex.copy()
+            below[-1] = -1000
+            feet[i] = polygon_line_intersection(ground, np.array([below, vertex]))
+        return Building.by_polygon_and_height(OrientedPolygon(feet), height, id, make_ccw=True, keep_ground=True,
+                                              flat_roof=True)
+
+    @staticmethod
+    def rebuild_building(polygon, grounds, height):
+        """The building(s) of footprint ``polygon`` standing on ``grounds``: one building when a single ground holds
+        every vertex, otherwise one per part of the footprint on each ground that holds some (reference :2438-2471)."""
+        if not isinstance(grounds, list):
+            return [Building.building_on_slope(polygon, grounds, height)]
+        sharing = []
+        for ground in grounds:
+            held = ground.points_contained(polygon)
+            if held.all():
+                return [Building.building_on_slope(polygon, ground, height)]
+            if held.any():
+                sharing.append(ground)
+        buildings = []
+        for ground, part in zip(sharing, polygon.split(sharing)):
+            for piece in (part if isinstance(part, list) else [part]):
+                buildings.append(Building.building_on_slope(piece, ground, height))
+        return buildings
 
     @staticmethod
     def create_tree_trunk(trunk_spot, trunk_size, trunk_height, rotate, crown_size=None, crown_height=None):
@@ -575,12 +758,41 @@ class OrientedPlace(OrientedGeometry):
     def obstructs_line_path(self, points):
         return polygons_obstruct_line_path(self.get_polygons_list(), points)
 
-    def add_polyhedron(self, polyhedron, allow_overlap=True):
-        """Appends a polyhedron (reference :2742-2748; the overlap check of the reference goes through Shapely and is
-        not made here)."""
+    def overlap_place(self, polyhedron):
+        """True when the polyhedron's top face, seen from above, shares area with the top face of a polyhedron of the
+        place (reference :2731-2740)."""
+        return any(mine.overlap(polyhedron) for mine in self.polyhedra)
+
+    def add_polyhedron(self, polyhedron, allow_overlap=False):
+        """Appends a polyhedron; unless ``allow_overlap``, one that overlaps a polyhedron of the place is refused
+        (reference :2742-2748)."""
         assert isinstance(polyhedron, OrientedPolyhedron), "given polyhedron is not of type OrientedPolyhedron"
+        if not allow_overlap:
+            assert not self.overlap_place(polyhedron), "the polyhedron overlaps another one in the place"
         self.polyhedra.append(polyhedron)
         self._scene_arrays = None
+
+    def add_tree(self, tree_size, how_close_to_buildings=2):
+        """Plants a tree trunk (random height, randomly turned) at a random spot of the first ground polygon that is
+        at least ``how_close_to_buildings + tree_size / 2`` away from every polyhedron's top face, seen from above
+        (reference :2753-2787).  Draws spots with ``random.uniform`` over the ground's box until one fits, as the
+        reference does over the box of the free zone; the reference grows the footprints with mitred corners, here
+        the distance is the plain one, so a spot diagonal to a corner can be accepted that the reference refuses.
+        Returns the spot."""
+        margin = how_close_to_buildings + tree_size / 2
+        ground = self.surface.polygons[0].points[:, :2]
+        lo, hi = ground.min(axis=0).tolist(), ground.max(axis=0).tolist()
+        tops = [p.get_top_face().points[:, :2] for p in self.polyhedra]
+        for _ in range(100000):
+            x, y = random.uniform(lo[0], hi[0]), random.uniform(lo[1], hi[1])
+            if not ring_contains(ground, x, y)[0]:
+                continue
+            if any(ring_contains(t, x, y)[0] or ring_distance(t, x, y)[0] <= margin for t in tops):
+                continue
+            spot = np.array([x, y, 0.0])
+            self.add_polyhedron(Building.create_tree_trunk(spot, tree_size, trunk_height=None, rotate=True))
+            return spot
+        raise RuntimeError("no room left for a tree")
 
     def add_tree_crowns(self):
         """Puts a crown on every tree trunk that carries crown attributes (reference :2789-2802).  Called after the
