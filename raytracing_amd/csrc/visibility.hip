@@ -745,6 +745,52 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
 #define PHASE(i)
 #endif
     bool visible = false;
+    // ---- shortcut: B inside ONE other entry (all of B's vertices strictly inside it and no edge of it meets B's ring)
+    // is hidden.  This settles nine candidates in ten, so it comes first; the shortcut after it, which can only find B
+    // visible, never contradicts it (a point of B is then a point of that entry).  Lanes = entries for the box test;
+    // then, for each entry whose box holds B's box, lanes = the single tests: (vertex of B, one of five points around
+    // it) inside the entry, and (edge of the entry, edge of B) apart.
+    {
+        bool hidden = false;
+        for (int base = 1; base < n && !hidden; base += 64) {
+            const int li = base + lane;
+            bool holds = false;
+            if (li < n) {
+                double x0, x1, y0, y1;
+                ps.box(li, x0, x1, y0, y1);
+                holds = x0 < bx0 && x1 > bx1 && y0 < by0 && y1 > by1;
+            }
+            unsigned long long todo = __ballot(holds);
+            while (todo != 0 && !hidden) {
+                const int e = base + (__ffsll((long long)todo) - 1);  // wave-uniform
+                todo &= todo - 1;
+                const int cn = ps.nv(e);
+                const double *cx = ps.x(e), *cy = ps.y(e);
+                const int n_pips = nv * 5, n_meets = cn * nv;
+                bool ok = true;
+                for (int w0 = 0; w0 < n_pips + n_meets && ok; w0 += 64) {
+                    const int w = w0 + lane;
+                    bool mine = true;
+                    if (w < n_pips) {
+                        // the vertex and four points 2e-9 around it must all be inside: strictly inside with margin
+                        const int v = w / 5, k = w % 5;
+                        const double ox = k == 1 ? 8 * VIS_DELTA : (k == 2 ? -8 * VIS_DELTA : 0.0);
+                        const double oy = k == 3 ? 8 * VIS_DELTA : (k == 4 ? -8 * VIS_DELTA : 0.0);
+                        mine = pip_ring(cx, cy, cn, x[v] + ox, y[v] + oy);
+                    } else if (w < n_pips + n_meets) {
+                        const int m = w - n_pips;
+                        const int q = m / nv, v = m % nv;
+                        const int p = q == 0 ? cn - 1 : q - 1, u = v == 0 ? nv - 1 : v - 1;
+                        mine = !segments_meet(cx[p], cy[p], cx[q], cy[q], x[u], y[u], x[v], y[v]);
+                    }
+                    ok = __all(mine);
+                }
+                hidden = ok;
+            }
+        }
+        PHASE(0);
+        if (hidden) return false;
+    }
     // ---- shortcut: a few points inside B (vertex average and the points halfway to some vertices); one of them
     // outside every other entry proves B visible.  Lanes = entries.
     {
@@ -793,52 +839,8 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
         visible = __any(lane < n_samples && splits.pstate[lane] != 0);
         if (visible && lane == 0) VIS_STAT(4, 1);
     }
-    PHASE(0);
+    PHASE(1);
     if (visible) return true;
-    // ---- shortcut: B inside ONE other entry (all of B's vertices strictly inside it and no edge of it meets B's ring)
-    // is hidden.  Lanes = entries for the box test; then, for each entry whose box holds B's box, lanes = the single
-    // tests: (vertex of B, one of five points around it) inside the entry, and (edge of the entry, edge of B) apart.
-    {
-        bool hidden = false;
-        for (int base = 1; base < n && !hidden; base += 64) {
-            const int li = base + lane;
-            bool holds = false;
-            if (li < n) {
-                double x0, x1, y0, y1;
-                ps.box(li, x0, x1, y0, y1);
-                holds = x0 < bx0 && x1 > bx1 && y0 < by0 && y1 > by1;
-            }
-            unsigned long long todo = __ballot(holds);
-            while (todo != 0 && !hidden) {
-                const int e = base + (__ffsll((long long)todo) - 1);  // wave-uniform
-                todo &= todo - 1;
-                const int cn = ps.nv(e);
-                const double *cx = ps.x(e), *cy = ps.y(e);
-                const int n_pips = nv * 5, n_meets = cn * nv;
-                bool ok = true;
-                for (int w0 = 0; w0 < n_pips + n_meets && ok; w0 += 64) {
-                    const int w = w0 + lane;
-                    bool mine = true;
-                    if (w < n_pips) {
-                        // the vertex and four points 2e-9 around it must all be inside: strictly inside with margin
-                        const int v = w / 5, k = w % 5;
-                        const double ox = k == 1 ? 8 * VIS_DELTA : (k == 2 ? -8 * VIS_DELTA : 0.0);
-                        const double oy = k == 3 ? 8 * VIS_DELTA : (k == 4 ? -8 * VIS_DELTA : 0.0);
-                        mine = pip_ring(cx, cy, cn, x[v] + ox, y[v] + oy);
-                    } else if (w < n_pips + n_meets) {
-                        const int m = w - n_pips;
-                        const int q = m / nv, v = m % nv;
-                        const int p = q == 0 ? cn - 1 : q - 1, u = v == 0 ? nv - 1 : v - 1;
-                        mine = !segments_meet(cx[p], cy[p], cx[q], cy[q], x[u], y[u], x[v], y[v]);
-                    }
-                    ok = __all(mine);
-                }
-                hidden = ok;
-            }
-        }
-        PHASE(1);
-        if (hidden) return false;
-    }
     // ---- B's own edges, witness on B's inner side
     const double sgn_b = (double)ps.sgn(0);
     for (int v = wave; v < nv; v += n_waves) {
