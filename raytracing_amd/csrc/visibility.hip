@@ -718,12 +718,64 @@ __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay,
     return found;
 }
 
+// Is entry 0 of `ps` (B) inside ONE other entry: all of B's vertices strictly inside it and no edge of it meeting B's
+// ring?  Then B is hidden.  One wave; lanes = entries for the box test; then, for each entry whose box holds B's box,
+// lanes = the single tests: (vertex of B, one of five points around it) inside the entry, and (edge of the entry, edge
+// of B) apart.  Wave-uniform result.
+template <typename Set>
+__device__ inline bool inside_one_entry(const Set &ps) {
+    const int lane = threadIdx.x & 63;
+    const int n = ps.count();
+    const int nv = ps.nv(0);
+    const double *x = ps.x(0), *y = ps.y(0);
+    double bx0, bx1, by0, by1;
+    ps.box(0, bx0, bx1, by0, by1);
+    bool hidden = false;
+    for (int base = 1; base < n && !hidden; base += 64) {
+        const int li = base + lane;
+        bool holds = false;
+        if (li < n) {
+            double x0, x1, y0, y1;
+            ps.box(li, x0, x1, y0, y1);
+            holds = x0 < bx0 && x1 > bx1 && y0 < by0 && y1 > by1;
+        }
+        unsigned long long todo = __ballot(holds);
+        while (todo != 0 && !hidden) {
+            const int e = base + (__ffsll((long long)todo) - 1);  // wave-uniform
+            todo &= todo - 1;
+            const int cn = ps.nv(e);
+            const double *cx = ps.x(e), *cy = ps.y(e);
+            const int n_pips = nv * 5, n_meets = cn * nv;
+            bool ok = true;
+            for (int w0 = 0; w0 < n_pips + n_meets && ok; w0 += 64) {
+                const int w = w0 + lane;
+                bool mine = true;
+                if (w < n_pips) {
+                    // the vertex and four points 2e-9 around it must all be inside: strictly inside with margin
+                    const int v = w / 5, k = w % 5;
+                    const double ox = k == 1 ? 8 * VIS_DELTA : (k == 2 ? -8 * VIS_DELTA : 0.0);
+                    const double oy = k == 3 ? 8 * VIS_DELTA : (k == 4 ? -8 * VIS_DELTA : 0.0);
+                    mine = pip_ring(cx, cy, cn, x[v] + ox, y[v] + oy);
+                } else if (w < n_pips + n_meets) {
+                    const int m = w - n_pips;
+                    const int q = m / nv, v = m % nv;
+                    const int p = q == 0 ? cn - 1 : q - 1, u = v == 0 ? nv - 1 : v - 1;
+                    mine = !segments_meet(cx[p], cy[p], cx[q], cy[q], x[u], y[u], x[v], y[v]);
+                }
+                ok = __all(mine);
+            }
+            hidden = ok;
+        }
+    }
+    return hidden;
+}
+
 // Decide whether entry 0 of `ps` has a part outside the union of the other entries (wave-uniform result).
 // Called by all waves of the workgroup with identical arguments (the result is uniform over the workgroup): the cheap
 // shortcuts are computed by every wave, the edge examinations are dealt out to the waves and joined through `flag`.
 template <typename Set>
 __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *lds_count, int32_t *work, int *flag,
-                                  const TileSpan &tile) {
+                                  const TileSpan &tile, bool inside_one_done) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int n = ps.count();
     const int nv = ps.nv(0);
@@ -745,52 +797,11 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
 #define PHASE(i)
 #endif
     bool visible = false;
-    // ---- shortcut: B inside ONE other entry (all of B's vertices strictly inside it and no edge of it meets B's ring)
-    // is hidden.  This settles nine candidates in ten, so it comes first; the shortcut after it, which can only find B
-    // visible, never contradicts it (a point of B is then a point of that entry).  Lanes = entries for the box test;
-    // then, for each entry whose box holds B's box, lanes = the single tests: (vertex of B, one of five points around
-    // it) inside the entry, and (edge of the entry, edge of B) apart.
-    {
-        bool hidden = false;
-        for (int base = 1; base < n && !hidden; base += 64) {
-            const int li = base + lane;
-            bool holds = false;
-            if (li < n) {
-                double x0, x1, y0, y1;
-                ps.box(li, x0, x1, y0, y1);
-                holds = x0 < bx0 && x1 > bx1 && y0 < by0 && y1 > by1;
-            }
-            unsigned long long todo = __ballot(holds);
-            while (todo != 0 && !hidden) {
-                const int e = base + (__ffsll((long long)todo) - 1);  // wave-uniform
-                todo &= todo - 1;
-                const int cn = ps.nv(e);
-                const double *cx = ps.x(e), *cy = ps.y(e);
-                const int n_pips = nv * 5, n_meets = cn * nv;
-                bool ok = true;
-                for (int w0 = 0; w0 < n_pips + n_meets && ok; w0 += 64) {
-                    const int w = w0 + lane;
-                    bool mine = true;
-                    if (w < n_pips) {
-                        // the vertex and four points 2e-9 around it must all be inside: strictly inside with margin
-                        const int v = w / 5, k = w % 5;
-                        const double ox = k == 1 ? 8 * VIS_DELTA : (k == 2 ? -8 * VIS_DELTA : 0.0);
-                        const double oy = k == 3 ? 8 * VIS_DELTA : (k == 4 ? -8 * VIS_DELTA : 0.0);
-                        mine = pip_ring(cx, cy, cn, x[v] + ox, y[v] + oy);
-                    } else if (w < n_pips + n_meets) {
-                        const int m = w - n_pips;
-                        const int q = m / nv, v = m % nv;
-                        const int p = q == 0 ? cn - 1 : q - 1, u = v == 0 ? nv - 1 : v - 1;
-                        mine = !segments_meet(cx[p], cy[p], cx[q], cy[q], x[u], y[u], x[v], y[v]);
-                    }
-                    ok = __all(mine);
-                }
-                hidden = ok;
-            }
-        }
-        PHASE(0);
-        if (hidden) return false;
-    }
+    // ---- shortcut: B inside ONE other entry is hidden.  This settles nine candidates in ten, so it comes first (the
+    // caller may already have had one wave do it); the shortcut after it, which can only find B visible, never
+    // contradicts it (a point of B is then a point of that entry).
+    if (!inside_one_done && inside_one_entry(ps)) return false;
+    PHASE(0);
     // ---- shortcut: a few points inside B (vertex average and the points halfway to some vertices); one of them
     // outside every other entry proves B visible.  Lanes = entries.
     {
@@ -1181,7 +1192,7 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
     __shared__ double lds_splits[NW][SPLIT_LDS];
     __shared__ double lds_px[NW][PIECE_LDS], lds_py[NW][PIECE_LDS];
     __shared__ int lds_pstate[NW][PIECE_LDS];
-    __shared__ int s_face, s_nlist, s_fits, s_flag;
+    __shared__ int s_face, s_nlist, s_fits, s_flag, s_inside_one;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LocalStore *store = &stores.staged;
     Store *cs = &stores.canvas;
@@ -1340,6 +1351,15 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                     VIS_STAT(0, 1);
                     VIS_STAT(1, n_list);
                 }
+                // the shortcut that settles most candidates, by this wave alone while the others wait at the barrier
+                // (they used to repeat it, taking issue slots from the other workgroups of the compute unit)
+                __builtin_amdgcn_wave_barrier();
+                bool inside_one = false;
+                if (n_list > 0) {
+                    CanvasSet<Store> mine{cs, n_cs, n_list + 1};
+                    inside_one = inside_one_entry(mine);
+                }
+                if (lane == 0) s_inside_one = inside_one ? 1 : 0;
             } else if (wave == 0) {
                 if (lane == 0) s_resident = 0;
                 // ---- canvas polygons whose box meets B's box
@@ -1425,13 +1445,13 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
             if (!visible) {
                 if (res_now) {
                     CanvasSet<Store> cv{cs, s_ncs, n_list + 1};
-                    visible = polygon_uncovered(cv, splits, lds_count, work, &s_flag, span);
+                    visible = !s_inside_one && polygon_uncovered(cv, splits, lds_count, work, &s_flag, span, true);
                 } else if (s_fits) {
                     LocalSet ls{store, n_list + 1};
-                    visible = polygon_uncovered(ls, splits, lds_count, work, &s_flag, span);
+                    visible = polygon_uncovered(ls, splits, lds_count, work, &s_flag, span, false);
                 } else {
                     GlobalSet gs{&sc, sph_f, meta_f, list, B, n_list + 1};
-                    visible = polygon_uncovered(gs, splits, lds_count, work, &s_flag, span);
+                    visible = polygon_uncovered(gs, splits, lds_count, work, &s_flag, span, false);
                 }
             }
 #ifdef RT_VIS_STAMPS
