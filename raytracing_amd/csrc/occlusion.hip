@@ -27,6 +27,9 @@ struct ObstructItems {
     int round;
     int64_t n_masked;
     const int32_t *index;  // when given, work item k is item index[k] (second pass over the stragglers of a first)
+    const int32_t *cursor; // when given with index: where item index[k] had got to when it was handed over, 8 ints per
+                           // entry (next record, end of the cell's records, column, row, last row of the column,
+                           // columns not yet entered, lowest point over the column as a double): the walk goes on from there
     int64_t count_add;     // added to the item count read from the device
 };
 
@@ -295,7 +298,8 @@ template <bool MASKED>
 __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(SceneView sc, ObstructItems items, int64_t n_cap,
                                                         const unsigned long long *__restrict__ n_dev,
                                                         const uint8_t *__restrict__ mask, uint8_t *out, int max_trips,
-                                                        unsigned long long *late_count, int32_t *late_items) {
+                                                        unsigned long long *late_count, int32_t *late_items,
+                                                        int32_t *late_cursor) {
     __shared__ int64_t wave_items[4][64];
     __shared__ double wave_ab[4][64][6];  // the segment of each lane, for the exact tests
     __shared__ uint32_t wave_queue[4][128];
@@ -381,6 +385,12 @@ __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(Scene
             }
         };
         bool finished = !active;
+        if (active && items.index && items.cursor) {
+            // the walk of an item handed over by the first pass goes on where it stopped
+            const int32_t *c = items.cursor + 8 * s;
+            k = c[0]; k_end = c[1]; i = c[2]; j = c[3]; j_hi = c[4]; cols_left = c[5];
+            z_low = __hiloint2double(c[7], c[6]);
+        }
         if (active && k >= k_end) finished = !next_cell();
         int qn = 0;  // wave-uniform
         wave_hit[lane] = 0;
@@ -435,7 +445,15 @@ __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(Scene
                 const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
                 const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
                 base = ((unsigned long long)hi << 32) | lo;
-                if (late) late_items[base + __popcll(lm & ((1ull << lane) - 1))] = (int32_t)item;
+                if (late) {
+                    const unsigned long long at = base + __popcll(lm & ((1ull << lane) - 1));
+                    late_items[at] = (int32_t)item;
+                    if (late_cursor) {
+                        int32_t *c = late_cursor + 8 * at;
+                        c[0] = k; c[1] = k_end; c[2] = i; c[3] = j; c[4] = j_hi; c[5] = cols_left;
+                        c[6] = __double2loint(z_low); c[7] = __double2hiint(z_low);
+                    }
+                }
             }
         }
 #ifdef RT_OCC_STATS
@@ -497,7 +515,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     }
     if (!d_segs && !(d_paths && tx && d_rx)) RT_FAIL("rt_launch_obstruct: no segments");
     const ObstructItems items{d_segs, tx ? ld3(tx) : mk3(0, 0, 0), d_rx, d_paths, round, d_mask ? n_masked : 0, d_index,
-                              d_count ? count_add : 0};
+                              nullptr, d_count ? count_add : 0};
     // small launches on small scenes are latency-bound: there the every-polygon walk, split over grid.y, is quicker
     const bool walk_grid = scene->occlusion_mode == 2 ||
                            (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
@@ -512,21 +530,23 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
             if (d_mask)
                 hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, stream, scene->view, items,
                                    n_item, d_count, d_mask, d_out, 0x7fffffff, (unsigned long long *)nullptr,
-                                   (int32_t *)nullptr);
+                                   (int32_t *)nullptr, (int32_t *)nullptr);
             else
                 hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, stream, scene->view, items,
                                    n_item, d_count, d_mask, d_out, 0x7fffffff, (unsigned long long *)nullptr,
-                                   (int32_t *)nullptr);
+                                   (int32_t *)nullptr, (int32_t *)nullptr);
         } else {
             // two hand-over lists (a pass reads one and fills the other) and their counters
-            if (scene->late_cap < 2 * (size_t)n_item) {
+            // (behind the two lists: where each handed-over item had got to, 8 ints per item)
+            if (scene->late_cap < 10 * (size_t)n_item) {
                 RT_HIP(hipStreamSynchronize(stream));
                 if (scene->late_items) (void)hipFree(scene->late_items);
                 scene->late_items = nullptr;
                 scene->late_cap = 0;
-                RT_HIP(hipMalloc((void **)&scene->late_items, sizeof(int32_t) * 2 * (size_t)n_item));
-                scene->late_cap = 2 * (size_t)n_item;
+                RT_HIP(hipMalloc((void **)&scene->late_items, sizeof(int32_t) * 10 * (size_t)n_item));
+                scene->late_cap = 10 * (size_t)n_item;
             }
+            int32_t *cursors = scene->late_items + 2 * (size_t)n_item;
             unsigned long long *counts = scene->d_counters + 6;  // [6], [7]
             RT_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), stream));
             const int trip_limits[OBS_PASSES] = {OBS_FIRST_PASS_TRIPS, 0x7fffffff};
@@ -536,6 +556,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
                 unsigned g = (unsigned)grid;
                 if (pass > 0) {
                     it.index = scene->late_items + (size_t)((pass - 1) & 1) * n_item;
+                    it.cursor = pass == 1 ? cursors : nullptr;
                     it.count_add = 0;
                     n_in = counts + ((pass - 1) & 1);
                     g = (unsigned)std::max<int64_t>(1024, grid >> (2 * pass));
@@ -546,10 +567,10 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
                 if (pass >= 2 && !last) RT_HIP(hipMemsetAsync(count_out, 0, sizeof(unsigned long long), stream));
                 if (d_mask)
                     hipLaunchKernelGGL(k_obstruct_grid<true>, dim3(g), dim3(block), 0, stream, scene->view, it, n_item, n_in,
-                                       d_mask, d_out, trip_limits[pass], count_out, late_out);
+                                       d_mask, d_out, trip_limits[pass], count_out, late_out, pass == 0 ? cursors : (int32_t *)nullptr);
                 else
                     hipLaunchKernelGGL(k_obstruct_grid<false>, dim3(g), dim3(block), 0, stream, scene->view, it, n_item, n_in,
-                                       d_mask, d_out, trip_limits[pass], count_out, late_out);
+                                       d_mask, d_out, trip_limits[pass], count_out, late_out, pass == 0 ? cursors : (int32_t *)nullptr);
             }
         }
     } else if (d_mask)
@@ -770,27 +791,27 @@ extern "C" int rt_obstruct_segments_noalloc(rt_scene *scene, const double *d_seg
     if (grid > (1 << 20)) grid = 1 << 20;
     hipLaunchKernelGGL(k_noalloc_clear, dim3((unsigned)(grid < 2048 ? grid : 2048)), dim3(block), 0, st, d_out, n_seg,
                        &scr->late_count);
-    ObstructItems items{d_segs, mk3(0, 0, 0), nullptr, nullptr, 0, d_mask ? n_seg : 0, nullptr, 0};
+    ObstructItems items{d_segs, mk3(0, 0, 0), nullptr, nullptr, 0, d_mask ? n_seg : 0, nullptr, nullptr, 0};
     // first pass: every wave stops after OBS_FIRST_PASS_TRIPS records per lane and lists the segments still walking
     if (d_mask)
         hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, st, scene->view, items, n_seg,
                            (const unsigned long long *)nullptr, d_mask, d_out, OBS_FIRST_PASS_TRIPS, &scr->late_count,
-                           scr->late_items);
+                           scr->late_items, (int32_t *)nullptr);
     else
         hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, st, scene->view, items, n_seg,
                            (const unsigned long long *)nullptr, d_mask, d_out, OBS_FIRST_PASS_TRIPS, &scr->late_count,
-                           scr->late_items);
+                           scr->late_items, (int32_t *)nullptr);
     // second pass: the listed segments, walked to the end (the count is read on the device)
     items.index = scr->late_items;
     const unsigned g2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(grid, std::max<int64_t>(1024, grid >> 2)));
     if (d_mask)
         hipLaunchKernelGGL(k_obstruct_grid<true>, dim3(g2), dim3(block), 0, st, scene->view, items, n_seg,
                            (const unsigned long long *)&scr->late_count, d_mask, d_out, 0x7fffffff,
-                           (unsigned long long *)nullptr, (int32_t *)nullptr);
+                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     else
         hipLaunchKernelGGL(k_obstruct_grid<false>, dim3(g2), dim3(block), 0, st, scene->view, items, n_seg,
                            (const unsigned long long *)&scr->late_count, d_mask, d_out, 0x7fffffff,
-                           (unsigned long long *)nullptr, (int32_t *)nullptr);
+                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     RT_HIP(hipGetLastError());
     return 0;
 }
