@@ -86,7 +86,8 @@ __device__ inline bool segments_meet(double ax, double ay, double bx, double by,
 // Valid ring: finite, >= 3 distinct vertices after dropping repeats, non-zero area, edges meet only at shared ends.
 // (Index arithmetic wraps with a comparison, not a remainder: an integer division costs tens of instructions and this
 // runs for every (face, polygon) pair.)
-__device__ bool ring_is_valid(const double *x, const double *y, int n_in, int *sgn) {
+template <typename Coords>
+__device__ bool ring_is_valid(Coords x, Coords y, int n_in, int *sgn) {
     for (int i = 0; i < n_in; ++i)
         if (!isfinite(x[i]) || !isfinite(y[i])) return false;
     // a vertex equal to its predecessor is a repeat and is skipped (repeated points are accepted)
@@ -273,6 +274,72 @@ __global__ __launch_bounds__(256) void k_vis_prepare(SceneView sc, FaceBatch fb,
     m.xmin = lo0; m.xmax = hi0; m.ymin = lo1; m.ymax = hi1;
     int sgn = 1;
     m.state = ring_is_valid(xs, ys, nv, &sgn) ? 2 : 1;
+    m.sgn = sgn;
+    *out = m;
+}
+
+// Polygons of a few more vertices (up to VIS_MID_POLY: most roofs): one thread per (face, polygon) again, but with the
+// polygon the same in all lanes of a wave and the faces along the lanes, so that the loops over its vertices run the
+// same number of times in every lane and its vertices come through the scalar path.  The mapped ring of each lane sits
+// in LDS, vertex-major (coordinate v of lane l at [v][l]: no bank conflicts), for the ring check.  A wave per polygon
+// (k_vis_prepare_big) spends most of its time reducing over lanes and waiting, with a dozen lanes busy.
+#define VIS_MID_POLY 32
+struct LaneColumn {  // coordinate i of this lane in a [.][64] array
+    const double *p;
+    __device__ double operator[](int i) const { return p[64 * i]; }
+};
+template <int NVM>
+__global__ __launch_bounds__(64) void k_vis_prepare_mid(SceneView sc, FaceBatch fb, const int32_t *__restrict__ mid, int n_mid,
+                                                         double *__restrict__ sph, PolyMeta *__restrict__ meta) {
+    __shared__ double s_x[NVM][64], s_y[NVM][64];
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x * 64 + lane;
+    const int b = mid[blockIdx.y];  // the same polygon in every lane
+    if (f >= fb.n_faces) return;
+    const int v0 = sc.vert_off[b], nv = sc.vert_off[b + 1] - v0;
+    PolyMeta m;
+    m.state = 0;
+    m.sgn = 1;
+    m.key1 = m.key2 = 0;
+    m.xmin = m.xmax = m.ymin = m.ymax = 0;
+    PolyMeta *out = meta + (size_t)f * sc.n + b;
+    if (b == fb.a_self[f]) {
+        *out = m;
+        return;
+    }
+    d3 fx, fy, fz, c;
+    face_frame(fb, f, fx, fy, fz, c);
+    double zmax = -INFINITY;
+    for (int v = 0; v < nv; ++v) zmax = fmax(zmax, dot(ld3(sc.verts + 3 * (size_t)(v0 + v)) - c, fz));
+    if (!(zmax > TOL_DZ)) {
+        *out = m;
+        return;
+    }
+    double *az = sph + ((size_t)f * sc.vtot + v0) * 2;
+    double *pol = az + nv;
+    double rmin = INFINITY;
+    double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+    for (int v = 0; v < nv; ++v) {
+        const d3 q = ld3(sc.verts + 3 * (size_t)(v0 + v)) - c;
+        const double qx = dot(q, fx), qy = dot(q, fy), qz = dot(q, fz);
+        const double r = sqrt(qx * qx + qy * qy + qz * qz);
+        const double a = atan2(qy, qx);
+        const double p = acos(qz / r);
+        az[v] = a;
+        pol[v] = p;
+        s_x[v][lane] = a;
+        s_y[v][lane] = p;
+        rmin = fmin(rmin, r);
+        lo0 = fmin(lo0, a); hi0 = fmax(hi0, a);
+        lo1 = fmin(lo1, p); hi1 = fmax(hi1, p);
+        lo2 = fmin(lo2, r); hi2 = fmax(hi2, r);
+    }
+    const double cx = (lo0 + hi0) / 2, cy = (lo1 + hi1) / 2, cz = (lo2 + hi2) / 2;
+    m.key1 = rmin;
+    m.key2 = sqrt(cx * cx + cy * cy + cz * cz);
+    m.xmin = lo0; m.xmax = hi0; m.ymin = lo1; m.ymax = hi1;
+    int sgn = 1;
+    m.state = ring_is_valid(LaneColumn{&s_x[0][lane]}, LaneColumn{&s_y[0][lane]}, nv, &sgn) ? 2 : 1;
     m.sgn = sgn;
     *out = m;
 }
@@ -1567,10 +1634,20 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     RT_HIP(hipMemcpyAsync(b_normal.p, a_normal.data(), sizeof(double) * a_normal.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(b_self.p, a_self.data(), sizeof(int32_t) * a_self.size(), hipMemcpyHostToDevice, st));
     // the polygons that are prepared one per wave
+    // the polygons that are not prepared one per thread by k_vis_prepare, by size: up to 8, 16 and VIS_MID_POLY vertices
+    // (a thread per face with the polygon shared by the wave), then the rest (a wave per polygon)
     std::vector<int32_t> &big = job.h_big;  // lives until the stream has been waited for
     big.clear();
-    for (int i = 0; i < sc.n; ++i)
-        if (scene->h_vert_off[i + 1] - scene->h_vert_off[i] > VIS_SMALL_POLY) big.push_back(i);
+    size_t class_end[4] = {0, 0, 0, 0};
+    for (int cls = 0; cls < 4; ++cls) {
+        const int lo = cls == 0 ? VIS_SMALL_POLY : (cls == 1 ? 8 : (cls == 2 ? 16 : VIS_MID_POLY));
+        const int hi = cls == 0 ? 8 : (cls == 1 ? 16 : (cls == 2 ? VIS_MID_POLY : 0x7fffffff));
+        for (int i = 0; i < sc.n; ++i) {
+            const int nv = scene->h_vert_off[i + 1] - scene->h_vert_off[i];
+            if (nv > lo && nv <= hi) big.push_back(i);
+        }
+        class_end[cls] = big.size();
+    }
     if (job.b_big.alloc(sizeof(int32_t) * big.size())) RT_FAIL("visibility: out of device memory");
     if (!big.empty()) RT_HIP(hipMemcpyAsync(job.b_big.p, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemsetAsync(b_counter.p, 0, sizeof(unsigned long long), st));
@@ -1583,9 +1660,25 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     }
     hipLaunchKernelGGL(k_vis_prepare, dim3((sc.n + 255) / 256, n_faces), dim3(256), 0, st, sc, fb, (double *)b_sph.p,
                        (PolyMeta *)b_meta.p);
-    if (!big.empty())
-        hipLaunchKernelGGL(k_vis_prepare_big, dim3(((unsigned)big.size() + 3) / 4, n_faces), dim3(256), 0, st, sc, fb,
-                           (const int32_t *)job.b_big.p, (int)big.size(), (double *)b_sph.p, (PolyMeta *)b_meta.p);
+    {
+        const int32_t *lists = (const int32_t *)job.b_big.p;
+        const unsigned face_blocks = ((unsigned)n_faces + 63) / 64;
+        const int n8 = (int)class_end[0], n16 = (int)(class_end[1] - class_end[0]), n32 = (int)(class_end[2] - class_end[1]),
+                  n_rest = (int)(class_end[3] - class_end[2]);
+        // (a grid's second dimension ends at 65 535)
+        for (int at = 0; at < n8; at += 65535)
+            hipLaunchKernelGGL(k_vis_prepare_mid<8>, dim3(face_blocks, (unsigned)std::min(65535, n8 - at)), dim3(64), 0, st, sc,
+                               fb, lists + at, n8, (double *)b_sph.p, (PolyMeta *)b_meta.p);
+        for (int at = 0; at < n16; at += 65535)
+            hipLaunchKernelGGL(k_vis_prepare_mid<16>, dim3(face_blocks, (unsigned)std::min(65535, n16 - at)), dim3(64), 0, st,
+                               sc, fb, lists + class_end[0] + at, n16, (double *)b_sph.p, (PolyMeta *)b_meta.p);
+        for (int at = 0; at < n32; at += 65535)
+            hipLaunchKernelGGL(k_vis_prepare_mid<VIS_MID_POLY>, dim3(face_blocks, (unsigned)std::min(65535, n32 - at)), dim3(64),
+                               0, st, sc, fb, lists + class_end[1] + at, n32, (double *)b_sph.p, (PolyMeta *)b_meta.p);
+        if (n_rest)
+            hipLaunchKernelGGL(k_vis_prepare_big, dim3(((unsigned)n_rest + 3) / 4, n_faces), dim3(256), 0, st, sc, fb,
+                               lists + class_end[2], n_rest, (double *)b_sph.p, (PolyMeta *)b_meta.p);
+    }
     if (job.ev[1]) RT_HIP(hipEventRecord(job.ev[1], st));
     if (!strict)
         hipLaunchKernelGGL(k_vis_sort, dim3(n_faces), dim3(VIS_SORT_THREADS), 0, st, sc.n, (const PolyMeta *)b_meta.p,
