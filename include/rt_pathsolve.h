@@ -251,6 +251,19 @@ int rt_fields(rt_scene *scene, const double *tx, const double *rx, int64_t n_rx,
 int64_t rt_format_array_rows(const double *values, int64_t n_rows, int32_t n_cols, int32_t is_complex, char *out,
                              int64_t capacity);
 
+/* ---- JSON text of a container of solved paths (RayTracingProblem.to_json, ray_tracing.py:66-132, writes
+ * `reflections` and `diffractions` with json.dump: {receiver: {order: [[points, polygon chain(, edge key, edge
+ * points)], ...]}}).  The paths come grouped by receiver in the order of keys[n_keys] (every key gets an entry, empty
+ * when it has no path) and within a receiver by order; path i has n_points[i] points of three doubles at
+ * points[i*point_stride ..] (emitter and receiver included), n_chain[i] polygon indices at chain[i*chain_stride ..] and,
+ * when edge_key and edge_points are given, its edge's two polygons edge_key[2i ..] and end points edge_points[6i ..].
+ * Writes into out[capacity] the characters json.dumps gives for that dictionary; returns their number, -1 for bad
+ * arguments, -2 when the paths are not grouped as said, and -(needed + 16) when capacity is too small.  Host code. */
+int64_t rt_format_paths_json(int64_t n_paths, const int64_t *path_rx, const int32_t *path_order, const int32_t *n_points,
+                             const double *points, int32_t point_stride, const int32_t *n_chain, const int32_t *chain,
+                             int32_t chain_stride, const int32_t *edge_key, const double *edge_points, int64_t n_keys,
+                             const int64_t *keys, char *out, int64_t capacity);
+
 /* ---- channel statistics of the result table (electromagnetism_fun/electromagnetism_plots.py:287-460) -----------------
  * Per receiver g, over its paths [group_off[g], group_off[g+1]) (rows of the table in their order, receivers without
  * a path have an empty range): compute_RMS_delay_spreads (:389-400), compute_RMS_angular_spreads (:403-431),

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "rt_visibility_last_timing": (c_int, [c_void_p, c_void_p]),
     "rt_describe_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "rt_format_array_rows": (c_int64, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64]),
+    "rt_format_paths_json": (c_int64, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
+                                       c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64]),
     "rt_channel_stats": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int32, c_double, c_void_p, c_int]),
     "rt_radiomap": (c_int, [c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_double, c_void_p,
@@ -554,6 +556,36 @@ def format_array_rows(values):
         raise RtError("rt_format_array_rows failed")
     rows = buf.raw[:n].decode("ascii").split("\n")[:-1]
     return [r if r else None for r in rows]
+
+
+def format_paths_json(keys, path_rx, path_order, n_points, points, n_chain, chain, edge_key=None, edge_points=None):
+    """The characters ``json.dumps`` gives for a container of solved paths ``{receiver: {order: [item, ...]}}`` (see
+    rt_format_paths_json): paths grouped by receiver in the order of ``keys`` and by order within a receiver;
+    ``points`` [P, m, 3] with the first ``n_points[i]`` used, ``chain`` [P, k] with the first ``n_chain[i]`` used;
+    ``edge_key`` [P, 2] and ``edge_points`` [P, 2, 3] for diffraction items."""
+    keys = np.ascontiguousarray(keys, dtype=np.int64)
+    path_rx = np.ascontiguousarray(path_rx, dtype=np.int64)
+    n = len(path_rx)
+    path_order = np.ascontiguousarray(path_order, dtype=np.int32)
+    n_points = np.ascontiguousarray(n_points, dtype=np.int32)
+    n_chain = np.ascontiguousarray(n_chain, dtype=np.int32)
+    points = np.ascontiguousarray(points, dtype=np.float64).reshape(n, -1) if n else np.zeros((0, 3))
+    chain = np.ascontiguousarray(chain, dtype=np.int32).reshape(n, -1) if n else np.zeros((0, 1), dtype=np.int32)
+    if chain.shape[1] == 0:
+        chain = np.zeros((n, 1), dtype=np.int32)
+    ek = ep = None
+    if edge_key is not None:
+        ek = np.ascontiguousarray(edge_key, dtype=np.int32).reshape(n, 2)
+        ep = np.ascontiguousarray(edge_points, dtype=np.float64).reshape(n, 6)
+    capacity = 64 + 16 * len(keys) + int(n_points.sum()) * 84 + int(n_chain.sum()) * 13 + n * (140 if ek is not None else 32)
+    buf = np.empty(capacity, dtype=np.uint8)
+    got = load().rt_format_paths_json(n, path_rx.ctypes.data, path_order.ctypes.data, n_points.ctypes.data, points.ctypes.data,
+                                      points.shape[1], n_chain.ctypes.data, chain.ctypes.data, chain.shape[1],
+                                      ek.ctypes.data if ek is not None else None, ep.ctypes.data if ep is not None else None,
+                                      len(keys), keys.ctypes.data, buf.ctypes.data, capacity)
+    if got < 0:
+        raise RtError(f"rt_format_paths_json failed ({got})")
+    return buf[:got].tobytes().decode("ascii")
 
 
 def channel_stats(group_off, power, time, el_deg, az_deg, xyz, is_los, n_strongest=1, power_percent=0.99, device=None):

@@ -126,3 +126,144 @@ extern "C" int64_t rt_format_array_rows(const double *values, int64_t n_rows, in
     }
     return at;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// JSON text of the solved problem's path containers (ray_tracing.py:66-132 of the reference writes them with
+// json.dump: {receiver: {order: [[points, polygon chain(, edge key, edge points)], ...]}}).  A coverage map holds a
+// few hundred thousand paths; building the nested Python lists and encoding them took seconds.  This writes the same
+// characters json.dumps writes: ", " and ": " separators, integer keys as strings, floats as Python's repr (the
+// shortest digits that read back as the same number; exponent form when the decimal point would lie more than 16
+// places right or 4 places left of the first digit; ".0" after an integral value in positional form).
+// ---------------------------------------------------------------------------------------------------------------
+#include <charconv>
+
+namespace {
+
+// Python's float repr of a finite x, appended to out
+inline void append_py_float(std::string &out, double x) {
+    char sci[40];
+    auto r = std::to_chars(sci, sci + sizeof(sci) - 1, x, std::chars_format::scientific);  // [-]d[.ddd]e[+-]dd
+    *r.ptr = 0;
+    const char *p = sci, *end = r.ptr;
+    if (*p == '-') {
+        out.push_back('-');
+        ++p;
+    }
+    const char *e = p;
+    while (e < end && *e != 'e') ++e;
+    char digits[24];
+    int nd = 0;
+    for (const char *q = p; q < e; ++q)
+        if (*q != '.') digits[nd++] = *q;
+    const int exp10 = std::atoi(e + 1);
+    const int decpt = exp10 + 1;  // value = 0.d1d2... * 10^decpt
+    if (x == 0.0) {
+        out.append("0.0");
+        return;
+    }
+    if (decpt <= -4 || decpt > 16) {
+        out.push_back(digits[0]);
+        if (nd > 1) {
+            out.push_back('.');
+            out.append(digits + 1, (size_t)(nd - 1));
+        }
+        out.push_back('e');
+        const int ex = decpt - 1;
+        out.push_back(ex < 0 ? '-' : '+');
+        const int ax = ex < 0 ? -ex : ex;
+        if (ax < 10) out.push_back('0');
+        out.append(std::to_string(ax));
+        return;
+    }
+    if (decpt <= 0) {
+        out.append("0.");
+        out.append((size_t)(-decpt), '0');
+        out.append(digits, (size_t)nd);
+    } else if (decpt >= nd) {
+        out.append(digits, (size_t)nd);
+        out.append((size_t)(decpt - nd), '0');
+        out.append(".0");
+    } else {
+        out.append(digits, (size_t)decpt);
+        out.push_back('.');
+        out.append(digits + decpt, (size_t)(nd - decpt));
+    }
+}
+
+inline void append_point(std::string &out, const double *p) {
+    out.push_back('[');
+    append_py_float(out, p[0]);
+    out.append(", ");
+    append_py_float(out, p[1]);
+    out.append(", ");
+    append_py_float(out, p[2]);
+    out.push_back(']');
+}
+
+}  // namespace
+
+extern "C" int64_t rt_format_paths_json(int64_t n_paths, const int64_t *path_rx, const int32_t *path_order,
+                                        const int32_t *n_points, const double *points, int32_t point_stride,
+                                        const int32_t *n_chain, const int32_t *chain, int32_t chain_stride,
+                                        const int32_t *edge_key, const double *edge_points, int64_t n_keys,
+                                        const int64_t *keys, char *out, int64_t capacity) {
+    if (n_paths < 0 || n_keys < 0 || (n_paths > 0 && (!path_rx || !path_order || !n_points || !points || !n_chain)) ||
+        (n_keys > 0 && !keys) || !out)
+        return -1;
+    std::string s;
+    s.reserve((size_t)std::max<int64_t>(1024, n_paths * 320 + n_keys * 12));
+    s.push_back('{');
+    int64_t i = 0;
+    for (int64_t k = 0; k < n_keys; ++k) {
+        if (k) s.append(", ");
+        s.push_back('"');
+        s.append(std::to_string(keys[k]));
+        s.append("\": {");
+        // the paths of this receiver follow each other, grouped by order in the order they came in
+        bool first_order = true;
+        while (i < n_paths && path_rx[i] == keys[k]) {
+            const int order = path_order[i];
+            if (!first_order) s.append(", ");
+            first_order = false;
+            s.push_back('"');
+            s.append(std::to_string(order));
+            s.append("\": [");
+            bool first_item = true;
+            while (i < n_paths && path_rx[i] == keys[k] && path_order[i] == order) {
+                if (!first_item) s.append(", ");
+                first_item = false;
+                s.append("[[");
+                for (int q = 0; q < n_points[i]; ++q) {
+                    if (q) s.append(", ");
+                    append_point(s, points + (size_t)i * point_stride + 3 * q);
+                }
+                s.append("], [");
+                for (int q = 0; q < n_chain[i]; ++q) {
+                    if (q) s.append(", ");
+                    s.append(std::to_string(chain[(size_t)i * chain_stride + q]));
+                }
+                s.push_back(']');
+                if (edge_key && edge_points) {
+                    s.append(", [");
+                    s.append(std::to_string(edge_key[2 * i]));
+                    s.append(", ");
+                    s.append(std::to_string(edge_key[2 * i + 1]));
+                    s.append("], [");
+                    append_point(s, edge_points + 6 * (size_t)i);
+                    s.append(", ");
+                    append_point(s, edge_points + 6 * (size_t)i + 3);
+                    s.push_back(']');
+                }
+                s.push_back(']');
+                ++i;
+            }
+            s.push_back(']');
+        }
+        s.push_back('}');
+    }
+    s.push_back('}');
+    if (i != n_paths) return -2;  // paths not grouped by receiver in the order of the keys
+    if ((int64_t)s.size() > capacity) return -(int64_t)s.size() - 16;  // the room it needs, negated (less 16)
+    std::memcpy(out, s.data(), s.size());
+    return (int64_t)s.size();
+}

@@ -51,7 +51,9 @@ class RayTracingProblem:
         self.sharp_edges = None
         self.path_solves_attempted = 0
         self._scene = None
-        self._plain = None  # JSON-ready mirror of reflections / diffractions, kept by store_paths for to_json
+        # paths handed to store_paths that have not been put into the containers yet (that happens when somebody reads
+        # `reflections` or `diffractions`; to_json writes them from the arrays)
+        self._pending = []
         self._edge_pairs = None
         self._edge_array = None
         n = self.receivers.shape[0]
@@ -60,6 +62,25 @@ class RayTracingProblem:
         self.diffractions = {r: defaultdict(list) for r in range(n)}
         if self.place is not None:
             self.precompute()
+
+    # ---- the result containers: the reference's dictionaries, filled when first looked at ---------------------
+    @property
+    def reflections(self):
+        self._fill_containers()
+        return self._reflections
+
+    @reflections.setter
+    def reflections(self, value):
+        self._reflections = value
+
+    @property
+    def diffractions(self):
+        self._fill_containers()
+        return self._diffractions
+
+    @diffractions.setter
+    def diffractions(self, value):
+        self._diffractions = value
 
     # ------------------------------------------------------------------------------------------------
     def _device_scene(self):
@@ -161,61 +182,56 @@ class RayTracingProblem:
             self.solved_receivers = receivers  # the reference only gets here for max_order >= 2 (:352-353, 390)
 
     def store_paths(self, rx, group, cand_index, points, cand):
-        """Appends solved paths to ``reflections`` / ``diffractions`` in the reference's container shapes
-        (ray_tracing.py:314, 350, 376).  ``rx``: receiver index of each path, ``group`` / ``cand_index``: its candidate
-        (lines of sight, group -1, are skipped: precompute stored them), ``points`` [P, RT_MAX_ORDER, 3]; the paths must
-        come sorted by (receiver, group, candidate), which is the reference's visiting order.  The point arrays of all
-        paths of a kind are put together at once; per path only the tuple is made."""
+        """Takes solved paths for ``reflections`` / ``diffractions`` (ray_tracing.py:314, 350, 376).  ``rx``: receiver
+        index of each path, ``group`` / ``cand_index``: its candidate (lines of sight, group -1, are skipped:
+        precompute stored them), ``points`` [P, RT_MAX_ORDER, 3]; the paths must come sorted by (receiver, group,
+        candidate), which is the reference's visiting order.  Only arrays are kept here: a coverage map has hundreds
+        of thousands of paths, and the per-path tuples of the reference's containers are made when the containers
+        are first read (``to_json`` writes the file from the arrays)."""
         rx = np.asarray(rx, dtype=np.int64)
         group = np.asarray(group, dtype=np.int64)
-        cand_index = np.asarray(cand_index, dtype=np.int64)
-        points = np.asarray(points, dtype=float).reshape(len(rx), _lib.RT_MAX_ORDER, 3)
-        emitter = np.asarray(self.emitter, dtype=float).reshape(1, 3)
-        receivers = np.asarray(self.receivers, dtype=float).reshape(-1, 3)
-        edge_keys = [tuple(int(v) for v in k) for k in self._edge_pairs]
-        items = [None] * len(rx)
-        plain_items = [None] * len(rx)  # the same items as nested lists, for to_json (one tolist() per group of paths)
-        for g in np.unique(group):
-            if g < 0:
-                continue
-            sel = np.flatnonzero(group == g)
-            n_refl, has_edge = cand.group_kind(int(g))
-            chains, edge_ids = cand.group(int(g))
-            n_pts = n_refl + (1 if has_edge else 0)
-            lines = np.empty((len(sel), n_pts + 2, 3))
-            lines[:, 0] = emitter
-            lines[:, 1:n_pts + 1] = points[sel, :n_pts]
-            lines[:, n_pts + 1] = receivers[rx[sel]]
-            chain_lists = chains[cand_index[sel]].tolist() if n_refl else [[] for _ in sel]
-            lines_plain = lines.tolist()
-            if has_edge:
-                e = edge_ids[cand_index[sel]]
-                edge_points = self._edge_array[e]  # a copy per path, as the reference's containers hold
-                edges_plain = edge_points.tolist()
-                for k, i in enumerate(sel):
-                    items[i] = (lines[k], chain_lists[k], edge_keys[e[k]], edge_points[k])
-                    plain_items[i] = [lines_plain[k], chain_lists[k], list(edge_keys[e[k]]), edges_plain[k]]
-            else:
-                for k, i in enumerate(sel):
-                    items[i] = (lines[k], chain_lists[k])
-                    plain_items[i] = [lines_plain[k], chain_lists[k]]
-        orders = np.where(group >= cand.max_order, group - cand.max_order + 1, group + 1)
-        if self._plain is None:
-            # a mirror only makes sense when it sees every item go in: started on empty containers, or never
-            self._plain = {"reflections": {r: defaultdict(list) for r in self.reflections},
-                           "diffractions": {r: defaultdict(list) for r in self.diffractions},
-                           "count": 0} if self._count_items() == 0 else False
-        for i in np.flatnonzero(group >= 0):  # in the given order
-            which = "diffractions" if group[i] >= cand.max_order else "reflections"
-            getattr(self, which)[int(rx[i])][int(orders[i])].append(items[i])
-            if self._plain:
-                self._plain[which][int(rx[i])][int(orders[i])].append(plain_items[i])
-        if self._plain:
-            self._plain["count"] += int(np.count_nonzero(group >= 0))
+        keep = group >= 0
+        rx, group = rx[keep], group[keep]
+        cand_index = np.asarray(cand_index, dtype=np.int64)[keep]
+        points = np.asarray(points, dtype=float).reshape(len(keep), _lib.RT_MAX_ORDER, 3)[keep]
+        if len(rx) == 0:
+            return
+        kind, chain, edge_polys, edge_points = cand.describe(group, cand_index)
+        n_refl = (kind & 255).astype(np.int32)
+        has_edge = (kind >> 8) != 0
+        self._pending.append(dict(rx=rx, order=(n_refl + has_edge).astype(np.int32), n_refl=n_refl, has_edge=has_edge,
+                                  points=points, chain=chain.astype(np.int32), edge_key=edge_polys.astype(np.int32),
+                                  edge_points=edge_points.reshape(-1, 2, 3)))
 
-    def _count_items(self):
-        return sum(len(lst) for c in (self.reflections, self.diffractions) for by_order in c.values()
-                   for lst in by_order.values())
+    def _lines_of(self, batch, sel):
+        """[len(sel), RT_MAX_ORDER + 2, 3]: emitter, interaction points, receiver of the listed paths of a batch (a
+        path of n points uses the first n + 2 rows)."""
+        n_pts = batch["order"][sel]
+        lines = np.zeros((len(sel), _lib.RT_MAX_ORDER + 2, 3))
+        lines[:, 0] = np.asarray(self.emitter, dtype=float).reshape(1, 3)
+        lines[:, 1:_lib.RT_MAX_ORDER + 1] = batch["points"][sel]
+        receivers = np.asarray(self.receivers, dtype=float).reshape(-1, 3)
+        lines[np.arange(len(sel)), n_pts + 1] = receivers[batch["rx"][sel]]
+        return lines, n_pts
+
+    def _fill_containers(self):
+        """Puts the paths store_paths has taken into the dictionaries, in the reference's item shapes: the point
+        arrays of all paths of a kind are put together at once; per path only the tuple is made."""
+        pending, self._pending = self._pending, []
+        for batch in pending:
+            everything = np.arange(len(batch["rx"]))
+            lines, n_pts = self._lines_of(batch, everything)
+            chains = batch["chain"].tolist()
+            keys = [tuple(k) for k in batch["edge_key"].tolist()]
+            rx, order, n_refl, has_edge = batch["rx"].tolist(), batch["order"].tolist(), batch["n_refl"].tolist(), batch["has_edge"]
+            for i in range(len(rx)):
+                path = lines[i, :n_pts[i] + 2]
+                if has_edge[i]:
+                    # (a copy of the edge per path, as the reference's containers hold)
+                    item = (path, chains[i][:n_refl[i]], keys[i], batch["edge_points"][i].copy())
+                    self._diffractions[rx[i]][order[i]].append(item)
+                else:
+                    self._reflections[rx[i]][order[i]].append((path, chains[i][:n_refl[i]]))
 
     # ------------------------------------------------------------------------------------------------
     def path_set(self):
@@ -277,9 +293,21 @@ class RayTracingProblem:
                 return float(obj)
             return obj
 
-        # the mirror store_paths keeps is used when it still describes the containers (nobody appended by hand, and the
-        # containers were empty when it was started); otherwise the containers are walked
-        mirror = self._plain if self._plain and self._plain["count"] == self._count_items() else None
+        # The two path containers are most of the file.  When the paths are still the arrays of one store_paths call
+        # and the dictionaries hold nothing else, their text is written from the arrays (the same characters json.dumps
+        # gives for the dictionaries, tests/test_paths_json.py); otherwise the dictionaries are walked.
+        from_arrays = None
+        if len(self._pending) == 1 and not any(by_order for c in (self._reflections, self._diffractions)
+                                               for by_order in c.values()):
+            batch = self._pending[0]
+            from_arrays = {}
+            for name, container, is_diff in (("reflections", self._reflections, False), ("diffractions", self._diffractions, True)):
+                sel = np.flatnonzero(batch["has_edge"] == is_diff)
+                lines, n_pts = self._lines_of(batch, sel)
+                from_arrays[name] = _lib.format_paths_json(
+                    list(container.keys()), batch["rx"][sel], batch["order"][sel], n_pts + 2, lines, batch["n_refl"][sel],
+                    batch["chain"][sel], batch["edge_key"][sel] if is_diff else None,
+                    batch["edge_points"][sel] if is_diff else None)
         data = {
             "place": self.place.to_json(),
             "receivers": plain(self.receivers),
@@ -287,12 +315,16 @@ class RayTracingProblem:
             "emitter": plain(self.emitter),
             "n_screens": self.n_screens,
             "los": plain(self.los),
-            "reflections": mirror["reflections"] if mirror else plain(self.reflections),
-            "diffractions": mirror["diffractions"] if mirror else plain(self.diffractions),
         }
+        if from_arrays is None:
+            data["reflections"] = plain(self.reflections)
+            data["diffractions"] = plain(self.diffractions)
+        text = json.dumps(data)  # one pass of the C encoder (json.dump would iterate in Python)
+        if from_arrays is not None:
+            text = f'{text[:-1]}, "reflections": {from_arrays["reflections"]}, "diffractions": {from_arrays["diffractions"]}}}'
         filename = filename if ".json" in filename else f"{filename}.json"
         with open(filename, "w") as f:
-            f.write(json.dumps(data))  # one pass of the C encoder (json.dump would iterate in Python)
+            f.write(text)
 
     @staticmethod
     def from_json(filename):

@@ -90,3 +90,27 @@ def test_all_save_load_after_solve_and_problem_round_trip(tmp_path):
                 assert list(ca) == list(cb)
     other = RayTracingProblem(tx + np.array([[0.0, 0.0, 1.0]]), place)
     assert other != problem
+
+
+@pytest.mark.gpu
+def test_json_written_from_the_arrays_is_the_json_of_the_dictionaries(tmp_path):
+    """to_json writes the path containers straight from the solve's arrays while nobody has looked at the
+    dictionaries; once they have been filled it walks them.  Same file, character for character."""
+    from raytracing_amd import geometry as geom
+    from raytracing_amd.ray_tracing import RayTracingProblem
+
+    place = geom.load_place("data/small.geojson")
+    tx, rx = small_tx_rx(12)
+    place.add_set_of_points(rx)
+    problem = RayTracingProblem(tx.reshape(1, 3), place)
+    problem.solve(max_order=2)
+    assert len(problem._pending) == 1
+    problem.to_json(str(tmp_path / "from_arrays.json"))
+    assert len(problem._pending) == 1  # writing the file has not filled the dictionaries
+    n_refl = sum(len(v) for by_order in problem.reflections.values() for v in by_order.values())
+    n_diff = sum(len(v) for by_order in problem.diffractions.values() for v in by_order.values())
+    assert not problem._pending and n_refl > 20 and n_diff > 20
+    problem.to_json(str(tmp_path / "from_dictionaries.json"))
+    assert open(tmp_path / "from_arrays.json").read() == open(tmp_path / "from_dictionaries.json").read()
+    loaded = RayTracingProblem.from_json(str(tmp_path / "from_arrays.json"))
+    assert loaded == problem and loaded.path_set() == problem.path_set()
