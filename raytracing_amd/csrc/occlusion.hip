@@ -160,7 +160,7 @@ __device__ __forceinline__ void obstruct_drain_lds(const OccRec *recs, const int
 #define RT_GRID_MIN_POLYGONS 512
 #define OBS_PASSES 2
 #ifndef OBS_FIRST_PASS_TRIPS
-#define OBS_FIRST_PASS_TRIPS 24
+#define OBS_FIRST_PASS_TRIPS 16 /* trips of up to two records each */
 #endif
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_obstruct(SceneView sc, ObstructItems items, int64_t n_cap,
@@ -401,27 +401,38 @@ __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(Scene
         // for.  Doubling the pre-test arithmetic costs 23 %.)
         while (__any(!finished) && trips < max_trips) {
             ++trips;
-            bool cand = false;
-            int poly = 0;
+            // two records of the cell per trip where it has two left: what a trip costs beside the pre-tests (moving on
+            // to the next cell, the votes, the loop) is then shared by both
+            bool cand = false, cand2 = false;
+            int poly = 0, poly2 = 0;
             if (!finished) {
                 const OccRec *r = sc.cell_recs + k;
+                const bool two = k + 1 < k_end;
                 poly = r->poly;
                 bool wanted = true;
                 if (MASKED) wanted = !use_mask || mask[poly] != 0;
                 if (wanted) cand = occ_pretest(r, sc, A, V, pad);
-                ++k;
+                if (two) {
+                    poly2 = r[1].poly;
+                    bool wanted2 = true;
+                    if (MASKED) wanted2 = !use_mask || mask[poly2] != 0;
+                    if (wanted2) cand2 = occ_pretest(r + 1, sc, A, V, pad);
+                }
+                k += two ? 2 : 1;
                 if (k >= k_end) finished = !next_cell();
 #ifdef RT_OCC_STATS
-                ++st_recs;
+                st_recs += two ? 2 : 1;
                 if (cand) ++st_exact;
+                if (cand2) ++st_exact;
 #endif
             }
 #ifdef RT_OCC_STATS
             if (lane == 0) ++st_iters;
 #endif
-            const unsigned long long m = __ballot(cand);
-            if (m != 0) {
-                if (cand) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)poly << 6) | (uint32_t)lane;
+            auto park = [&](bool c, int p) {
+                const unsigned long long m = __ballot(c);
+                if (m == 0) return;
+                if (c) wq[qn + __popcll(m & ((1ull << lane) - 1))] = ((uint32_t)p << 6) | (uint32_t)lane;
                 qn += __popcll(m);
                 __builtin_amdgcn_wave_barrier();
                 if (qn >= 64) {
@@ -430,7 +441,9 @@ __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(Scene
                     __builtin_amdgcn_wave_barrier();
                     if (wave_hit[lane]) finished = true;
                 }
-            }
+            };
+            park(cand, poly);
+            park(cand2, poly2);
         }
         if (qn > 0) obstruct_drain<false>(sc, wave_ab[wave], wave_items[wave], 0, wq, qn, lane, wave_hit, out);
         __builtin_amdgcn_wave_barrier();
@@ -520,10 +533,10 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
     const bool walk_grid = scene->occlusion_mode == 2 ||
                            (scene->occlusion_mode == 0 && (scene->view.n > RT_GRID_MIN_POLYGONS || n_grid >= (1 << 16)));
     if (walk_grid) {
-        // Large launches go in passes: every wave of the first stops after OBS_FIRST_PASS_TRIPS records per lane and
+        // Large launches go in passes: every wave of the first stops after OBS_FIRST_PASS_TRIPS trips and
         // hands the items still walking to a second launch over just those, which walks them to the end (a wave lasts
         // as long as its longest walk, and most walks are short). Measured on 25 M segments of lln: one pass 17.2 ms,
-        // two passes 12.6 ms with 24 trips (worse with 8, 12, 16 or 40), three passes (24, 96, rest) 12.9 ms: a handed
+        // two passes 12.6 ms with 24 one-record trips (worse with 8, 12, 16 or 40), three passes (24, 96, rest) 12.9 ms: a handed
         // over item starts its walk again.
         const bool passes = n_grid >= (1 << 20) && n_item <= 0x7fffffffLL;
         if (!passes) {
