@@ -1762,7 +1762,9 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
                                           (scene->reflect_mode == 0 && n_rx >= 128 && n_rx * total_cand >= (1ll << 28)));
     RxTiles tiles{};
     if (tiled) {
-        chunk = std::max<int64_t>(RX_TILE, std::min<int64_t>(chunk, 1ll << 22) / RX_TILE * RX_TILE);
+        // (a chunk boundary has to fall on a tile boundary; a batch that goes in one chunk keeps its odd receivers: cut
+        // down to whole tiles it left a second chunk of a few receivers behind, whose sizes then steered the next solve)
+        if (chunk < n_rx || chunk > (1ll << 22)) chunk = std::max<int64_t>(RX_TILE, std::min<int64_t>(chunk, 1ll << 22) / RX_TILE * RX_TILE);
         int g_side = 1;
         while (g_side < 256 && (int64_t)g_side * g_side * 4 < n_rx) g_side *= 2;
         const SceneView &v = scene->view;
@@ -1790,6 +1792,8 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         tiles = RxTiles{rxs, perm, boxes};
     }
     unsigned long long found_before = 0;
+    // what the next solve sizes its launches from: the largest chunk of this one, not its last
+    int64_t seen_paths = 0, seen_segments = 0, seen_clear = 0;
 
     for (int64_t r0 = 0; r0 < n_rx;) {
         const int64_t r1 = std::min(n_rx, r0 + chunk);
@@ -1903,9 +1907,12 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         }
         found_before = h_counters[2];
         scene->counters_dirty = false;
-        scene->hint_paths = std::max<int64_t>(n_paths, 1);
-        scene->hint_segments = std::max<int64_t>(n_segs, 1);
-        scene->hint_clear = std::max<int64_t>((int64_t)h_counters[3], 1);
+        seen_paths = std::max<int64_t>(seen_paths, n_paths);
+        seen_segments = std::max<int64_t>(seen_segments, n_segs);
+        seen_clear = std::max<int64_t>(seen_clear, (int64_t)h_counters[3]);
+        scene->hint_paths = std::max<int64_t>(seen_paths, 1);
+        scene->hint_segments = std::max<int64_t>(seen_segments, 1);
+        scene->hint_clear = std::max<int64_t>(seen_clear, 1);
         // segments walked: every queued segment on the one-launch route; by rounds, the last segment of every queued
         // path and then, per further round, at most the paths still clear after the first (nearly all of them are
         // walked again; those that have no segment at that place are not: an upper bound a per cent or two high)

@@ -1,0 +1,30 @@
+"""Step time of the lln map for several receiver counts (not a test): python scripts/size_probe.py 60 71 80 100"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from raytracing_amd import _lib, scenarios  # noqa: E402
+from raytracing_amd import device_pipeline as dp  # noqa: E402
+from raytracing_amd import geometry as geom  # noqa: E402
+
+place, tx, _ = scenarios.lln_grid(10)
+scene = _lib.Scene(geom.scene_arrays_of(place.get_polygons_list()))
+pairs, edges = scene.sharp_edges()
+cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
+cand = scene.enumerate(vis, np.logical_or.reduce(screens), pairs, edges, 2, with_diffraction=True)
+scene.set_timing(True)
+for n_side in [int(v) for v in sys.argv[1:]]:
+    _, _, rx = scenarios.lln_grid(n_side)
+    d_rx = torch.tensor(rx, dtype=torch.float64, device="cuda:0")
+    pipe = dp.DevicePipeline(scene, cand, tx, capacity=40 * len(rx))
+    out = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        block = pipe.run(d_rx, [3.6e9], fields=False)
+        out.append((round(1e3 * (time.perf_counter() - t0), 2), round(block.solve_timing["ms"]["obstruct"], 2),
+                    block.solve_timing["launches"]["obstruct"]))
+    print(n_side, len(rx), "paths", block.n_paths, "(wall ms, obstruct ms, obstruct launches) per step:", out, flush=True)

@@ -430,3 +430,39 @@ def test_levant_study_scenes_match_the_exact_oracle(which, tmp_path, monkeypatch
     for (_, got), want in zip(df.iterrows(), rows):
         if want["path_type"] != "Impossible":
             assert abs(10 * np.log10(got["path_power"]) - 10 * np.log10(want["path_power"])) <= 0.01
+
+
+def test_odd_receiver_count_goes_in_one_chunk_and_keeps_the_next_solve_sized(places):
+    """A batch on receiver tiles whose count is no multiple of the tile size used to be cut into whole tiles plus a
+    second chunk of the few receivers left over, and the sizes of that tiny chunk then steered the launches of the next
+    solve (queues too small, the chunk redone, the one-launch obstruction route on millions of segments: a step of
+    the 5 041-receiver lln map took 320 ms instead of 7).  One chunk, and the same launches solve after solve."""
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import scenarios
+
+    place = places("place_levant")
+    polygons = place.get_polygons_list()
+    lo, hi = place.get_domain()
+    tx = scenarios.emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 25.0)
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+    scene.set_reflect_mode(2)  # receiver tiles, as large batches use them
+    launches = {}
+    for n_side in (48, 47):  # 2 304 = 144 tiles; 2 209 = 138 tiles and one receiver
+        rx = scenarios.lattice_receivers(place, n_side, 1.5)
+        assert (len(rx) % 16 == 0) == (n_side == 48)
+        results = [scene.solve_paths(cand, tx, rx) for _ in range(3)]
+        seen = [scene.last_timing()["launches"] for _ in range(1)]
+        launches[n_side] = seen[0]
+        for r in results[1:]:
+            assert r["n_attempted"] == results[0]["n_attempted"]
+            np.testing.assert_array_equal(np.sort(r["cand"]), np.sort(results[0]["cand"]))
+    scene.set_reflect_mode(0)
+    assert launches[47] == launches[48], launches  # one chunk each: the same number of launches of every family
+    cand.close()
+    scene.close()
