@@ -243,6 +243,17 @@ int rt_fields(rt_scene *scene, const double *tx, const double *rx, int64_t n_rx,
               int on_device);
 
 
+/* ---- one fixed-size record per receiver: what the ranks of a multi-GPU coverage map exchange instead of their paths
+ * (the device-side stand-in for merge_solved_problems, multithread_solve.py:45-60).  Device pointers of the scene's GPU
+ * only: power_db[n_rx*n_freq] as rt_fields left it, path_rx / path_kind / path_status[n_paths] (status may be NULL).
+ * out[n_rx * rt_receiver_record_bytes(n_freq)]: per receiver n_freq doubles (dB per frequency), then int32: paths per
+ * path type (line of sight; 1..RT_MAX_ORDER reflections; 0..RT_MAX_ORDER-1 reflections and a diffraction), paths in all,
+ * paths with a non-zero field status, largest status code; padded to a multiple of 8 bytes (56 at one frequency).
+ * Queued on the scene's stream and waited for. */
+int32_t rt_receiver_record_bytes(int32_t n_freq);
+int rt_receiver_records(rt_scene *scene, int64_t n_rx, int32_t n_freq, const double *power_db, int64_t n_paths,
+                        const int32_t *path_rx, const int32_t *path_kind, const int32_t *path_status, unsigned char *out);
+
 /* ---- text encoding of the result table's array columns (electromagnetism_utils.py:104-117 / :217-269: the CSV holds
  * each small array as numpy.array2string(a, separator=",") without spaces).  values[n_rows*n_cols] real or
  * [n_rows*n_cols*2] complex (re, im interleaved), n_cols <= 16; the rows' strings are written one after the other, each

@@ -69,6 +69,8 @@ _SIGNATURES = {
     "rt_fields_last_timing": (c_int, [c_void_p, c_void_p]),
     "rt_visibility_last_timing": (c_int, [c_void_p, c_void_p]),
     "rt_describe_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "rt_receiver_record_bytes": (c_int32, [c_int32]),
+    "rt_receiver_records": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rt_format_array_rows": (c_int64, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64]),
     "rt_format_paths_json": (c_int64, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
                                        c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64]),
@@ -305,6 +307,12 @@ class Scene:
         """Largest deepest reflection level (bytes of its chains) that ``enumerate`` stores; above it the level's
         chains are formed in the kernels from the level before (same candidates and indices)."""
         _check(load().rt_debug_set_stored_chain_limit(self.handle, int(n_bytes)), "rt_debug_set_stored_chain_limit")
+
+    def receiver_records_device(self, n_rx, n_freq, power_db_ptr, n_paths, path_rx_ptr, path_kind_ptr, path_status_ptr,
+                                out_ptr):
+        """One fixed-size record per receiver from the arrays ``fields_device`` left on this GPU (rt_receiver_records)."""
+        _check(load().rt_receiver_records(self.handle, int(n_rx), int(n_freq), power_db_ptr, int(n_paths), path_rx_ptr,
+                                          path_kind_ptr, path_status_ptr, out_ptr), "rt_receiver_records")
 
     def set_timing(self, on):
         """Per-kernel-family timing of the solves on (default) or off; ``last_timing`` reports zeros while off."""

@@ -1036,3 +1036,66 @@ extern "C" int rt_fields_last_timing(rt_scene *scene, double *ms2) {
     ms2[1] = scene->last_fields_ms[1];
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// One fixed-size record per receiver: what the ranks of a multi-GPU run exchange instead of their paths (the
+// device-side stand-in for merge_solved_problems of a coverage map, multithread_solve.py:45-60 of the reference).
+// Record: n_freq doubles (power in dB per frequency), then RT_RECORD_INTS int32: paths per path type (line of sight;
+// 1..RT_MAX_ORDER reflections; 0..RT_MAX_ORDER-1 reflections and a diffraction), paths in all, paths whose field status
+// is not zero, largest status code; padded to a multiple of 8 bytes.
+// ---------------------------------------------------------------------------------------------------------------
+#define RT_RECORD_TYPES (1 + 2 * RT_MAX_ORDER)
+#define RT_RECORD_INTS (RT_RECORD_TYPES + 3)
+
+__global__ void k_records_start(int64_t n_rx, int n_freq, const double *__restrict__ power_db, unsigned char *__restrict__ rec,
+                                int record_bytes) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rx) return;
+    double *db = (double *)(rec + r * record_bytes);
+    for (int f = 0; f < n_freq; ++f) db[f] = power_db[r * n_freq + f];
+    int32_t *ints = (int32_t *)(rec + r * record_bytes + 8 * n_freq);
+    for (int k = 0; k < (record_bytes - 8 * n_freq) / 4; ++k) ints[k] = 0;
+}
+
+__global__ void k_records_count(int64_t n_paths, int64_t n_rx, const int32_t *__restrict__ path_rx,
+                                const int32_t *__restrict__ path_kind, const int32_t *__restrict__ path_status, int n_freq,
+                                unsigned char *__restrict__ rec, int record_bytes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_paths) return;
+    const int64_t r = path_rx[i];
+    if (r < 0 || r >= n_rx) return;
+    int32_t *ints = (int32_t *)(rec + r * record_bytes + 8 * n_freq);
+    const int kind = path_kind[i];
+    const int type = (kind & 255) + (RT_MAX_ORDER + 1) * (kind >> 8);  // LOS, R.., then D, RD, ..
+    if (type >= 0 && type < RT_RECORD_TYPES) atomicAdd(&ints[type], 1);
+    atomicAdd(&ints[RT_RECORD_TYPES], 1);
+    const int status = path_status ? path_status[i] : 0;
+    if (status != 0) {
+        atomicAdd(&ints[RT_RECORD_TYPES + 1], 1);
+        atomicMax(&ints[RT_RECORD_TYPES + 2], status);
+    }
+}
+
+extern "C" int32_t rt_receiver_record_bytes(int32_t n_freq) {
+    const int raw = 8 * n_freq + 4 * RT_RECORD_INTS;
+    return (raw + 7) & ~7;
+}
+
+extern "C" int rt_receiver_records(rt_scene *scene, int64_t n_rx, int32_t n_freq, const double *power_db, int64_t n_paths,
+                                   const int32_t *path_rx, const int32_t *path_kind, const int32_t *path_status,
+                                   unsigned char *out) {
+    if (!scene) RT_FAIL("rt_receiver_records: null scene");
+    if (n_rx < 0 || n_paths < 0 || n_freq < 1) RT_FAIL("rt_receiver_records: bad size");
+    if (n_rx == 0) return 0;
+    if (!power_db || !out || (n_paths > 0 && (!path_rx || !path_kind))) RT_FAIL("rt_receiver_records: null array");
+    RT_HIP(hipSetDevice(scene->device));
+    hipStream_t st = scene->stream;
+    const int bytes = rt_receiver_record_bytes(n_freq);
+    hipLaunchKernelGGL(k_records_start, dim3((unsigned)((n_rx + 255) / 256)), dim3(256), 0, st, n_rx, n_freq, power_db, out, bytes);
+    if (n_paths > 0)
+        hipLaunchKernelGGL(k_records_count, dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, st, n_paths, n_rx, path_rx,
+                           path_kind, path_status, n_freq, out, bytes);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(st));
+    return 0;
+}

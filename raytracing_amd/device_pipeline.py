@@ -122,34 +122,26 @@ class DevicePipeline:
                                      power_db.data_ptr(), n_late_polygons=self.n_late_polygons, **antenna)
             fields_timing = self.field_scene.fields_timing()
         views = {k: v[:n] for k, v in b.items()}
-        return PathBlock(n_rx=n_rx, n_paths=n, n_attempted=int(attempted), power_db=power_db, frequencies=freqs,
+        return PathBlock(scene=self.field_scene, n_rx=n_rx, n_paths=n, n_attempted=int(attempted), power_db=power_db,
+                         frequencies=freqs,
                          solve_timing=solve_timing, fields_timing=fields_timing, **views)
 
 
 def receiver_records(block):
     """One fixed-size record per receiver of a PathBlock, as a uint8 CUDA tensor [n_rx, record_bytes(n_freq)]:
     float64 dB per frequency (-inf without a path), then int32 path counts per type (TYPE_NAMES), the number of paths,
-    the number of paths whose field status is non-zero and the largest status code.  Device work only."""
+    the number of paths whose field status is non-zero and the largest status code (``rt_receiver_records``: two
+    launches on the library's stream)."""
     import torch
 
     n_rx, nf, n = block.n_rx, len(block.frequencies), block.n_paths
-    dev = block.power_db.device
-    ints = torch.zeros((n_rx, N_INT_COLUMNS), dtype=torch.int32, device=dev)
-    if n:
-        rx = block.rx.to(torch.int64)
-        kind = block.kind.to(torch.int64)
-        code = (kind & 255) + (_lib.RT_MAX_ORDER + 1) * (kind >> 8)
-        counts = torch.bincount(rx * N_TYPES + code, minlength=n_rx * N_TYPES).reshape(n_rx, N_TYPES)
-        ints[:, :N_TYPES] = counts.to(torch.int32)
-        ints[:, N_TYPES] = counts.sum(dim=1).to(torch.int32)
-        bad = block.status != 0
-        ints[:, N_TYPES + 1] = torch.bincount(rx[bad], minlength=n_rx).to(torch.int32)
-        worst = torch.zeros(n_rx, dtype=torch.int32, device=dev)
-        worst.scatter_reduce_(0, rx, block.status, reduce="amax", include_self=True)
-        ints[:, N_TYPES + 2] = worst
-    rec = torch.zeros((n_rx, record_bytes(nf)), dtype=torch.uint8, device=dev)
-    rec[:, :8 * nf] = block.power_db.contiguous().view(torch.uint8).reshape(n_rx, 8 * nf)
-    rec[:, 8 * nf:8 * nf + 4 * N_INT_COLUMNS] = ints.view(torch.uint8).reshape(n_rx, 4 * N_INT_COLUMNS)
+    assert _lib.load().rt_receiver_record_bytes(nf) == record_bytes(nf)
+    rec = torch.empty((n_rx, record_bytes(nf)), dtype=torch.uint8, device=block.power_db.device)
+    if n_rx:
+        scene = block.scene
+        scene.wait_for_stream(torch.cuda.current_stream(block.power_db.device).cuda_stream)
+        scene.receiver_records_device(n_rx, nf, block.power_db.data_ptr(), n, block.rx.data_ptr(), block.kind.data_ptr(),
+                                      block.status.data_ptr(), rec.data_ptr())
     return rec
 
 

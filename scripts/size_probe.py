@@ -17,14 +17,21 @@ cube = geom.Cube.by_point_and_side_length(tx, 0.2)
 vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
 cand = scene.enumerate(vis, np.logical_or.reduce(screens), pairs, edges, 2, with_diffraction=True)
 scene.set_timing(True)
-for n_side in [int(v) for v in sys.argv[1:]]:
+for arg in sys.argv[1:]:
+    # "71": a 71 x 71 map; "100/8": the first of eight contiguous blocks of the 100 x 100 map (one rank of eight)
+    parts = arg.split("/")
+    n_side = int(parts[0])
     _, _, rx = scenarios.lln_grid(n_side)
+    if len(parts) > 1:
+        per = (len(rx) + int(parts[1]) - 1) // int(parts[1])
+        k = int(parts[2]) if len(parts) > 2 else 0
+        rx = rx[k * per:(k + 1) * per]
     d_rx = torch.tensor(rx, dtype=torch.float64, device="cuda:0")
     pipe = dp.DevicePipeline(scene, cand, tx, capacity=40 * len(rx))
     out = []
     for _ in range(5):
         t0 = time.perf_counter()
         block = pipe.run(d_rx, [3.6e9], fields=False)
-        out.append((round(1e3 * (time.perf_counter() - t0), 2), round(block.solve_timing["ms"]["obstruct"], 2),
-                    block.solve_timing["launches"]["obstruct"]))
-    print(n_side, len(rx), "paths", block.n_paths, "(wall ms, obstruct ms, obstruct launches) per step:", out, flush=True)
+        out.append((round(1e3 * (time.perf_counter() - t0), 2),) + tuple(round(float(block.solve_timing["ms"][k]), 2)
+                                                                         for k in ("reflect", "diffract", "obstruct", "finalize")))
+    print(arg, len(rx), "paths", block.n_paths, "(wall, reflect, diffract, obstruct, finalize ms) per step:", out[1:], flush=True)

@@ -368,3 +368,45 @@ def test_pipeline_waits_on_the_device_for_the_callers_stream(places):
     torch.cuda.synchronize()
     for name in ("rx", "group", "cand", "points", "power", "power_db"):
         np.testing.assert_array_equal(got[name], want[name])
+
+
+@pytest.mark.gpu
+def test_receiver_records_hold_what_the_path_arrays_say(places):
+    """The fixed-size record per receiver (rt_receiver_records) against a NumPy count over the same block's path
+    arrays: dB per frequency, paths per type, paths in all, flagged paths, worst status."""
+    import torch
+
+    from raytracing_amd import _lib
+    from raytracing_amd import device_pipeline as dp
+    from raytracing_amd import geometry as geom
+
+    place = places("small")
+    tx, rx = small_tx_rx(16)
+    rx = np.concatenate([rx, [[500.0, 500.0, 1.5]]])  # a receiver no path reaches but the line of sight
+    scene = _lib.Scene(geom.scene_arrays_of(place.get_polygons_list()))
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    cand = scene.enumerate(vis, ev, pairs, edges, 3, with_diffraction=True)
+    pipe = dp.DevicePipeline(scene, cand, tx)
+    d_rx = torch.tensor(rx, dtype=torch.float64, device="cuda:0")
+    freqs = [3.6e9, 28e9, 60e9]
+    block = pipe.run(d_rx, freqs)
+    block.status[::7] = 3  # as if the field step had flagged some paths
+    block.status[5] = 9
+    rec = dp.unpack_records(dp.receiver_records(block).cpu().numpy(), len(freqs))
+    host = block.to_host()
+    status = block.status.cpu().numpy()
+    prx, kind = block.rx.cpu().numpy(), block.kind.cpu().numpy()
+    assert dp.record_bytes(3) == 72 and dp.record_bytes(2) == 64 and dp.record_bytes(1) == 56
+    np.testing.assert_array_equal(rec["power_db"], host["power_db"])
+    types = (kind & 255) + (_lib.RT_MAX_ORDER + 1) * (kind >> 8)
+    for r in range(len(rx)):
+        mine = prx == r
+        np.testing.assert_array_equal(rec["counts"][r], np.bincount(types[mine], minlength=dp.N_TYPES))
+        assert rec["n_paths"][r] == mine.sum()
+        assert rec["n_flagged"][r] == (status[mine] != 0).sum()
+        assert rec["worst_status"][r] == (status[mine].max() if mine.any() and status[mine].max() > 0 else 0)
+    assert rec["n_paths"].sum() == block.n_paths > 100 and rec["counts"][:, 0].sum() >= 10
+    assert set(np.unique(types).tolist()) >= {0, 1, 2, 5, 6}  # LOS, R, RR, D, RD all occur
