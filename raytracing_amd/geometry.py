@@ -104,7 +104,8 @@ def ring_contains(ring, x, y):
     ring = np.asarray(ring, dtype=float)
     x = np.atleast_1d(np.asarray(x, dtype=float))
     y = np.atleast_1d(np.asarray(y, dtype=float))
-    ax, ay = np.roll(ring[:, 0], 1)[:, None], np.roll(ring[:, 1], 1)[:, None]
+    before = np.concatenate([ring[-1:], ring[:-1]])  # the vertex each side starts from
+    ax, ay = before[:, 0][:, None], before[:, 1][:, None]
     bx, by = ring[:, 0][:, None], ring[:, 1][:, None]
     cross = (bx - ax) * (y[None, :] - ay) - (by - ay) * (x[None, :] - ax)
     on_edge = (cross == 0.0) & (np.minimum(ax, bx) <= x) & (x <= np.maximum(ax, bx)) & (np.minimum(ay, by) <= y) & \

@@ -43,17 +43,7 @@ def _inside_any_many(footprints, boxes, xs, ys):
         sel = np.flatnonzero((lo[0] <= xs) & (xs <= hi[0]) & (lo[1] <= ys) & (ys <= hi[1]) & ~inside)
         if len(sel) == 0:
             continue
-        x, y = xs[sel], ys[sel]
-        odd = np.zeros(len(sel), dtype=bool)
-        on_edge = np.zeros(len(sel), dtype=bool)
-        n = len(ring)
-        for k in range(n):
-            ax, ay = ring[k - 1]
-            bx, by = ring[k]
-            cr = (bx - ax) * (y - ay) - (by - ay) * (x - ax)
-            on_edge |= (cr == 0) & (min(ax, bx) <= x) & (x <= max(ax, bx)) & (min(ay, by) <= y) & (y <= max(ay, by))
-            odd ^= ((ay > y) != (by > y)) & ((cr > 0) == (by > ay))
-        inside[sel] = on_edge | odd
+        inside[sel] = geom.ring_contains(ring, xs[sel], ys[sel])  # the same crossing-number and on-edge tests, all sides at once
     return inside
 
 
