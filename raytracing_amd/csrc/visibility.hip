@@ -40,6 +40,7 @@ __device__ unsigned long long g_vis_phase[16];
 extern "C" int rt_debug_visibility_phases(unsigned long long *out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_vis_phase), sizeof(g_vis_phase)) != hipSuccess) return -1;
     unsigned long long z[16] = {0};
+    z[15] = ~0ull;  // slot of a minimum
     return hipMemcpyToSymbol(HIP_SYMBOL(g_vis_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 // Compiled in only for profiling builds (-DRT_VIS_STATS, ~170 M updates on a 7 615-polygon scene); otherwise
@@ -626,6 +627,20 @@ __device__ inline int edge_cuts(double ax, double ay, double bx, double by, doub
     return k;
 }
 
+// a / d for small non-negative a (below 2^21) and a divisor that is the same for every lane: the hardware has no
+// integer division, the compiler's expansion is some forty instructions, and these loops are bound by how many
+// instructions one wave can issue.  (a + 0.5) / d is never within 0.5 / d of an integer, far more than the rounding.
+struct SmallDivisor {
+    int d;
+    float inv;
+    __device__ explicit SmallDivisor(int d_) : d(d_), inv(1.0f / (float)d_) {}
+    __device__ int quotient(int a) const { return (int)(((float)a + 0.5f) * inv); }
+    __device__ void split(int a, int &q, int &r) const {
+        q = quotient(a);
+        r = a - q * d;
+    }
+};
+
 // Cut parameters of the edge being examined: the first SPLIT_LDS live in LDS, the rare overflow in global memory.
 #define SPLIT_LDS 192
 #define PIECE_LDS 64 /* pieces (or sample points) whose witnesses are tested with lanes = (piece, entry) pairs */
@@ -645,7 +660,7 @@ struct SplitBuf {
 // Examine every piece of edge a->b of entry `owner` (witness side `side`): returns true (wave-uniform) when a witness
 // proves B visible.
 template <typename Set>
-__device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay, double bx, double by, double side,
+__device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay, double bx, double by, double side,
                                  bool need_in_b, const SplitBuf &splits, int *lds_count, const TileSpan &tile) {
     const int lane = threadIdx.x & 63;
     const double ex = bx - ax, ey = by - ay;
@@ -722,7 +737,6 @@ __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay,
     if (n_splits > SPLIT_LDS) __threadfence_block();
     if (n_splits > splits.cap) n_splits = (int)splits.cap;  // cannot happen: capacity is 3 cuts per scene edge + 1
     if (lane == 0) {
-        VIS_STAT(3, n_splits);
         VIS_STAT(7, 1);
     }
     // ---- every piece (t_j, next larger cut or 1)
@@ -743,14 +757,43 @@ __device__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay,
             splits.py[lane] = ay + tm * ey + side * VIS_DELTA * (ex / len);
             splits.pstate[lane] = ((t1 - t0) * len > VIS_MIN_PIECE && tile.holds(wx)) ? 1 : 0;
         }
-        __builtin_amdgcn_wave_barrier();
+        // only an entry whose box reaches the edge's can hold a witness (they stand VIS_DELTA beside the edge): those
+        // are listed first, in the part of the cut buffer that this few cuts leave free (B itself, when the witnesses
+        // have to be inside it, is always listed)
         const int first = need_in_b ? 0 : 1;
-        const int per_piece = n - first;
+        int *near_list = (int *)(splits.lds + PIECE_LDS);
+        const int near_cap = (SPLIT_LDS - PIECE_LDS) * 2;
+        int n_near = 0;
+        {
+            const double e_x0 = fmin(ax, bx) - 2 * VIS_DELTA, e_x1 = fmax(ax, bx) + 2 * VIS_DELTA;
+            const double e_y0 = fmin(ay, by) - 2 * VIS_DELTA, e_y1 = fmax(ay, by) + 2 * VIS_DELTA;
+            for (int base = first; base < n; base += 64) {
+                const int li = base + lane;
+                bool reaches = false;
+                if (li < n) {
+                    double x0, x1, y0, y1;
+                    ps.box(li, x0, x1, y0, y1);
+                    reaches = li == 0 || !(x1 < e_x0 || x0 > e_x1 || y1 < e_y0 || y0 > e_y1);
+                }
+                const unsigned long long mk = __ballot(reaches);
+                if (reaches) {
+                    const int slot = n_near + __popcll(mk & ((1ull << lane) - 1));
+                    if (slot < near_cap) near_list[slot] = li;
+                }
+                n_near += __popcll(mk);
+            }
+        }
+        const bool listed = n_near <= near_cap;
+        __builtin_amdgcn_wave_barrier();
+        const int per_piece = listed ? n_near : n - first;
         const int n_pairs = n_splits * per_piece;
+        const SmallDivisor by_piece(per_piece > 0 ? per_piece : 1);
         for (int base = 0; base < n_pairs; base += 64) {
             const int pair = base + lane;
             if (pair < n_pairs) {
-                const int j = pair / per_piece, i = first + pair % per_piece;
+                int j, at;
+                by_piece.split(pair, j, at);
+                const int i = listed ? near_list[at] : first + at;
                 if (splits.pstate[j]) {
                     const double wx = splits.px[j], wy = splits.py[j];
                     if (i == 0) {
@@ -813,6 +856,7 @@ __device__ inline bool inside_one_entry(const Set &ps) {
             const int cn = ps.nv(e);
             const double *cx = ps.x(e), *cy = ps.y(e);
             const int n_pips = nv * 5, n_meets = cn * nv;
+            const SmallDivisor by_nv(nv);
             bool ok = true;
             for (int w0 = 0; w0 < n_pips + n_meets && ok; w0 += 64) {
                 const int w = w0 + lane;
@@ -825,7 +869,8 @@ __device__ inline bool inside_one_entry(const Set &ps) {
                     mine = pip_ring(cx, cy, cn, x[v] + ox, y[v] + oy);
                 } else if (w < n_pips + n_meets) {
                     const int m = w - n_pips;
-                    const int q = m / nv, v = m % nv;
+                    int q, v;
+                    by_nv.split(m, q, v);
                     const int p = q == 0 ? cn - 1 : q - 1, u = v == 0 ? nv - 1 : v - 1;
                     mine = !segments_meet(cx[p], cy[p], cx[q], cy[q], x[u], y[u], x[v], y[v]);
                 }
@@ -837,11 +882,155 @@ __device__ inline bool inside_one_entry(const Set &ps) {
     return hidden;
 }
 
+// Is entry 0 of `ps` (B, convex) inside the union of TWO other convex entries A and C?  For convex A, C and B it is
+// enough that B's ring lies in A u C: a point of B outside both would have every chord through it end once in A only
+// and once in C only, and turning the chord half round swaps the ends, so some chord ends in both.  Each edge of B is
+// clipped to A shrunk by VIS_TWO_MARGIN; what sticks out must lie in C shrunk likewise, which for a convex C is a
+// test of the end points of those parts.  Two walls of a building share their corner edge exactly (the same mapped
+// vertices, bit for bit): along such an edge nothing is shrunk - A ends where C starts - and a point where B's edge
+// leaves A through it is not asked to be on C's side of it.  One wave, lanes = pairs (A, C) among the first
+// VIS_TWO_ENTRIES listed; only rings of at most VIS_TWO_NV vertices take part.  A proof that fails says nothing.
+#define VIS_TWO_ENTRIES 11
+#define VIS_TWO_NV 8
+#define VIS_TWO_MARGIN 1e-9
+template <typename P>
+__device__ inline bool ring_turns_one_way(P x, P y, int nv, double sgn) {
+    for (int v = 0; v < nv; ++v) {
+        const int u = v == 0 ? nv - 1 : v - 1, w = v + 1 == nv ? 0 : v + 1;
+        if (sgn * ((x[v] - x[u]) * (y[w] - y[v]) - (y[v] - y[u]) * (x[w] - x[v])) < 0.0) return false;
+    }
+    return true;
+}
+// inside every edge of the convex ring by the margin; edge `skip` (its end vertex) is not asked, edge `closed` only
+// has to hold without margin
+template <typename P>
+__device__ inline bool inside_shrunk(P x, P y, int nv, double sgn, double px, double py, int skip, int closed) {
+    for (int k = 0; k < nv; ++k) {
+        if (k == skip) continue;
+        const int u = k == 0 ? nv - 1 : k - 1;
+        const double ex = x[k] - x[u], ey = y[k] - y[u];
+        const double cr = sgn * (ex * (py - y[u]) - ey * (px - x[u]));
+        if (cr < 0.0) return false;
+        if (k != closed && cr * cr < VIS_TWO_MARGIN * VIS_TWO_MARGIN * (ex * ex + ey * ey)) return false;
+    }
+    return true;
+}
+// One edge (u -> v) of B against the pair: clipped to A (shrunk, except along the shared edge `ea`), and what sticks
+// out asked of C (shrunk; along the shared edge `ec` only closed, and not asked at all of a point where B's edge
+// leaves A through the shared edge).
+template <typename Set>
+__device__ inline bool edge_in_pair(const Set &ps, int ia, int ic, int ea, int ec, int v) {
+    const int nv = ps.nv(0), an = ps.nv(ia), cn = ps.nv(ic);
+    const double *x = ps.x(0), *y = ps.y(0);
+    const double *ax = ps.x(ia), *ay = ps.y(ia), *cx = ps.x(ic), *cy = ps.y(ic);
+    const double sa = (double)ps.sgn(ia), sc = (double)ps.sgn(ic);
+    const int u = v == 0 ? nv - 1 : v - 1;
+    const double px = x[u], py = y[u], qx = x[v], qy = y[v];
+    double t0 = 0.0, t1 = 1.0;
+    int by0 = -1, by1 = -1;  // the edges of A that bound the part inside
+    for (int k = 0; k < an; ++k) {
+        const int w = k == 0 ? an - 1 : k - 1;
+        const double ex = ax[k] - ax[w], ey = ay[k] - ay[w];
+        const double back = k == ea ? 0.0 : VIS_TWO_MARGIN * sqrt(ex * ex + ey * ey);
+        const double fp = sa * (ex * (py - ay[w]) - ey * (px - ax[w])) - back;
+        const double fq = sa * (ex * (qy - ay[w]) - ey * (qx - ax[w])) - back;
+        if (fp < 0.0 && fq < 0.0) {
+            t0 = 2.0;
+        } else if (fp < 0.0) {
+            const double t = fp / (fp - fq);
+            if (t > t0) { t0 = t; by0 = k; }
+        } else if (fq < 0.0) {
+            const double t = fp / (fp - fq);
+            if (t < t1) { t1 = t; by1 = k; }
+        }
+    }
+    const bool none = t0 > t1;  // nothing of this edge in A: both ends in C
+    bool ok = true;
+    if (none || t0 > 0.0) ok = inside_shrunk(cx, cy, cn, sc, px, py, -1, ec);
+    if (ok && (none || t1 < 1.0)) ok = inside_shrunk(cx, cy, cn, sc, qx, qy, -1, ec);
+    if (ok && !none && t0 > 0.0)
+        ok = inside_shrunk(cx, cy, cn, sc, px + t0 * (qx - px), py + t0 * (qy - py), by0 == ea ? ec : -1, ec);
+    if (ok && !none && t1 < 1.0)
+        ok = inside_shrunk(cx, cy, cn, sc, px + t1 * (qx - px), py + t1 * (qy - py), by1 == ea ? ec : -1, ec);
+    return ok;
+}
+// Wave-uniform.  Steps, each with its own meaning of a lane: (entry, vertex of B) - which vertices of B each entry
+// holds; entry - is it a small convex ring; pair - do the two hold all of B's vertices between them (a necessary
+// condition that leaves a pair or two); then per such pair: (edge of A, edge of C) for the shared edge and edge of B
+// for the clipping.
+template <typename Set>
+__device__ inline bool inside_two_entries(const Set &ps) {
+    const int lane = threadIdx.x & 63;
+    const int n = ps.count(), nv = ps.nv(0);
+    if (n < 3 || nv > VIS_TWO_NV) return false;
+    if (!ring_turns_one_way(ps.x(0), ps.y(0), nv, (double)ps.sgn(0))) return false;
+    int m = n - 1 < VIS_TWO_ENTRIES ? n - 1 : VIS_TWO_ENTRIES;
+    if (m * nv > 64) m = 64 / nv;
+    const double *x = ps.x(0), *y = ps.y(0);
+    bool holds = false;
+    if (lane < m * nv) {
+        int e, v;
+        SmallDivisor(nv).split(lane, e, v);
+        e += 1;
+        holds = inside_shrunk(ps.x(e), ps.y(e), ps.nv(e), (double)ps.sgn(e), x[v], y[v], -1, -1);
+    }
+    const unsigned long long held = __ballot(holds);
+    bool usable = false;
+    if (lane < m) {
+        const int e = 1 + lane, cn = ps.nv(e);
+        usable = cn <= VIS_TWO_NV && ring_turns_one_way(ps.x(e), ps.y(e), cn, (double)ps.sgn(e));
+    }
+    const unsigned long long convex = __ballot(usable);
+    const unsigned long long all_b = (1ull << nv) - 1;
+    bool wanted = false;
+    int i = 1, j = 2;
+    if (lane < m * (m - 1) / 2) {
+        int rest = lane;
+        while (rest >= m - i) {
+            rest -= m - i;
+            ++i;
+        }
+        j = i + 1 + rest;
+        const unsigned long long hi = (held >> ((i - 1) * nv)) & all_b, hj = (held >> ((j - 1) * nv)) & all_b;
+        wanted = ((convex >> (i - 1)) & (convex >> (j - 1)) & 1) != 0 && (hi | hj) == all_b;
+    }
+    unsigned long long todo = __ballot(wanted);
+    while (todo != 0) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int ia = __shfl(i, src), ic = __shfl(j, src);
+        const int an = ps.nv(ia), cn = ps.nv(ic);
+        // the edge A and C share, if any (end vertex of the edge in each ring): the same two mapped vertices, bit for
+        // bit, and the two interiors on different sides of it
+        bool shared = false;
+        if (lane < an * cn) {
+            const double *ax = ps.x(ia), *ay = ps.y(ia), *cx = ps.x(ic), *cy = ps.y(ic);
+            int k, q;
+            SmallDivisor(cn).split(lane, k, q);
+            const int u = k == 0 ? an - 1 : k - 1, w = q == 0 ? cn - 1 : q - 1;
+            const bool same = ax[u] == cx[w] && ay[u] == cy[w] && ax[k] == cx[q] && ay[k] == cy[q];
+            const bool turned = ax[u] == cx[q] && ay[u] == cy[q] && ax[k] == cx[w] && ay[k] == cy[w];
+            const bool apart = ps.sgn(ia) != ps.sgn(ic);
+            shared = (same && apart) || (turned && !apart);
+        }
+        const unsigned long long sh = __ballot(shared);
+        int ea = -1, ec = -1;
+        if (sh != 0) {
+            const int at = __ffsll((long long)sh) - 1;
+            ea = at / cn;
+            ec = at % cn;
+        }
+        const bool ok = lane >= nv || edge_in_pair(ps, ia, ic, ea, ec, lane);
+        if (__all(ok)) return true;
+    }
+    return false;
+}
+
 // Decide whether entry 0 of `ps` has a part outside the union of the other entries (wave-uniform result).
 // Called by all waves of the workgroup with identical arguments (the result is uniform over the workgroup): the cheap
 // shortcuts are computed by every wave, the edge examinations are dealt out to the waves and joined through `flag`.
 template <typename Set>
-__device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *lds_count, int32_t *work, int *flag,
+__device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *lds_count, int32_t *work, int *flag,
                                   const TileSpan &tile, bool inside_one_done) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int n = ps.count();
@@ -849,7 +1038,7 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
     const double *x = ps.x(0), *y = ps.y(0);
     double bx0, bx1, by0, by1;
     ps.box(0, bx0, bx1, by0, by1);
-#ifdef RT_VIS_STAMPS
+#if defined(RT_VIS_STAMPS) && !defined(RT_VIS_ITEMS_ONLY)
     unsigned long long t_prev = wall_clock64();
 #define PHASE(i)                                                                                 \
     do {                                                                                         \
@@ -894,10 +1083,13 @@ __device__ bool polygon_uncovered(const Set &ps, const SplitBuf &splits, int *ld
         __builtin_amdgcn_wave_barrier();
         const int per_sample = n - 1;
         const int n_pairs = n_samples * per_sample;
+        const SmallDivisor by_sample(per_sample > 0 ? per_sample : 1);
         for (int base = 0; base < n_pairs; base += 64) {
             const int pair = base + lane;
             if (pair < n_pairs) {
-                const int sidx = pair / per_sample, li = 1 + pair % per_sample;
+                int sidx, li;
+                by_sample.split(pair, sidx, li);
+                li += 1;
                 if (splits.pstate[sidx]) {
                     const double px = splits.px[sidx], py = splits.py[sidx];
                     double x0, x1, y0, y1;
@@ -1240,7 +1432,7 @@ __global__ __launch_bounds__(1024) void k_vis_item_offsets(const int32_t *__rest
 // One workgroup (NW waves: four when many faces are painted at once, sixteen for a handful) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
 // polygons whose box meets it and stages them in LDS; all waves then decide coverage together.
 template <typename Store, int NW>
-__global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch fb, const double *__restrict__ sph,
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneView sc, FaceBatch fb, const double *__restrict__ sph,
                                                     const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
                                                     int m_stride, const int32_t *__restrict__ counts, PaintScratch ps,
                                                     int strict, unsigned long long *work_counter,
@@ -1296,7 +1488,7 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
             }
         }
         __syncthreads();
-        const int f = s_face;
+        const int f = __builtin_amdgcn_readfirstlane(s_face);
         if (f < 0) break;
         // the sector lives in LDS and is read where it is needed: held in registers through the whole decision it
         // pushed the kernel from 138 to 219 vector registers and into scratch memory
@@ -1347,25 +1539,73 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
             m = s_mt;
             ord = tlist;
         }
+        m = __builtin_amdgcn_readfirstlane(m);
         int n_canvas = 0;
-        bool resident = true;  // wave 0's view; the others read s_resident after the barrier
+        bool resident = true;  // kept alike by every wave
         int n_cs = 0, used = 0;
 #ifdef RT_VIS_STAMPS
         unsigned long long acc_setup = 0, acc_decide = 0, acc_tail = 0;
+        const unsigned long long t_item = wall_clock64();
 #endif
+        // A candidate's record is three dependent reads away (its index in the order, its box and vertex range, its
+        // mapped vertices), and a face's candidates are decided one after the other: read on demand, that latency was
+        // most of the time of the nine candidates in ten that the first shortcut settles.  So the reads run ahead, in
+        // vector registers (vector loads stay in flight across LDS traffic; scalar loads share their counter with it):
+        // the order in batches of 64 (lane = place), the record of candidate k + 2 (lanes 0-13 its words, lanes 14/15
+        // its vertex range) and the vertices of candidate k + 1 (lane = coordinate; longer rings are read on demand).
+        int ord_cur = lane < m ? ord[lane] : 0, ord_next = 64 + lane < m ? ord[64 + lane] : 0;
+        int rec0 = 0, rec1 = 0;
+        double xy0 = 0.0;
+        if (m > 0) {
+            const int Bx = __builtin_amdgcn_readlane(ord_cur, 0);
+            rec0 = lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
+            const int v0x = __builtin_amdgcn_readlane(rec0, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec0, 15) - v0x);
+            if (wave == 0 && lane < n2) xy0 = sph_f[(size_t)v0x * 2 + lane];  // candidate 0 is prepared by wave 0
+        }
+        if (m > 1) {
+            const int Bx = __builtin_amdgcn_readlane(ord_cur, 1);
+            rec1 = lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
+        }
         for (int k = 0; k < m; ++k) {
 #ifdef RT_VIS_STAMPS
             const unsigned long long t_a = wall_clock64();
 #endif
-            const int B = ord[k];  // uniform over the workgroup
-            const PolyMeta mb = meta_f[B];
+            if (k != 0 && (k & 63) == 0) {
+                ord_cur = ord_next;
+                ord_next = k + 64 + lane < m ? ord[k + 64 + lane] : 0;
+            }
+            const int B = __builtin_amdgcn_readlane(ord_cur, k & 63);  // uniform over the workgroup
+            PolyMeta mb;
+            {
+                auto word = [&](int i) { return (unsigned long long)(unsigned)__builtin_amdgcn_readlane(rec0, i); };
+                mb.xmin = __longlong_as_double((long long)(word(4) | (word(5) << 32)));
+                mb.xmax = __longlong_as_double((long long)(word(6) | (word(7) << 32)));
+                mb.ymin = __longlong_as_double((long long)(word(8) | (word(9) << 32)));
+                mb.ymax = __longlong_as_double((long long)(word(10) | (word(11) << 32)));
+                mb.sgn = __builtin_amdgcn_readlane(rec0, 13);
+            }
+            const int b_v0 = __builtin_amdgcn_readlane(rec0, 14), b_nv = __builtin_amdgcn_readlane(rec0, 15) - b_v0;
+            const double b_xy = xy0;
+            // the reads that run ahead
+            int rec2 = 0;
+            if (k + 2 < m) {
+                const int idx = k + 2;
+                const int Bx = (idx >> 6) == (k >> 6) ? __builtin_amdgcn_readlane(ord_cur, idx & 63)
+                                                      : __builtin_amdgcn_readlane(ord_next, idx & 63);
+                rec2 = lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
+            }
+            double xy1 = 0.0;
+            if (k + 1 < m && wave == (k + 1) % NW) {
+                const int v0x = __builtin_amdgcn_readlane(rec1, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec1, 15) - v0x);
+                if (lane < n2) xy1 = sph_f[(size_t)v0x * 2 + lane];
+            }
             // what of B can show in this tile lies in B's box cut to the sector: only canvas polygons reaching there matter
             const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
-            if (wave == 0 && resident) {
-                const int v0 = sc.vert_off[B], nvb = sc.vert_off[B + 1] - v0;
-                if (n_cs >= Store::max_poly - 1 || used + 2 * nvb > Store::max_coord) resident = false;
-            }
-            if (wave == 0 && resident) {
+            // the candidates take turns in which wave prepares them: the waves of a workgroup sit on different SIMDs,
+            // and with one fixed wave doing it that SIMD had the work of all the compute unit's workgroups
+            const int lead = k % NW;
+            if (resident && (n_cs >= Store::max_poly - 1 || used + 2 * b_nv > Store::max_coord)) resident = false;
+            if (wave == lead && resident) {
                 // ---- resident canvas: list the slots whose box meets B's box, stage B in the free slot
                 int n_list = 0;
                 for (int base = 0; base < n_cs; base += 64) {
@@ -1379,9 +1619,10 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                     if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = ci;
                     n_list += __popcll(mk);
                 }
-                const int v0 = sc.vert_off[B], nvb = sc.vert_off[B + 1] - v0;
-                const double *src = sph_f + (size_t)v0 * 2;
-                for (int q = lane; q < 2 * nvb; q += 64) cs->xy[used + q] = src[q];
+                const int nvb = b_nv;
+                const double *src = sph_f + (size_t)b_v0 * 2;
+                if (lane < 2 * nvb) cs->xy[used + lane] = b_xy;
+                for (int q = 64 + lane; q < 2 * nvb; q += 64) cs->xy[used + q] = src[q];
                 // running vertex count over the set: the candidate first, then the listed slots
                 {
                     int total = nvb;
@@ -1425,9 +1666,14 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                 if (n_list > 0) {
                     CanvasSet<Store> mine{cs, n_cs, n_list + 1};
                     inside_one = inside_one_entry(mine);
+                    // what that leaves is mostly hidden by two walls that meet in a corner of a building
+                    if (!inside_one && inside_two_entries(mine)) {
+                        inside_one = true;
+                        if (lane == 0) VIS_STAT(3, 1);
+                    }
                 }
                 if (lane == 0) s_inside_one = inside_one ? 1 : 0;
-            } else if (wave == 0) {
+            } else if (wave == lead) {
                 if (lane == 0) s_resident = 0;
                 // ---- canvas polygons whose box meets B's box
                 int n_list = 0;
@@ -1534,11 +1780,14 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
                     __threadfence_block();
                 }
                 ++n_canvas;
-                if (wave == 0 && resident) {  // the staged candidate keeps its slot
-                    used += 2 * (sc.vert_off[B + 1] - sc.vert_off[B]);
+                if (resident) {  // the staged candidate keeps its slot
+                    used += 2 * b_nv;
                     ++n_cs;
                 }
             }
+            rec0 = rec1;
+            rec1 = rec2;
+            xy0 = xy1;
             __syncthreads();  // canvas / LDS store are rewritten for the next candidate
 #ifdef RT_VIS_STAMPS
             acc_setup += t_b - t_a;
@@ -1548,6 +1797,11 @@ __global__ __launch_bounds__(64 * NW) void k_vis_paint(SceneView sc, FaceBatch f
         }
 #ifdef RT_VIS_STAMPS
         if (threadIdx.x == 0) {
+            const unsigned long long t_end = wall_clock64();
+            atomicAdd(&g_vis_phase[12], t_end - t_item);
+            atomicMax(&g_vis_phase[13], t_end - t_item);
+            atomicMax(&g_vis_phase[14], t_end);
+            atomicMin(&g_vis_phase[15], t_item);
             atomicAdd(&g_vis_stats[0], acc_setup);
             atomicAdd(&g_vis_stats[1], acc_decide);
             atomicAdd(&g_vis_stats[2], acc_tail);
