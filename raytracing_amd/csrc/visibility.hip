@@ -526,8 +526,9 @@ template <int CS_MAX_POLY, int CS_MAX_COORD>
 struct CanvasStore {
     static constexpr int max_poly = CS_MAX_POLY, max_coord = CS_MAX_COORD;  // coordinates in doubles
     int nvs[CS_MAX_POLY], offs[CS_MAX_POLY], sgns[CS_MAX_POLY];
-    int list[CS_MAX_POLY];  // slots listed for the current candidate
-    int lpre[CS_MAX_POLY + 1];  // vertices before entry i of the current set (entry 0 = the candidate, then the listed)
+    // a list of any length, for the candidate that is decided on its own (the waves' own lists are short):
+    uint16_t list[CS_MAX_POLY];      // slots listed for the candidate
+    uint16_t lpre[CS_MAX_POLY + 2];  // vertices before entry i of the set (entry 0 = the candidate, then the listed)
     double boxes[CS_MAX_POLY * 4];
     double xy[CS_MAX_COORD];
 };
@@ -538,19 +539,20 @@ struct CanvasSet {
     // the vertices of all entries are numbered through lpre, so that a loop over every ring edge of every entry can
     // give each lane one edge (a roof has tens of vertices: one lane walking its ring is the slow way)
     static constexpr bool flat = true;
-    __device__ int total_vertices() const { return st->lpre[n]; }
+    __device__ int total_vertices() const { return lpre[n]; }
     __device__ void locate(int e, int &i, int &v) const {
         int lo = 0, hi = n - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (st->lpre[mid] <= e) lo = mid; else hi = mid - 1;
+            if (lpre[mid] <= e) lo = mid; else hi = mid - 1;
         }
         i = lo;
-        v = e - st->lpre[lo];
+        v = e - lpre[lo];
     }
     const Store *st;
+    const uint16_t *list, *lpre;  // the listed slots and the running vertex count (n + 1 values)
     int b_slot, n;
-    __device__ int slot(int i) const { return i == 0 ? b_slot : st->list[i - 1]; }
+    __device__ int slot(int i) const { return i == 0 ? b_slot : list[i - 1]; }
     __device__ int count() const { return n; }
     __device__ int nv(int i) const { return st->nvs[slot(i)]; }
     __device__ const double *x(int i) const { return st->xy + st->offs[slot(i)]; }
@@ -1429,6 +1431,79 @@ __global__ __launch_bounds__(1024) void k_vis_item_offsets(const int32_t *__rest
     if (threadIdx.x == 0) item_off[n_faces] = carry;
 }
 
+// ---- pieces of the painter's resident path, each run by one wave
+#define VIS_WAVE_LIST 96 /* listed canvas polygons a wave's own list holds; a longer list is decided with the store's */
+
+// running vertex count over a set: the candidate (nvb vertices) first, then the listed slots
+template <typename Store>
+__device__ inline void canvas_prefix(const Store *cs, const uint16_t *list, int n_list, int nvb, uint16_t *lpre) {
+    const int lane = threadIdx.x & 63;
+    int total = nvb;
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < n_list; base += 64) {
+        const int li = base + lane;
+        const int cnt = li < n_list ? cs->nvs[list[li]] : 0;
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (li < n_list) lpre[li + 1] = (uint16_t)(total + incl - cnt);
+        total += __shfl(incl, 63);
+    }
+    if (lane == 0) {
+        lpre[0] = 0;
+        lpre[n_list + 1] = (uint16_t)total;
+    }
+}
+
+// the ring staged in slot `from` becomes slot `to` with its vertices at `to_off`: never further up than it is, so the
+// copy goes upwards in steps of a wave, each step read before it is written
+template <typename Store>
+__device__ inline void move_staged(Store *cs, int from, int to, int to_off) {
+    const int lane = threadIdx.x & 63;
+    const int from_off = cs->offs[from], n2 = 2 * cs->nvs[from];
+    if (from == to && from_off == to_off) return;
+    if (from_off != to_off)
+        for (int base = 0; base < n2; base += 64) {
+            const int q = base + lane;
+            const double v = q < n2 ? cs->xy[from_off + q] : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            if (q < n2) cs->xy[to_off + q] = v;
+            __builtin_amdgcn_wave_barrier();
+        }
+    const int nv = cs->nvs[from], sg = cs->sgns[from];
+    const double bx = lane < 4 ? cs->boxes[4 * from + lane] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 4) cs->boxes[4 * to + lane] = bx;
+    if (lane == 0) {
+        cs->nvs[to] = nv;
+        cs->offs[to] = to_off;
+        cs->sgns[to] = sg;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// one wave tries the shortcuts on the candidate staged in slot b_slot against the listed slots: 0 = hidden, 1 = shows,
+// VIS_UNSETTLED = neither shortcut says
+#define VIS_UNSETTLED 2
+template <typename Store>
+__device__ __forceinline__ int shortcuts_alone(const Store *cs, const uint16_t *list, const uint16_t *lpre, int b_slot,
+                                               int n_list, const TileSpan &span) {
+    // nothing of the canvas near it: it shows (a valid ring has area); in a tile it still has to be shown that it
+    // reaches into the sector at all (its box does, its ring may not)
+    if (n_list == 0) return span.bounded() ? VIS_UNSETTLED : 1;
+    const CanvasSet<Store> set{cs, list, lpre, b_slot, n_list + 1};
+    // inside one canvas polygon settles nine candidates in ten; inside two convex ones most of the rest (two walls
+    // that meet in a corner of a building)
+    if (inside_one_entry(set)) return 0;
+    if (inside_two_entries(set)) {
+        if ((threadIdx.x & 63) == 0) VIS_STAT(3, 1);
+        return 0;
+    }
+    return VIS_UNSETTLED;
+}
+
 // One workgroup (NW waves: four when many faces are painted at once, sixteen for a handful) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
 // polygons whose box meets it and stages them in LDS; all waves then decide coverage together.
 template <typename Store, int NW>
@@ -1447,11 +1522,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
         LocalStore staged;   // used once the face's canvas no longer fits the resident store
         Store canvas;        // used until then
     } stores;
-    __shared__ int s_resident, s_ncs;
+    __shared__ uint16_t s_wlist[NW][VIS_WAVE_LIST], s_wlpre[NW][VIS_WAVE_LIST + 2];  // each wave's own list
+    __shared__ int s_gnv[NW], s_gB[NW], s_verdict[NW], s_again[NW];  // the group: coordinates staged, polygon, verdict
     __shared__ double lds_splits[NW][SPLIT_LDS];
     __shared__ double lds_px[NW][PIECE_LDS], lds_py[NW][PIECE_LDS];
     __shared__ int lds_pstate[NW][PIECE_LDS];
-    __shared__ int s_face, s_nlist, s_fits, s_flag, s_inside_one;
+    __shared__ int s_face, s_nlist, s_fits, s_flag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LocalStore *store = &stores.staged;
     Store *cs = &stores.canvas;
@@ -1541,140 +1617,210 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
         }
         m = __builtin_amdgcn_readfirstlane(m);
         int n_canvas = 0;
-        bool resident = true;  // kept alike by every wave
         int n_cs = 0, used = 0;
 #ifdef RT_VIS_STAMPS
-        unsigned long long acc_setup = 0, acc_decide = 0, acc_tail = 0;
         const unsigned long long t_item = wall_clock64();
 #endif
+        // ---- While the canvas fits the resident store: NW candidates at a time, one per wave.  Each wave decides its
+        // candidate alone against the canvas as it stood BEFORE the group.  That canvas is part of the canvas the
+        // candidate really has to be held against (which also has the group's earlier members that show), and hidden
+        // behind a part is hidden behind the whole: a "hidden" stands, and so does a "shows" when no earlier member of
+        // the group showed.  Only a "shows" after another "shows" in the same group is decided again (one candidate
+        // in sixty shows, so that is rare).  A workgroup used to decide one candidate at a time, and for nine in ten
+        // one wave did all of it while the others waited: a wave issues one instruction every four or five cycles at
+        // best, and that was the painter's speed.
+        //
         // A candidate's record is three dependent reads away (its index in the order, its box and vertex range, its
-        // mapped vertices), and a face's candidates are decided one after the other: read on demand, that latency was
-        // most of the time of the nine candidates in ten that the first shortcut settles.  So the reads run ahead, in
-        // vector registers (vector loads stay in flight across LDS traffic; scalar loads share their counter with it):
-        // the order in batches of 64 (lane = place), the record of candidate k + 2 (lanes 0-13 its words, lanes 14/15
-        // its vertex range) and the vertices of candidate k + 1 (lane = coordinate; longer rings are read on demand).
-        int ord_cur = lane < m ? ord[lane] : 0, ord_next = 64 + lane < m ? ord[64 + lane] : 0;
-        int rec0 = 0, rec1 = 0;
-        double xy0 = 0.0;
-        if (m > 0) {
-            const int Bx = __builtin_amdgcn_readlane(ord_cur, 0);
-            rec0 = lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
-            const int v0x = __builtin_amdgcn_readlane(rec0, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec0, 15) - v0x);
-            if (wave == 0 && lane < n2) xy0 = sph_f[(size_t)v0x * 2 + lane];  // candidate 0 is prepared by wave 0
-        }
-        if (m > 1) {
-            const int Bx = __builtin_amdgcn_readlane(ord_cur, 1);
-            rec1 = lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
-        }
-        for (int k = 0; k < m; ++k) {
-#ifdef RT_VIS_STAMPS
-            const unsigned long long t_a = wall_clock64();
-#endif
-            if (k != 0 && (k & 63) == 0) {
-                ord_cur = ord_next;
-                ord_next = k + 64 + lane < m ? ord[k + 64 + lane] : 0;
+        // mapped vertices).  The reads run ahead, in vector registers (vector loads stay in flight across LDS
+        // traffic; scalar loads share their counter with it): the order in batches of 64 (lane = place), the record
+        // of the wave's candidate two groups on (lanes 0-13 its words, lanes 14/15 its vertex range) and the vertices
+        // of its candidate of the next group (lane = coordinate; longer rings are read when they are staged).
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        int k = 0;
+        {
+            int ord_cur = lane < m ? ord[lane] : 0, ord_next = 64 + lane < m ? ord[64 + lane] : 0;
+            auto place = [&](int idx, int from) -> int {  // candidate at place idx (uniform), seen from group `from`
+                return (idx >> 6) == (from >> 6) ? __builtin_amdgcn_readlane(ord_cur, idx & 63)
+                                                 : __builtin_amdgcn_readlane(ord_next, idx & 63);
+            };
+            auto record = [&](int Bx) -> int {
+                return lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
+            };
+            int rec0 = 0, rec1 = 0;
+            double xy0 = 0.0;
+            if (wave_u < m) {
+                rec0 = record(place(wave_u, 0));
+                const int v0x = __builtin_amdgcn_readlane(rec0, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec0, 15) - v0x);
+                if (lane < n2) xy0 = sph_f[(size_t)v0x * 2 + lane];
             }
-            const int B = __builtin_amdgcn_readlane(ord_cur, k & 63);  // uniform over the workgroup
-            PolyMeta mb;
-            {
-                auto word = [&](int i) { return (unsigned long long)(unsigned)__builtin_amdgcn_readlane(rec0, i); };
-                mb.xmin = __longlong_as_double((long long)(word(4) | (word(5) << 32)));
-                mb.xmax = __longlong_as_double((long long)(word(6) | (word(7) << 32)));
-                mb.ymin = __longlong_as_double((long long)(word(8) | (word(9) << 32)));
-                mb.ymax = __longlong_as_double((long long)(word(10) | (word(11) << 32)));
-                mb.sgn = __builtin_amdgcn_readlane(rec0, 13);
-            }
-            const int b_v0 = __builtin_amdgcn_readlane(rec0, 14), b_nv = __builtin_amdgcn_readlane(rec0, 15) - b_v0;
-            const double b_xy = xy0;
-            // the reads that run ahead
-            int rec2 = 0;
-            if (k + 2 < m) {
-                const int idx = k + 2;
-                const int Bx = (idx >> 6) == (k >> 6) ? __builtin_amdgcn_readlane(ord_cur, idx & 63)
-                                                      : __builtin_amdgcn_readlane(ord_next, idx & 63);
-                rec2 = lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
-            }
-            double xy1 = 0.0;
-            if (k + 1 < m && wave == (k + 1) % NW) {
-                const int v0x = __builtin_amdgcn_readlane(rec1, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec1, 15) - v0x);
-                if (lane < n2) xy1 = sph_f[(size_t)v0x * 2 + lane];
-            }
-            // what of B can show in this tile lies in B's box cut to the sector: only canvas polygons reaching there matter
-            const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
-            // the candidates take turns in which wave prepares them: the waves of a workgroup sit on different SIMDs,
-            // and with one fixed wave doing it that SIMD had the work of all the compute unit's workgroups
-            const int lead = k % NW;
-            if (resident && (n_cs >= Store::max_poly - 1 || used + 2 * b_nv > Store::max_coord)) resident = false;
-            if (wave == lead && resident) {
-                // ---- resident canvas: list the slots whose box meets B's box, stage B in the free slot
-                int n_list = 0;
-                for (int base = 0; base < n_cs; base += 64) {
-                    const int ci = base + lane;
-                    bool take = false;
-                    if (ci < n_cs) {
-                        const double *cb = cs->boxes + 4 * ci;
-                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
-                    }
-                    const unsigned long long mk = __ballot(take);
-                    if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = ci;
-                    n_list += __popcll(mk);
+            if (NW + wave_u < m) rec1 = record(place(NW + wave_u, 0));
+            uint16_t *my_list = s_wlist[wave_u], *my_lpre = s_wlpre[wave_u];
+            while (k < m) {
+                if (k != 0 && (k & 63) == 0) {
+                    ord_cur = ord_next;
+                    ord_next = k + 64 + lane < m ? ord[k + 64 + lane] : 0;
                 }
-                const int nvb = b_nv;
-                const double *src = sph_f + (size_t)b_v0 * 2;
-                if (lane < 2 * nvb) cs->xy[used + lane] = b_xy;
-                for (int q = 64 + lane; q < 2 * nvb; q += 64) cs->xy[used + q] = src[q];
-                // running vertex count over the set: the candidate first, then the listed slots
+                const int mine = k + wave_u;
+                const bool have = mine < m;
+                const int B = have ? place(mine, k) : 0;
+                PolyMeta mb;
                 {
-                    int total = nvb;
-                    __builtin_amdgcn_wave_barrier();
-                    for (int base = 0; base < n_list; base += 64) {
-                        const int li = base + lane;
-                        const int cnt = li < n_list ? cs->nvs[cs->list[li]] : 0;
-                        int incl = cnt;
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const int t = __shfl_up(incl, off);
-                            if (lane >= off) incl += t;
-                        }
-                        if (li < n_list) cs->lpre[li + 1] = total + incl - cnt;
-                        total += __shfl(incl, 63);
-                    }
-                    if (lane == 0) {
-                        cs->lpre[0] = 0;
-                        cs->lpre[n_list + 1] = total;
-                    }
+                    auto word = [&](int i) { return (unsigned long long)(unsigned)__builtin_amdgcn_readlane(rec0, i); };
+                    mb.xmin = __longlong_as_double((long long)(word(4) | (word(5) << 32)));
+                    mb.xmax = __longlong_as_double((long long)(word(6) | (word(7) << 32)));
+                    mb.ymin = __longlong_as_double((long long)(word(8) | (word(9) << 32)));
+                    mb.ymax = __longlong_as_double((long long)(word(10) | (word(11) << 32)));
+                    mb.sgn = __builtin_amdgcn_readlane(rec0, 13);
+                }
+                const int b_v0 = __builtin_amdgcn_readlane(rec0, 14);
+                const int nv2 = have ? 2 * (__builtin_amdgcn_readlane(rec0, 15) - b_v0) : 0;
+                const double b_xy = xy0;
+                // the reads that run ahead
+                int rec2 = 0;
+                if (mine + 2 * NW < m) rec2 = record(place(mine + 2 * NW, k));
+                double xy1 = 0.0;
+                if (mine + NW < m) {
+                    const int v0x = __builtin_amdgcn_readlane(rec1, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec1, 15) - v0x);
+                    if (lane < n2) xy1 = sph_f[(size_t)v0x * 2 + lane];
                 }
                 if (lane == 0) {
-                    cs->nvs[n_cs] = nvb;
-                    cs->offs[n_cs] = used;
-                    cs->sgns[n_cs] = mb.sgn;
-                    cs->boxes[4 * n_cs] = mb.xmin;
-                    cs->boxes[4 * n_cs + 1] = mb.xmax;
-                    cs->boxes[4 * n_cs + 2] = mb.ymin;
-                    cs->boxes[4 * n_cs + 3] = mb.ymax;
-                    s_nlist = n_list;
-                    s_fits = 1;
-                    s_flag = 0;
-                    s_resident = 1;
-                    s_ncs = n_cs;
-                    VIS_STAT(0, 1);
-                    VIS_STAT(1, n_list);
+                    s_gnv[wave_u] = nv2;
+                    s_gB[wave_u] = B;
                 }
-                // the shortcut that settles most candidates, by this wave alone while the others wait at the barrier
-                // (they used to repeat it, taking issue slots from the other workgroups of the compute unit)
-                __builtin_amdgcn_wave_barrier();
-                bool inside_one = false;
-                if (n_list > 0) {
-                    CanvasSet<Store> mine{cs, n_cs, n_list + 1};
-                    inside_one = inside_one_entry(mine);
-                    // what that leaves is mostly hidden by two walls that meet in a corner of a building
-                    if (!inside_one && inside_two_entries(mine)) {
-                        inside_one = true;
-                        if (lane == 0) VIS_STAT(3, 1);
+                __syncthreads();
+                int before = 0, total = 0;  // coordinates the group's earlier members / all its members stage
+                for (int w = 0; w < NW; ++w) {
+                    const int c = s_gnv[w];
+                    if (w < wave_u) before += c;
+                    total += c;
+                }
+                if (n_cs + NW > Store::max_poly || used + total > Store::max_coord) {
+                    break;  // the same in every wave: the rest of the face goes the slow way
+                }
+                const int slot_b = n_cs + wave_u, at_b = used + before;
+                int verdict = 0;  // 0 hidden, 1 shows, or unsettled
+                if (have) {
+                    // what of B can show in this tile lies in B's box cut to the sector: only canvas polygons reaching
+                    // there matter
+                    const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+                    int n_list = 0;
+                    for (int base = 0; base < n_cs; base += 64) {
+                        const int ci = base + lane;
+                        bool take = false;
+                        if (ci < n_cs) {
+                            const double *cb = cs->boxes + 4 * ci;
+                            take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                        }
+                        const unsigned long long mk = __ballot(take);
+                        const int at = n_list + __popcll(mk & ((1ull << lane) - 1));
+                        if (take && at < VIS_WAVE_LIST) my_list[at] = (uint16_t)ci;
+                        n_list += __popcll(mk);
+                    }
+                    const double *src = sph_f + (size_t)b_v0 * 2;
+                    if (lane < nv2) cs->xy[at_b + lane] = b_xy;
+                    for (int q = 64 + lane; q < nv2; q += 64) cs->xy[at_b + q] = src[q];
+                    if (lane == 0) {
+                        cs->nvs[slot_b] = nv2 / 2;
+                        cs->offs[slot_b] = at_b;
+                        cs->sgns[slot_b] = mb.sgn;
+                        cs->boxes[4 * slot_b] = mb.xmin;
+                        cs->boxes[4 * slot_b + 1] = mb.xmax;
+                        cs->boxes[4 * slot_b + 2] = mb.ymin;
+                        cs->boxes[4 * slot_b + 3] = mb.ymax;
+                        VIS_STAT(0, 1);
+                        VIS_STAT(1, n_list);
+                    }
+                    if (n_list > VIS_WAVE_LIST) {
+                        verdict = VIS_UNSETTLED;
+                    } else {
+                        canvas_prefix(cs, my_list, n_list, nv2 / 2, my_lpre);
+                        __builtin_amdgcn_wave_barrier();
+                        verdict = shortcuts_alone(cs, my_list, my_lpre, slot_b, n_list, span);
                     }
                 }
-                if (lane == 0) s_inside_one = inside_one ? 1 : 0;
-            } else if (wave == lead) {
-                if (lane == 0) s_resident = 0;
+                if (lane == 0) s_verdict[wave_u] = verdict;
+                __syncthreads();
+                // ---- the group's verdicts in order
+                int shown = 0;
+                for (int j = 0; j < NW && k + j < m; ++j) {
+                    int v = s_verdict[j];
+                    const int nv2_j = s_gnv[j];
+                    bool in_place = false;
+                    if (v == VIS_UNSETTLED || (v == 1 && shown > 0)) {
+                        // the full decision, by all waves together, against the canvas as it is now: its wave moves it
+                        // to the canvas's next slot and lists again (any length; the shortcuts again only if the
+                        // canvas has grown since they were tried)
+                        if (wave_u == j) {
+                            move_staged(cs, slot_b, n_cs, used);
+                            int n_list = 0;
+                            const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+                            for (int base = 0; base < n_cs; base += 64) {
+                                const int ci = base + lane;
+                                bool take = false;
+                                if (ci < n_cs) {
+                                    const double *cb = cs->boxes + 4 * ci;
+                                    take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                                }
+                                const unsigned long long mk = __ballot(take);
+                                if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = (uint16_t)ci;
+                                n_list += __popcll(mk);
+                            }
+                            canvas_prefix(cs, cs->list, n_list, nv2 / 2, cs->lpre);
+                            __builtin_amdgcn_wave_barrier();
+                            int again = VIS_UNSETTLED;
+                            if (shown > 0 || v != VIS_UNSETTLED || n_list > VIS_WAVE_LIST)
+                                again = shortcuts_alone(cs, cs->list, cs->lpre, n_cs, n_list, span);
+                            if (lane == 0) {
+                                // (slots of their own: a wave that is late may still be reading the first verdict,
+                                // and every wave has to take the same way through the barriers)
+                                s_again[j] = again;
+                                s_nlist = n_list;
+                                s_flag = 0;
+                            }
+                        }
+                        __syncthreads();
+                        v = s_again[j];
+                        if (v == VIS_UNSETTLED) {
+                            const CanvasSet<Store> cv{cs, cs->list, cs->lpre, n_cs, s_nlist + 1};
+                            v = polygon_uncovered(cv, splits, lds_count, work, &s_flag, span, true) ? 1 : 0;
+                            __syncthreads();  // the flag and the list are the next unsettled candidate's after this
+                        }
+                        in_place = true;
+                    }
+                    if (v == 1) {
+                        if (wave_u == j && !in_place) move_staged(cs, slot_b, n_cs, used);
+                        __syncthreads();  // the moved ring is part of the canvas for what comes after
+                        if (threadIdx.x == 0) {
+                            const int Bj = s_gB[j];
+                            VIS_STAT(5, 1);
+                            canvas[n_canvas] = Bj;  // (kept in global memory too, for a face that outgrows the store)
+                            double *cb = cbox + 4 * (size_t)n_canvas;
+                            const double *bb = cs->boxes + 4 * n_cs;
+                            cb[0] = bb[0]; cb[1] = bb[1]; cb[2] = bb[2]; cb[3] = bb[3];
+                            if (faces_viewer(sc, fb, f, Bj)) out_f[Bj] = 1;
+                            __threadfence_block();
+                        }
+                        ++n_cs;
+                        used += nv2_j;
+                        ++n_canvas;
+                        ++shown;
+                    }
+                }
+                rec0 = rec1;
+                rec1 = rec2;
+                xy0 = xy1;
+                k += NW;
+                __syncthreads();  // the staging slots and the verdicts are rewritten by the next group
+            }
+        }
+        __threadfence_block();
+        // ---- what is left once the canvas has outgrown the resident store: one candidate at a time, all waves
+        // together, the canvas read from global memory (staged in LDS per candidate when it fits)
+        for (; k < m; ++k) {
+            const int B = ord[k];  // uniform over the workgroup
+            const PolyMeta mb = meta_f[B];
+            const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+            if (wave == 0) {
                 // ---- canvas polygons whose box meets B's box
                 int n_list = 0;
                 for (int base = 0; base < n_canvas; base += 64) {
@@ -1747,19 +1893,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                 }
             }
             __syncthreads();
-#ifdef RT_VIS_STAMPS
-            const unsigned long long t_b = wall_clock64();
-#endif
             const int n_list = s_nlist;
             // nothing of the canvas near B: B shows (a valid ring has area); in a tile it still has to be shown that B
             // reaches into the sector at all (its box does, its ring may not)
             bool visible = n_list == 0 && !span.bounded();
-            const bool res_now = s_resident != 0;
             if (!visible) {
-                if (res_now) {
-                    CanvasSet<Store> cv{cs, s_ncs, n_list + 1};
-                    visible = !s_inside_one && polygon_uncovered(cv, splits, lds_count, work, &s_flag, span, true);
-                } else if (s_fits) {
+                if (s_fits) {
                     LocalSet ls{store, n_list + 1};
                     visible = polygon_uncovered(ls, splits, lds_count, work, &s_flag, span, false);
                 } else {
@@ -1767,9 +1906,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     visible = polygon_uncovered(gs, splits, lds_count, work, &s_flag, span, false);
                 }
             }
-#ifdef RT_VIS_STAMPS
-            const unsigned long long t_c = wall_clock64();
-#endif
             if (visible) {
                 if (threadIdx.x == 0) {
                     VIS_STAT(5, 1);
@@ -1780,20 +1916,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     __threadfence_block();
                 }
                 ++n_canvas;
-                if (resident) {  // the staged candidate keeps its slot
-                    used += 2 * b_nv;
-                    ++n_cs;
-                }
             }
-            rec0 = rec1;
-            rec1 = rec2;
-            xy0 = xy1;
             __syncthreads();  // canvas / LDS store are rewritten for the next candidate
-#ifdef RT_VIS_STAMPS
-            acc_setup += t_b - t_a;
-            acc_decide += t_c - t_b;
-            acc_tail += wall_clock64() - t_c;
-#endif
         }
 #ifdef RT_VIS_STAMPS
         if (threadIdx.x == 0) {
@@ -1802,9 +1926,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
             atomicMax(&g_vis_phase[13], t_end - t_item);
             atomicMax(&g_vis_phase[14], t_end);
             atomicMin(&g_vis_phase[15], t_item);
-            atomicAdd(&g_vis_stats[0], acc_setup);
-            atomicAdd(&g_vis_stats[1], acc_decide);
-            atomicAdd(&g_vis_stats[2], acc_tail);
             atomicAdd(&g_vis_stats[3], (unsigned long long)m);
             atomicAdd(&g_vis_stats[4], (unsigned long long)n_canvas);
         }
