@@ -1226,22 +1226,39 @@ __device__ inline bool order_less(const PolyMeta *meta_f, int a, int b) {
 // one workgroup per face: candidates (valid rings in front of the face) sorted by the painter's key.  Up to
 // VIS_SORT_LDS candidates the keys are brought into LDS once and the bitonic network runs there (a compare used to read
 // two 64-byte records from global memory); a face with more candidates sorts through global memory as before.
-#define VIS_SORT_LDS 4096
+#define VIS_SORT_LDS 8192
 #define VIS_SORT_THREADS 1024
 __global__ __launch_bounds__(VIS_SORT_THREADS) void k_vis_sort(int n, const PolyMeta *__restrict__ meta,
                                                                int32_t *__restrict__ order, int m_stride,
                                                                int32_t *__restrict__ counts) {
     __shared__ int cnt;
-    __shared__ double s_k1[VIS_SORT_LDS], s_k2[VIS_SORT_LDS];
+    __shared__ double s_k1[VIS_SORT_LDS];  // the second key is read from the records, on a tie of the first only
     __shared__ int32_t s_id[VIS_SORT_LDS];
     const int f = blockIdx.x, tid = threadIdx.x;
     const PolyMeta *meta_f = meta + (size_t)f * n;
     int32_t *ord = order + (size_t)f * m_stride;
+    // the candidates, in scene order: a wave's lanes count themselves with a ballot and the wave takes its places with
+    // one addition (one addition per candidate on one LDS word took longer than the sort)
+    __shared__ int s_wave_cnt[VIS_SORT_THREADS / 64];
     if (tid == 0) cnt = 0;
     __syncthreads();
-    for (int b = tid; b < n; b += VIS_SORT_THREADS)
-        if (meta_f[b].state == 2) ord[atomicAdd(&cnt, 1)] = b;
-    __syncthreads();
+    for (int base = 0; base < n; base += VIS_SORT_THREADS) {
+        const int b = base + tid;
+        const bool take = b < n && meta_f[b].state == 2;
+        const unsigned long long mk = __ballot(take);
+        if ((tid & 63) == 0) s_wave_cnt[tid >> 6] = __popcll(mk);
+        __syncthreads();
+        int at = cnt + __popcll(mk & ((1ull << (tid & 63)) - 1));
+        for (int w = 0; w < (tid >> 6); ++w) at += s_wave_cnt[w];
+        if (take) ord[at] = b;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < VIS_SORT_THREADS / 64; ++w) tot += s_wave_cnt[w];
+            cnt += tot;
+        }
+        __syncthreads();
+    }
     const int m = cnt;
     int m_pad = 1;
     while (m_pad < m) m_pad <<= 1;
@@ -1251,7 +1268,6 @@ __global__ __launch_bounds__(VIS_SORT_THREADS) void k_vis_sort(int n, const Poly
             const int b = i < m ? ord[i] : -1;
             s_id[i] = b;
             s_k1[i] = b >= 0 ? meta_f[b].key1 : INFINITY;
-            s_k2[i] = b >= 0 ? meta_f[b].key2 : INFINITY;
         }
         __syncthreads();
         auto less = [&](int i, int l) {  // entry i before entry l?
@@ -1259,7 +1275,8 @@ __global__ __launch_bounds__(VIS_SORT_THREADS) void k_vis_sort(int n, const Poly
             if (a < 0) return false;
             if (b < 0) return true;
             if (s_k1[i] != s_k1[l]) return s_k1[i] < s_k1[l];
-            if (s_k2[i] != s_k2[l]) return s_k2[i] < s_k2[l];
+            const double a2 = meta_f[a].key2, b2 = meta_f[b].key2;
+            if (a2 != b2) return a2 < b2;
             return a < b;
         };
         for (int k = 2; k <= m_pad; k <<= 1) {
@@ -1270,9 +1287,9 @@ __global__ __launch_bounds__(VIS_SORT_THREADS) void k_vis_sort(int n, const Poly
                         const bool up = (i & k) == 0;
                         if (up ? less(l, i) : less(i, l)) {
                             const int ti = s_id[i];
-                            const double t1 = s_k1[i], t2 = s_k2[i];
-                            s_id[i] = s_id[l]; s_k1[i] = s_k1[l]; s_k2[i] = s_k2[l];
-                            s_id[l] = ti; s_k1[l] = t1; s_k2[l] = t2;
+                            const double t1 = s_k1[i];
+                            s_id[i] = s_id[l]; s_k1[i] = s_k1[l];
+                            s_id[l] = ti; s_k1[l] = t1;
                         }
                     }
                 }
