@@ -663,7 +663,11 @@ struct SplitBuf {
 // proves B visible.
 template <typename Set>
 __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay, double bx, double by, double side,
-                                 bool need_in_b, const SplitBuf &splits, int *lds_count, const TileSpan &tile) {
+                                 bool need_in_b, const SplitBuf &splits, int *lds_count, const TileSpan &tile,
+                                 double t_lo = 0.0, double t_hi = 1.0) {
+    // (t_lo, t_hi): the part of the edge that is examined.  An edge of a canvas polygon is often many times as long
+    // as B is wide, and a witness has to be inside B: only the part inside B's box is cut into pieces, and only the
+    // entries that reach that part are looked at.
     const int lane = threadIdx.x & 63;
     const double ex = bx - ax, ey = by - ay;
     const double len = sqrt(ex * ex + ey * ey);
@@ -671,17 +675,19 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
     // ---- gather the cuts: lanes = entries, each walks its own ring
     if (lane == 0) {
         int k = 1;
-        splits.put(0, 0.0);
+        splits.put(0, t_lo);
         // the tile's borders cut the edge too (a piece must not straddle a border: its witness stands for all of it)
         if (ex != 0.0) {
             const double ta = (tile.x0 - ax) / ex, tb = (tile.x1 - ax) / ex;
-            if (ta > 0.0 && ta < 1.0) splits.put(k++, ta);
-            if (tb > 0.0 && tb < 1.0) splits.put(k++, tb);
+            if (ta > t_lo && ta < t_hi) splits.put(k++, ta);
+            if (tb > t_lo && tb < t_hi) splits.put(k++, tb);
         }
         *lds_count = k;
     }
     __builtin_amdgcn_wave_barrier();
     const int n = ps.count();
+    // the examined part's own ends and box
+    const double pax = ax + t_lo * ex, pay = ay + t_lo * ey, pbx = ax + t_hi * ex, pby = ay + t_hi * ey;
     if (Set::flat) {
         // lanes = ring edges of all entries
         const int tv = ps.total_vertices();
@@ -693,14 +699,18 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
             if (li == owner) continue;
             double x0, x1, y0, y1;
             ps.box(li, x0, x1, y0, y1);
-            const bool near = !(x1 < fmin(ax, bx) - VIS_ON_LINE || x0 > fmax(ax, bx) + VIS_ON_LINE ||
-                                y1 < fmin(ay, by) - VIS_ON_LINE || y0 > fmax(ay, by) + VIS_ON_LINE);
+            const bool near = !(x1 < fmin(pax, pbx) - VIS_ON_LINE || x0 > fmax(pax, pbx) + VIS_ON_LINE ||
+                                y1 < fmin(pay, pby) - VIS_ON_LINE || y0 > fmax(pay, pby) + VIS_ON_LINE);
             if (!near) continue;
             const int nv = ps.nv(li);
             const double *x = ps.x(li), *y = ps.y(li);
             const int u = v == 0 ? nv - 1 : v - 1;
             double t[3];
-            const int k = edge_cuts(ax, ay, bx, by, x[u], y[u], x[v], y[v], t);
+            int k = edge_cuts(ax, ay, bx, by, x[u], y[u], x[v], y[v], t);
+            int kept = 0;
+            for (int q = 0; q < k; ++q)
+                if (t[q] > t_lo && t[q] < t_hi) t[kept++] = t[q];
+            k = kept;
             if (k > 0) {
                 const int slot = atomicAdd(lds_count, k);
                 for (int q = 0; q < k; ++q) splits.put(slot + q, t[q]);
@@ -713,8 +723,8 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
             double x0, x1, y0, y1;
             ps.box(li, x0, x1, y0, y1);
             // the other ring can only cut this edge where their boxes meet
-            const bool near = !(x1 < fmin(ax, bx) - VIS_ON_LINE || x0 > fmax(ax, bx) + VIS_ON_LINE ||
-                                y1 < fmin(ay, by) - VIS_ON_LINE || y0 > fmax(ay, by) + VIS_ON_LINE);
+            const bool near = !(x1 < fmin(pax, pbx) - VIS_ON_LINE || x0 > fmax(pax, pbx) + VIS_ON_LINE ||
+                                y1 < fmin(pay, pby) - VIS_ON_LINE || y0 > fmax(pay, pby) + VIS_ON_LINE);
             if (near) {
                 const int nv = ps.nv(li);
                 const double *x = ps.x(li), *y = ps.y(li);
@@ -722,7 +732,11 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
                 for (int v = 0; v < nv; ++v) {
                     const double dx = x[v], dy = y[v];
                     double t[3];
-                    const int k = edge_cuts(ax, ay, bx, by, cx, cy, dx, dy, t);
+                    int k = edge_cuts(ax, ay, bx, by, cx, cy, dx, dy, t);
+                    int kept = 0;
+                    for (int q = 0; q < k; ++q)
+                        if (t[q] > t_lo && t[q] < t_hi) t[kept++] = t[q];
+                    k = kept;
                     if (k > 0) {
                         const int slot = atomicAdd(lds_count, k);
                         for (int q = 0; q < k; ++q) splits.put(slot + q, t[q]);
@@ -748,7 +762,7 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
         // instead of one lane walking every entry.
         if (lane < n_splits) {
             const double t0 = splits.get(lane);
-            double t1 = 1.0;
+            double t1 = t_hi;
             for (int i = 0; i < n_splits; ++i) {
                 const double ti = splits.get(i);
                 if (ti > t0 && ti < t1) t1 = ti;
@@ -767,8 +781,8 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
         const int near_cap = (SPLIT_LDS - PIECE_LDS) * 2;
         int n_near = 0;
         {
-            const double e_x0 = fmin(ax, bx) - 2 * VIS_DELTA, e_x1 = fmax(ax, bx) + 2 * VIS_DELTA;
-            const double e_y0 = fmin(ay, by) - 2 * VIS_DELTA, e_y1 = fmax(ay, by) + 2 * VIS_DELTA;
+            const double e_x0 = fmin(pax, pbx) - 2 * VIS_DELTA, e_x1 = fmax(pax, pbx) + 2 * VIS_DELTA;
+            const double e_y0 = fmin(pay, pby) - 2 * VIS_DELTA, e_y1 = fmax(pay, pby) + 2 * VIS_DELTA;
             for (int base = first; base < n; base += 64) {
                 const int li = base + lane;
                 bool reaches = false;
@@ -818,7 +832,7 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
         bool mine = false;
         if (j < n_splits) {
             const double t0 = splits.get(j);
-            double t1 = 1.0;
+            double t1 = t_hi;
             for (int i = 0; i < n_splits; ++i) {
                 const double ti = splits.get(i);
                 if (ti > t0 && ti < t1) t1 = ti;
@@ -1209,7 +1223,29 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
             side = w == n_work ? -1.0 : 1.0;
         }
         if (lane == 0) VIS_STAT(6, 1);
-        if (edge_has_witness(ps, li, ax, ay, ex_, ey_, side, true, splits, lds_count, tile) && lane == 0) *flag = 1;
+        // the part of the edge inside B's box (a little more), by clipping against the box's four sides
+        double t_lo = 0.0, t_hi = 1.0;
+        {
+            const double dx = ex_ - ax, dy = ey_ - ay, pad = 4 * VIS_ON_LINE;
+            const double lo_x = bx0 - pad, hi_x = bx1 + pad, lo_y = by0 - pad, hi_y = by1 + pad;
+            if (dx != 0.0) {
+                const double ta = (lo_x - ax) / dx, tb = (hi_x - ax) / dx;
+                t_lo = fmax(t_lo, fmin(ta, tb));
+                t_hi = fmin(t_hi, fmax(ta, tb));
+            } else if (ax < lo_x || ax > hi_x) {
+                t_hi = -1.0;
+            }
+            if (dy != 0.0) {
+                const double ta = (lo_y - ay) / dy, tb = (hi_y - ay) / dy;
+                t_lo = fmax(t_lo, fmin(ta, tb));
+                t_hi = fmin(t_hi, fmax(ta, tb));
+            } else if (ay < lo_y || ay > hi_y) {
+                t_hi = -1.0;
+            }
+        }
+        if (!(t_hi > t_lo)) continue;  // it passes B's box by
+        if (edge_has_witness(ps, li, ax, ay, ex_, ey_, side, true, splits, lds_count, tile, t_lo, t_hi) && lane == 0)
+            *flag = 1;
     }
     __syncthreads();
     PHASE(4);
