@@ -277,6 +277,8 @@ def main():
         torch.cuda.synchronize()
 
     # ---- precompute: scene file -> candidates (once per scene and emitter) ----------------------------------------
+    # (the HIP runtime's own first allocation and first launch, ~0.15 s per process, are not the pipeline's: done here)
+    torch.zeros(1, device=dev).add_(1)
     barrier()
     t_wall = time.perf_counter()
     stamps = {}
