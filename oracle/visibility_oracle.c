@@ -13,8 +13,12 @@
  *     covered = the part of B outside the union of the canvas polygons has no area, decided EXACTLY by a slab
  *               decomposition: between two consecutive abscissae taken from {vertices, pairwise edge
  *               intersections} nothing changes topologically, so one vertical line per slab decides it.
- *               A slab narrower than EPS_X or an uncovered stretch shorter than EPS_Y is floating-point
- *               noise and ignored.
+ *               A slab narrower than EPS_X or an uncovered stretch shorter than EPS_Y is ignored.  GEOS has no
+ *               such thresholds (any difference with area counts), so they are kept as small as the coordinates
+ *               allow; they are also the two lengths the HIP painter works with (a piece of an edge shorter than
+ *               1e-9 is not examined, a witness stands 2.5e-10 beside its edge), so that both call the same slivers
+ *               nothing.  With EPS_Y at 1e-9 one pair of lln's 58 million was decided differently: two walls 640 m
+ *               apart, 3.25e-10 rad of one showing through a gap 6.7e-8 rad wide.
  * No reference fixture pins these two predicates: parity unpinned.
  */
 #include <math.h>
@@ -24,7 +28,7 @@
 #define TOL_DZ 1e-4   /* geometry.py:947 */
 #define TOL_DOT 1e-4  /* geometry.py:948 */
 #define EPS_X 1e-9
-#define EPS_Y 1e-9
+#define EPS_Y 2.5e-10
 
 typedef struct {
     int index;      /* polygon index in the scene */

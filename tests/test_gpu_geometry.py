@@ -253,6 +253,32 @@ def test_visibility_rows_of_lln_match_oracle(places):
     assert n_visible > 1000
 
 
+def test_every_row_of_the_lln_matrix_is_the_oracles(places):
+    """All 7 615 rows (58 million entries) against tests/golden/lln_matrix_rows.npz, the oracle painter's rows made on
+    the CPU by tests/golden/make_lln_matrix.py; the rows painted whole (one call with every face) and, for a sample,
+    alone (a single face is painted in sectors)."""
+    import os
+
+    from conftest import GOLDEN
+    from raytracing_amd import geometry as geom
+
+    z = np.load(os.path.join(GOLDEN, "lln_matrix_rows.npz"))
+    n = int(z["n"])
+    want = np.unpackbits(z["bits"])[: n * n].reshape(n, n).astype(bool)
+    place = places("lln")
+    polygons = place.get_polygons_list()
+    assert len(polygons) == n
+    scene = geom.scene_arrays_of(polygons).device_scene()
+    face = lambda i: (polygons[i].points, polygons[i].get_parametric(), i)  # noqa: E731
+    got = np.asarray(scene.faces_visibility([face(i) for i in range(n)], False)).astype(bool)
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, f"{len(bad)} entries differ, first {bad[:10].tolist()}"
+    assert int(got.sum()) == 428090
+    for i in [5496, 6713, 12, 4000]:  # (the first two: a gap 3e-10 rad high decides whether one sees the other)
+        alone = np.asarray(scene.faces_visibility([face(i)], False)[0]).astype(bool)
+        np.testing.assert_array_equal(alone, want[i])
+
+
 @pytest.mark.parametrize("name", ["small", "ny", "place_levant", "place_saint_jean/place_saint_jean"])
 def test_sharp_edges_match_oracle(places, name):
     from oracle import geometry_oracle as go
