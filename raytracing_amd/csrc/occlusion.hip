@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(Scene
                                                         const unsigned long long *__restrict__ n_dev,
                                                         const uint8_t *__restrict__ mask, uint8_t *out, int max_trips,
                                                         unsigned long long *late_count, int32_t *late_items,
-                                                        int32_t *late_cursor) {
+                                                        int32_t *late_cursor, int split_shift) {
+    // split_shift: a launch of few items walks every segment in 2^split_shift pieces, one lane each (a piece = its share
+    // of the columns the segment crosses, tested against the whole segment like any other: a polygon reaches the
+    // segment inside a cell of some piece).  A launch lasts as long as its longest walk, and with few segments there
+    // is nothing else to fill the chip with.  Not combined with the hand-over between passes.
     __shared__ int64_t wave_items[4][64];
     __shared__ double wave_ab[4][64][6];  // the segment of each lane, for the exact tests
     __shared__ uint32_t wave_queue[4][128];
@@ -314,13 +318,15 @@ __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(Scene
     uint32_t *wq = wave_queue[wave];
     volatile uint8_t *wave_hit = wave_hits[wave];
     const OccCell global_cell = sc.cells[sc.gnx * sc.gny];
-    for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_seg; tile += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n_lanes = n_seg << split_shift;
+    for (int64_t tile = (int64_t)blockIdx.x * blockDim.x; tile < n_lanes; tile += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s_base = tile + wave * 64;
         const int64_t s = s_base + lane;
-        int64_t item = s;
+        int64_t item = s >> split_shift;
+        const int piece = (int)(s & ((1 << split_shift) - 1));
         bool use_mask = false;
         d3 A = mk3(0, 0, 0), B = mk3(1, 0, 0);
-        const bool active = s < n_seg && item_segment(items, item, out, use_mask, A, B);
+        const bool active = s < n_lanes && item_segment(items, item, out, use_mask, A, B);
         wave_items[wave][lane] = item;
         st3(wave_ab[wave][lane], A);
         st3(wave_ab[wave][lane] + 3, B);
@@ -342,6 +348,15 @@ __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(Scene
         int i = (step > 0 ? i_first : i_last) - step;  // current column
         int j = 1, j_hi = 0;
         int k = active ? global_cell.begin : 0, k_end = active ? global_cell.end : 0;
+        const bool resumed = active && items.index && items.cursor;
+        if (split_shift > 0 && !resumed) {
+            // this piece's columns, counted along the walk; the polygons too large for the grid go with the first piece
+            const int lo = (int)(((int64_t)cols_left * piece) >> split_shift);
+            const int hi = (int)(((int64_t)cols_left * (piece + 1)) >> split_shift);
+            i += step * lo;
+            cols_left = hi - lo;
+            if (piece != 0) k = k_end = 0;
+        }
 #ifdef RT_OCC_STATS
         unsigned long long st_cells = 0, st_recs = 0, st_iters = 0, st_exact = 0;
 #endif
@@ -385,11 +400,23 @@ __global__ __launch_bounds__(256, OBS_GRID_MIN_WAVES) void k_obstruct_grid(Scene
             }
         };
         bool finished = !active;
-        if (active && items.index && items.cursor) {
-            // the walk of an item handed over by the first pass goes on where it stopped
-            const int32_t *c = items.cursor + 8 * s;
-            k = c[0]; k_end = c[1]; i = c[2]; j = c[3]; j_hi = c[4]; cols_left = c[5];
-            z_low = __hiloint2double(c[7], c[6]);
+        if (resumed) {
+            // the walk of an item handed over by the first pass goes on where it stopped; in pieces, the first piece
+            // finishes the column the walk was in and every piece takes its share of the columns not yet entered
+            const int32_t *c = items.cursor + 8 * (s >> split_shift);
+            const int left = c[5];
+            const int lo = (int)(((int64_t)left * piece) >> split_shift);
+            const int hi = (int)(((int64_t)left * (piece + 1)) >> split_shift);
+            i = c[2] + step * lo;
+            cols_left = hi - lo;
+            if (piece == 0) {
+                k = c[0]; k_end = c[1]; j = c[3]; j_hi = c[4];
+                z_low = __hiloint2double(c[7], c[6]);
+            } else {
+                k = k_end = 0;
+                j = 1;
+                j_hi = 0;
+            }
         }
         if (active && k >= k_end) finished = !next_cell();
         int qn = 0;  // wave-uniform
@@ -540,14 +567,17 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
         // over item starts its walk again.
         const bool passes = n_grid >= (1 << 20) && n_item <= 0x7fffffffLL;
         if (!passes) {
+            // few segments (the later rounds of a solve, a rank's share of a map): walked in pieces
+            const int split_shift = n_grid <= (1 << 17) ? 3 : (n_grid <= (1 << 19) ? 2 : 1);
+            grid = ((n_grid << split_shift) + block - 1) / block;
             if (d_mask)
                 hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, stream, scene->view, items,
                                    n_item, d_count, d_mask, d_out, 0x7fffffff, (unsigned long long *)nullptr,
-                                   (int32_t *)nullptr, (int32_t *)nullptr);
+                                   (int32_t *)nullptr, (int32_t *)nullptr, split_shift);
             else
                 hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, stream, scene->view, items,
                                    n_item, d_count, d_mask, d_out, 0x7fffffff, (unsigned long long *)nullptr,
-                                   (int32_t *)nullptr, (int32_t *)nullptr);
+                                   (int32_t *)nullptr, (int32_t *)nullptr, split_shift);
         } else {
             // two hand-over lists (a pass reads one and fills the other) and their counters
             // (behind the two lists: where each handed-over item had got to, 8 ints per item)
@@ -563,6 +593,8 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
             unsigned long long *counts = scene->d_counters + 6;  // [6], [7]
             RT_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), stream));
             const int trip_limits[OBS_PASSES] = {OBS_FIRST_PASS_TRIPS, 0x7fffffff};
+            // about a quarter of the items are handed over; when that is too few to fill the chip they go on in pieces
+            const int late_shift = n_grid <= (1 << 22) ? 2 : (n_grid <= (1 << 23) ? 1 : 0);
             for (int pass = 0; pass < OBS_PASSES; ++pass) {
                 ObstructItems it = items;
                 const unsigned long long *n_in = d_count;
@@ -572,7 +604,7 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
                     it.cursor = pass == 1 ? cursors : nullptr;
                     it.count_add = 0;
                     n_in = counts + ((pass - 1) & 1);
-                    g = (unsigned)std::max<int64_t>(1024, grid >> (2 * pass));
+                    g = (unsigned)std::max<int64_t>(1024, (grid >> (2 * pass)) << late_shift);
                 }
                 const bool last = pass == OBS_PASSES - 1;
                 int32_t *late_out = last ? nullptr : scene->late_items + (size_t)(pass & 1) * n_item;
@@ -580,10 +612,12 @@ int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_item, co
                 if (pass >= 2 && !last) RT_HIP(hipMemsetAsync(count_out, 0, sizeof(unsigned long long), stream));
                 if (d_mask)
                     hipLaunchKernelGGL(k_obstruct_grid<true>, dim3(g), dim3(block), 0, stream, scene->view, it, n_item, n_in,
-                                       d_mask, d_out, trip_limits[pass], count_out, late_out, pass == 0 ? cursors : (int32_t *)nullptr);
+                                       d_mask, d_out, trip_limits[pass], count_out, late_out, pass == 0 ? cursors : (int32_t *)nullptr,
+                                       pass == 1 ? late_shift : 0);
                 else
                     hipLaunchKernelGGL(k_obstruct_grid<false>, dim3(g), dim3(block), 0, stream, scene->view, it, n_item, n_in,
-                                       d_mask, d_out, trip_limits[pass], count_out, late_out, pass == 0 ? cursors : (int32_t *)nullptr);
+                                       d_mask, d_out, trip_limits[pass], count_out, late_out, pass == 0 ? cursors : (int32_t *)nullptr,
+                                       pass == 1 ? late_shift : 0);
             }
         }
     } else if (d_mask)
@@ -809,22 +843,22 @@ extern "C" int rt_obstruct_segments_noalloc(rt_scene *scene, const double *d_seg
     if (d_mask)
         hipLaunchKernelGGL(k_obstruct_grid<true>, dim3((unsigned)grid), dim3(block), 0, st, scene->view, items, n_seg,
                            (const unsigned long long *)nullptr, d_mask, d_out, OBS_FIRST_PASS_TRIPS, &scr->late_count,
-                           scr->late_items, (int32_t *)nullptr);
+                           scr->late_items, (int32_t *)nullptr, 0);
     else
         hipLaunchKernelGGL(k_obstruct_grid<false>, dim3((unsigned)grid), dim3(block), 0, st, scene->view, items, n_seg,
                            (const unsigned long long *)nullptr, d_mask, d_out, OBS_FIRST_PASS_TRIPS, &scr->late_count,
-                           scr->late_items, (int32_t *)nullptr);
+                           scr->late_items, (int32_t *)nullptr, 0);
     // second pass: the listed segments, walked to the end (the count is read on the device)
     items.index = scr->late_items;
     const unsigned g2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(grid, std::max<int64_t>(1024, grid >> 2)));
     if (d_mask)
         hipLaunchKernelGGL(k_obstruct_grid<true>, dim3(g2), dim3(block), 0, st, scene->view, items, n_seg,
                            (const unsigned long long *)&scr->late_count, d_mask, d_out, 0x7fffffff,
-                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 0);
     else
         hipLaunchKernelGGL(k_obstruct_grid<false>, dim3(g2), dim3(block), 0, st, scene->view, items, n_seg,
                            (const unsigned long long *)&scr->late_count, d_mask, d_out, 0x7fffffff,
-                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+                           (unsigned long long *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 0);
     RT_HIP(hipGetLastError());
     return 0;
 }
