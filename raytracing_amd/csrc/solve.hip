@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_reflect(SceneView sc, ReflectGroups g, 
 }
 
 template <int MO>
-__global__ __launch_bounds__(256) void k_reflect_tiled(SceneView sc, ReflectGroups g, d3 tx, RxTiles rt, int64_t r0,
+__global__ __launch_bounds__(256, MO <= 2 ? 3 : 2) void k_reflect_tiled(SceneView sc, ReflectGroups g, d3 tx, RxTiles rt, int64_t r0,
                                                         int64_t r1, int tiles_per_block, Queues q) {
     __shared__ ReflectTiledShared sh;
     const unsigned b = blockIdx.x;
