@@ -311,7 +311,7 @@ def main():
     precompute_s = time.perf_counter() - t_wall
 
     def step():
-        block = pipe.run(d_rx, [FREQUENCY_HZ])
+        block = pipe.run(d_rx, [FREQUENCY_HZ], records=True)
         records = dp.all_gather_records(dp.receiver_records(block), n_total, pg)
         return block, records
 

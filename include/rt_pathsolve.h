@@ -50,6 +50,15 @@ int32_t rt_scene_polygon_count(const rt_scene *scene);
  * For on_device = 1 calls whose inputs the caller's own kernels produce.  No reference counterpart. */
 int rt_scene_wait_for_stream(rt_scene *scene, void *stream);
 
+/* No counterpart in the reference: a serving loop that calls the path description, the field step and the receiver
+ * records one after the other with device pointers (on_device = 1) pays for three waits in which the GPU has nothing
+ * queued.  With deferred synchronisation on, those three calls only queue their work on the scene's stream and return;
+ * rt_scene_synchronize waits for all of it and reports a failed launch.  Their outputs and the timing of the field
+ * step are valid after that call only.  The host-array forms (on_device = 0) wait as before.
+ * (ray_tracing.py:201-390 and electromagnetism.py:216-420 run these steps strictly one after the other on the host.) */
+int rt_scene_set_deferred_sync(rt_scene *scene, int on);
+int rt_scene_synchronize(rt_scene *scene);
+
 /* ---- obstruction: polygons_obstruct_line_path (geometry.py:836-898) ----------------------------------------------
  * segs[n_seg*6] = (A, B) per segment; mask[N] or NULL restricts the test to polygons with mask != 0 (the LOS step
  * passes the emitter visibility, ray_tracing.py:232-236); out[n_seg] = 1 when some polygon obstructs. */

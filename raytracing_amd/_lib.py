@@ -49,6 +49,8 @@ _SIGNATURES = {
     "rt_debug_set_visibility_tiling": (c_int, [c_void_p, c_int32, c_int32]),
     "rt_scene_set_timing": (c_int, [c_void_p, c_int]),
     "rt_scene_wait_for_stream": (c_int, [c_void_p, c_void_p]),
+    "rt_scene_set_deferred_sync": (c_int, [c_void_p, c_int]),
+    "rt_scene_synchronize": (c_int, [c_void_p]),
     "rt_debug_set_stored_chain_limit": (c_int, [c_void_p, c_int64]),
     "rt_scene_set_reference_solver": (c_int, [c_void_p, c_int]),
     "rt_debug_set_reflect_mode": (c_int, [c_void_p, c_int]),
@@ -302,6 +304,15 @@ class Scene:
         """Orders the scene's stream after what is queued on the caller's stream (a hipStream_t as an integer, e.g.
         ``torch.cuda.current_stream().cuda_stream``; 0 = the null stream), on the device: the host does not wait."""
         _check(load().rt_scene_wait_for_stream(self.handle, c_void_p(int(stream_handle))), "rt_scene_wait_for_stream")
+
+    def set_deferred_sync(self, on):
+        """While on, the device-pointer forms of the path description, the field step and the receiver records only
+        queue their work on the scene's stream; ``synchronize`` waits for it."""
+        _check(load().rt_scene_set_deferred_sync(self.handle, 1 if on else 0), "rt_scene_set_deferred_sync")
+
+    def synchronize(self):
+        """Waits for everything queued on the scene's stream (and reports a launch that failed)."""
+        _check(load().rt_scene_synchronize(self.handle), "rt_scene_synchronize")
 
     def set_stored_chain_limit(self, n_bytes):
         """Largest deepest reflection level (bytes of its chains) that ``enumerate`` stores; above it the level's

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "rt_candidates.h"
+#include <cstring>
 #include "rt_common.h"
 #include "rt_fresnel.h"
 
@@ -689,6 +690,22 @@ __global__ void k_rx_power_sum(const int64_t *__restrict__ off, const int32_t *_
 }
 
 #define STATUS_UNSET 0x7f7f7f7f /* what hipMemset(0x7f) leaves: larger than any (frequency, status) key */
+// Start values of the field step's accumulators: power sums, per-receiver counts and class counts zero, the shortest
+// lengths and their indices all ones, every status "not computed" (bytes 0x7f).
+__global__ void k_fields_start(double *__restrict__ power_sum, int64_t n_sum, unsigned long long *__restrict__ best_len,
+                               unsigned long long *__restrict__ best_idx, int64_t n_rx, int32_t *__restrict__ rx_counts,
+                               unsigned long long *__restrict__ cls_counts, int32_t *__restrict__ status, int64_t n_paths) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = first; i < n_sum; i += stride) power_sum[i] = 0.0;
+    for (int64_t i = first; i < n_rx; i += stride) {
+        best_len[i] = ~0ull;
+        best_idx[i] = ~0ull;
+    }
+    for (int64_t i = first; i < 2 * n_rx; i += stride) rx_counts[i] = 0;
+    for (int64_t i = first; i < n_paths; i += stride) status[i] = 0x7f7f7f7f;
+    if (first < 3) cls_counts[first] = 0;
+}
+
 __global__ void k_status_final(int32_t *__restrict__ status, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -778,16 +795,29 @@ extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group,
         }
     }
     auto dalloc = [&](size_t bytes) -> void * { return rt_scene_temp(scene, bytes); };
+    const bool deferred = on_device && scene->defer_sync;
     int rc = -1;
     do {
-        int *d_refl = (int *)dalloc(sizeof(int) * h_refl.size()), *d_edge = (int *)dalloc(sizeof(int) * h_edge.size());
-        ChainSource *d_chains = (ChainSource *)dalloc(sizeof(ChainSource) * h_chains.size());
-        const int32_t **d_eids = (const int32_t **)dalloc(sizeof(void *) * h_eids.size());
-        if (!d_refl || !d_edge || !d_chains || !d_eids) break;
-        if (hipMemcpyAsync(d_refl, h_refl.data(), sizeof(int) * h_refl.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
-        if (hipMemcpyAsync(d_edge, h_edge.data(), sizeof(int) * h_edge.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
-        if (hipMemcpyAsync(d_chains, h_chains.data(), sizeof(ChainSource) * h_chains.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
-        if (hipMemcpyAsync(d_eids, h_eids.data(), sizeof(void *) * h_eids.size(), hipMemcpyHostToDevice, st) != hipSuccess) break;
+        // the per-group tables: built and copied once per set of candidates (a set never changes after rt_enumerate)
+        const size_t n_tab = h_refl.size();
+        const size_t off_edge = sizeof(int) * n_tab, off_chains = (2 * sizeof(int) * n_tab + 15) & ~(size_t)15;
+        const size_t off_eids = off_chains + sizeof(ChainSource) * n_tab, tab_bytes = off_eids + sizeof(void *) * n_tab;
+        if (!cand->d_describe_tables) {
+            std::vector<unsigned char> h_tab(tab_bytes, 0);
+            std::memcpy(h_tab.data(), h_refl.data(), sizeof(int) * n_tab);
+            std::memcpy(h_tab.data() + off_edge, h_edge.data(), sizeof(int) * n_tab);
+            std::memcpy(h_tab.data() + off_chains, h_chains.data(), sizeof(ChainSource) * n_tab);
+            std::memcpy(h_tab.data() + off_eids, h_eids.data(), sizeof(void *) * n_tab);
+            void *d = nullptr;
+            if (hipMalloc(&d, tab_bytes) != hipSuccess) break;
+            cand->allocations.push_back(d);
+            if (hipMemcpy(d, h_tab.data(), tab_bytes, hipMemcpyHostToDevice) != hipSuccess) break;
+            cand->d_describe_tables = d;
+        }
+        unsigned char *tab = (unsigned char *)cand->d_describe_tables;
+        int *d_refl = (int *)tab, *d_edge = (int *)(tab + off_edge);
+        ChainSource *d_chains = (ChainSource *)(tab + off_chains);
+        const int32_t **d_eids = (const int32_t **)(tab + off_eids);
         const int32_t *d_group = path_group, *d_cand = path_cand;
         int32_t *d_kind = out_kind, *d_chain = out_chain, *d_ep = out_edge_polys;
         double *d_pts = out_edge_points;
@@ -814,7 +844,7 @@ extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group,
             if (hipMemcpyAsync(out_edge_polys, d_ep, 8 * n, hipMemcpyDeviceToHost, st) != hipSuccess) break;
             if (hipMemcpyAsync(out_edge_points, d_pts, 48 * n, hipMemcpyDeviceToHost, st) != hipSuccess) break;
         }
-        if (hipStreamSynchronize(st) != hipSuccess) break;
+        if (!deferred && hipStreamSynchronize(st) != hipSuccess) break;
         rc = 0;
     } while (0);
     if (rc) {
@@ -972,17 +1002,18 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
     unsigned long long *cls_counts = scene->d_counters + 13;  // [13], [14], [15]
     F_PTR(fo.power_sum); F_PTR(best_len); F_PTR(best_idx); F_PTR(rx_counts); F_PTR(rx_off); F_PTR(rx_order);
     F_PTR(cls_lists); F_PTR(los_trees);
-    F_HIP(hipMemsetAsync(fo.power_sum, 0, sizeof(double) * n_rx * nf, st));
-    F_HIP(hipMemsetAsync(best_len, 0xff, sizeof(unsigned long long) * n_rx, st));
-    F_HIP(hipMemsetAsync(best_idx, 0xff, sizeof(unsigned long long) * n_rx, st));
-    F_HIP(hipMemsetAsync(rx_counts, 0, sizeof(int32_t) * 2 * n_rx, st));
-    F_HIP(hipMemsetAsync(cls_counts, 0, sizeof(unsigned long long) * 3, st));
+    // everything that has to start from a fixed value, in one launch (six fills used to go one by one)
+    {
+        const int64_t most = std::max<int64_t>((int64_t)(n_rx * nf), std::max<int64_t>(2 * n_rx, (int64_t)np_));
+        hipLaunchKernelGGL(k_fields_start, dim3((unsigned)std::min<int64_t>(2048, (most + 255) / 256)), dim3(256), 0, st,
+                           fo.power_sum, (int64_t)(n_rx * nf), best_len, best_idx, (int64_t)n_rx, rx_counts, cls_counts,
+                           fo.status, (int64_t)np_);
+    }
     const d3 TX = ld3(tx);
     if (n_paths > 0) {
         const unsigned grid = (unsigned)((n_paths + 255) / 256);
         hipLaunchKernelGGL(k_best_length, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len);
         hipLaunchKernelGGL(k_best_index, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len, best_idx);
-        F_HIP(hipMemsetAsync(fo.status, 0x7f, sizeof(int32_t) * np_, st));
         hipLaunchKernelGGL(k_field_classes, dim3(grid), dim3(256), 0, st, pa, cls_lists, cls_counts);
         if (ev[1]) F_HIP(hipEventRecord(ev[1], st));
         // the class kernels read their list's length on the device: the grids are sized for the whole batch and the
@@ -1020,6 +1051,14 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         F_HIP(hipMemcpyAsync(out_power_db, d_db, sizeof(double) * n_rx * nf, hipMemcpyDeviceToHost, st));
     }
     if (ev[3]) F_HIP(hipEventRecord(ev[3], st));
+    if (on_device && scene->defer_sync) {
+        // queued only: rt_scene_synchronize waits and reads the events.  The temporary blocks may be handed out again
+        // at once: whoever gets them queues on the same stream, behind these kernels.
+        scene->fields_events_pending = ev[0] != nullptr;
+        scene->fields_events_with_kernels = n_paths > 0;
+        rt_scene_temp_release_all(scene);
+        return 0;
+    }
     F_HIP(hipStreamSynchronize(st));
     if (ev[0]) {
         float t = 0;
@@ -1096,6 +1135,6 @@ extern "C" int rt_receiver_records(rt_scene *scene, int64_t n_rx, int32_t n_freq
         hipLaunchKernelGGL(k_records_count, dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, st, n_paths, n_rx, path_rx,
                            path_kind, path_status, n_freq, out, bytes);
     RT_HIP(hipGetLastError());
-    RT_HIP(hipStreamSynchronize(st));
+    if (!scene->defer_sync) RT_HIP(hipStreamSynchronize(st));
     return 0;
 }

@@ -65,4 +65,7 @@ struct rt_candidates {
     int32_t *d_edge_pairs = nullptr;
     uint8_t *d_ev = nullptr;      // [n]
     std::vector<void *> allocations;
+    // per-group tables of the path description (reflections, has an edge, chain source, edge ids), copied to the
+    // device by the first description and kept: one block, in `allocations`
+    void *d_describe_tables = nullptr;
 };

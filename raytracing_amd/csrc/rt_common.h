@@ -133,6 +133,11 @@ struct rt_scene {
     int64_t last_segments = 0;
     // device time of the last rt_fields call: [0] k_fields, [1] everything the call queued
     double last_fields_ms[2] = {0, 0};
+    // rt_scene_set_deferred_sync: the device-pointer forms of the path description, the field step and the receiver
+    // records then only queue their work; rt_scene_synchronize waits for it (and reads the field step's events)
+    bool defer_sync = false;
+    bool fields_events_pending = false;
+    bool fields_events_with_kernels = false;
     // device time of the last visibility call: rows / matrix [0] mapping, [1] sorting, [2] painting, [3] all of it;
     // [4..7] the same for the extra faces of rt_visibility_with_faces / rt_faces_visibility
     double last_vis_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -223,6 +223,26 @@ extern "C" int rt_scene_wait_for_stream(rt_scene *s, void *stream) {
     return 0;
 }
 
+extern "C" int rt_scene_set_deferred_sync(rt_scene *s, int on) {
+    if (!s) RT_FAIL("rt_scene_set_deferred_sync: null scene");
+    s->defer_sync = on != 0;
+    return 0;
+}
+
+extern "C" int rt_scene_synchronize(rt_scene *s) {
+    if (!s) RT_FAIL("rt_scene_synchronize: null scene");
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipStreamSynchronize(s->stream));
+    if (s->fields_events_pending && s->event_pool.size() >= 4) {
+        float t = 0;
+        if (s->fields_events_with_kernels && hipEventElapsedTime(&t, s->event_pool[1], s->event_pool[2]) == hipSuccess)
+            s->last_fields_ms[0] = t;
+        if (hipEventElapsedTime(&t, s->event_pool[0], s->event_pool[3]) == hipSuccess) s->last_fields_ms[1] = t;
+    }
+    s->fields_events_pending = false;
+    return 0;
+}
+
 extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *vert_off, const double *verts,
                                      const double *planes, const int32_t *material_id, const int32_t *building_id) {
     if (n_poly <= 0 || !vert_off || !verts || !planes) {

@@ -87,8 +87,11 @@ class DevicePipeline:
             angles=torch.empty((capacity, 4), dtype=f64, device=dev), time=torch.empty(capacity, dtype=f64, device=dev),
             status=torch.empty(capacity, dtype=i32, device=dev))
 
-    def run(self, d_rx, frequencies, fields=True, **antenna):
-        """d_rx: float64 CUDA tensor [n, 3] on this pipeline's GPU.  Returns a PathBlock."""
+    def run(self, d_rx, frequencies, fields=True, records=False, **antenna):
+        """d_rx: float64 CUDA tensor [n, 3] on this pipeline's GPU.  Returns a PathBlock.  ``records``: also make the
+        per-receiver records (``receiver_records(block)`` then returns them).  Description, field step and records
+        are queued one behind the other on the library's stream and waited for once (three waits, with the GPU idle
+        while the host came back for the next call, were a tenth of a small block's step)."""
         torch = self.torch
         assert d_rx.is_cuda and d_rx.dtype == torch.float64 and d_rx.is_contiguous() and d_rx.shape[1] == 3
         freqs = np.atleast_1d(np.asarray(frequencies, dtype=np.float64))
@@ -112,18 +115,33 @@ class DevicePipeline:
         n = int(found)
         power_db = torch.empty((n_rx, len(freqs)), dtype=torch.float64, device=self.device)
         fields_timing = None
+        rec = None
         if fields and n_rx:
-            self.cand.describe_device(b["group"].data_ptr(), b["cand"].data_ptr(), n, b["kind"].data_ptr(),
-                                      b["chain"].data_ptr(), b["edge_polys"].data_ptr(), b["edge_points"].data_ptr())
-            self.field_scene.fields_device(self.tx, d_rx.data_ptr(), n_rx, b["rx"].data_ptr(), b["kind"].data_ptr(),
-                                     b["chain"].data_ptr(), b["edge_polys"].data_ptr(), b["edge_points"].data_ptr(),
-                                     b["points"].data_ptr(), n, freqs, b["field"].data_ptr(), b["power"].data_ptr(),
-                                     b["angles"].data_ptr(), b["time"].data_ptr(), b["status"].data_ptr(),
-                                     power_db.data_ptr(), n_late_polygons=self.n_late_polygons, **antenna)
+            # one stream for all three steps: queued without waiting in between (two scenes have two streams, and the
+            # description then has to be waited for before the other scene's field step)
+            one_stream = self.field_scene is self.scene
+            if one_stream:
+                self.scene.set_deferred_sync(True)
+            try:
+                self.cand.describe_device(b["group"].data_ptr(), b["cand"].data_ptr(), n, b["kind"].data_ptr(),
+                                          b["chain"].data_ptr(), b["edge_polys"].data_ptr(), b["edge_points"].data_ptr())
+                self.field_scene.fields_device(self.tx, d_rx.data_ptr(), n_rx, b["rx"].data_ptr(), b["kind"].data_ptr(),
+                                         b["chain"].data_ptr(), b["edge_polys"].data_ptr(), b["edge_points"].data_ptr(),
+                                         b["points"].data_ptr(), n, freqs, b["field"].data_ptr(), b["power"].data_ptr(),
+                                         b["angles"].data_ptr(), b["time"].data_ptr(), b["status"].data_ptr(),
+                                         power_db.data_ptr(), n_late_polygons=self.n_late_polygons, **antenna)
+                if records:
+                    rec = torch.empty((n_rx, record_bytes(len(freqs))), dtype=torch.uint8, device=self.device)
+                    self.field_scene.receiver_records_device(n_rx, len(freqs), power_db.data_ptr(), n, b["rx"].data_ptr(),
+                                                             b["kind"].data_ptr(), b["status"].data_ptr(), rec.data_ptr())
+            finally:
+                if one_stream:
+                    self.scene.set_deferred_sync(False)
+                    self.scene.synchronize()
             fields_timing = self.field_scene.fields_timing()
         views = {k: v[:n] for k, v in b.items()}
         return PathBlock(scene=self.field_scene, n_rx=n_rx, n_paths=n, n_attempted=int(attempted), power_db=power_db,
-                         frequencies=freqs,
+                         frequencies=freqs, records=rec,
                          solve_timing=solve_timing, fields_timing=fields_timing, **views)
 
 
@@ -136,6 +154,8 @@ def receiver_records(block):
 
     n_rx, nf, n = block.n_rx, len(block.frequencies), block.n_paths
     assert _lib.load().rt_receiver_record_bytes(nf) == record_bytes(nf)
+    if getattr(block, "records", None) is not None:
+        return block.records  # made by the run itself (DevicePipeline.run(records=True))
     rec = torch.empty((n_rx, record_bytes(nf)), dtype=torch.uint8, device=block.power_db.device)
     if n_rx:
         scene = block.scene

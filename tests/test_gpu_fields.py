@@ -410,3 +410,46 @@ def test_receiver_records_hold_what_the_path_arrays_say(places):
         assert rec["worst_status"][r] == (status[mine].max() if mine.any() and status[mine].max() > 0 else 0)
     assert rec["n_paths"].sum() == block.n_paths > 100 and rec["counts"][:, 0].sum() >= 10
     assert set(np.unique(types).tolist()) >= {0, 1, 2, 5, 6}  # LOS, R, RR, D, RD all occur
+
+
+def test_steps_queued_behind_each_other_give_what_the_waited_for_steps_give(places):
+    """rt_scene_set_deferred_sync: description, field step and records queued on the scene's stream with one wait at
+    the end (DevicePipeline.run(records=True)) against the same three steps each waited for; twice, so that the
+    temporary blocks handed out again behind queued work are covered."""
+    import torch
+
+    from raytracing_amd import _lib
+    from raytracing_amd import device_pipeline as dp
+    from raytracing_amd import geometry as geom
+
+    place = places("place_levant")
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    lo, hi = place.get_domain()
+    tx = np.array([(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0])
+    rng = np.random.default_rng(3)
+    rx = np.column_stack((rng.uniform(lo[0], hi[0], 300), rng.uniform(lo[1], hi[1], 300), np.full(300, 1.5)))
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+    cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+    pipe = dp.DevicePipeline(scene, cand, tx)
+    freqs = [3.6e9, 28e9]
+    for n in (300, 117):
+        d_rx = torch.tensor(rx[:n], dtype=torch.float64, device="cuda:0")
+        waited = pipe.run(d_rx, freqs)
+        want = waited.to_host()  # (sorted by receiver, group, candidate: a solve leaves its paths in no fixed order)
+        want_rec = dp.receiver_records(waited).clone()
+        queued = pipe.run(d_rx, freqs, records=True)
+        assert queued.records is not None and queued.n_paths == waited.n_paths > 200
+        got = queued.to_host()
+        n_pts = (want["kind"] & 255) + (want["kind"] >> 8)
+        used = np.arange(want["points"].shape[1])[None, :] < n_pts[:, None]  # the slots past a path's points are not written
+        for k, v in want.items():
+            if k == "points":
+                np.testing.assert_array_equal(got[k][used], v[used], err_msg=k)
+            else:
+                np.testing.assert_array_equal(got[k], v, err_msg=k)
+        assert torch.equal(dp.receiver_records(queued), want_rec)
+        assert queued.fields_timing is not None
