@@ -78,6 +78,13 @@ struct SceneView {
     const double *uv_recs;   // [n*16] x axis (3), y axis (3) of the own frame, then min u, min v, max u, max v of the ring
     const int32_t *material; // [n]
     const int32_t *building; // [n]
+    // the polygons of each building, for the shortcut of the diffraction kernel (a ray that leaves an edge into its own
+    // building is tested against that building's faces at once): building b of the polygons that were given an id owns
+    // bld_polys[bld_off[b] .. bld_off[b + 1]); bld_of[p] = b, or -1 for a polygon without one.  n_bld = 0 without ids.
+    int32_t n_bld;
+    const int32_t *bld_off;   // [n_bld + 1]
+    const int32_t *bld_polys; // [n]
+    const int32_t *bld_of;    // [n]
     // Uniform grid of square cells over the horizontal extent of the scene (buildings are extrusions, so a 2-D grid
     // separates them well).  Cell c = row * gnx + column lists every polygon whose footprint comes within RT_GRID_PAD of
     // it; the extra cell gnx*gny lists the polygons too large to be worth registering cell by cell (the ground), which

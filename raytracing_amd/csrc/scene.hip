@@ -325,7 +325,24 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
             }
         }
     }
-    bool ok = upload(s, s->h_vert_off, &s->view.vert_off) == 0 && upload(s, s->h_verts, &s->view.verts) == 0 &&
+    // polygons grouped by building id (any integers; without ids there are no groups)
+    std::vector<int32_t> bld_off(1, 0), bld_polys, bld_of(n_poly, -1);
+    if (building_id) {
+        std::vector<int32_t> order(n_poly);
+        for (int i = 0; i < n_poly; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return building_id[a] < building_id[b]; });
+        for (int k = 0; k < n_poly; ++k) {
+            if (k > 0 && building_id[order[k]] != building_id[order[k - 1]]) bld_off.push_back((int32_t)bld_polys.size());
+            bld_of[order[k]] = (int32_t)bld_off.size() - 1;
+            bld_polys.push_back(order[k]);
+        }
+        bld_off.push_back((int32_t)bld_polys.size());
+    }
+    if (bld_polys.empty()) bld_polys.push_back(0);
+    s->view.n_bld = building_id ? (int32_t)bld_off.size() - 1 : 0;
+    bool ok = upload(s, bld_off, &s->view.bld_off) == 0 && upload(s, bld_polys, &s->view.bld_polys) == 0 &&
+              upload(s, bld_of, &s->view.bld_of) == 0 &&
+              upload(s, s->h_vert_off, &s->view.vert_off) == 0 && upload(s, s->h_verts, &s->view.verts) == 0 &&
               upload(s, s->h_planes, &s->view.planes) == 0 && upload(s, frames, &s->view.frames) == 0 &&
               upload(s, s->h_bbox, &s->view.bbox) == 0 && upload(s, uv, &s->view.uv) == 0 &&
               upload(s, uv_recs, &s->view.uv_recs) == 0 &&

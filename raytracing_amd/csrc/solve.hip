@@ -1189,12 +1189,16 @@ struct DiffSetup {
     double xe, ye, ze, z1;
     double ax, ay, az, rhoA;
     double A[3];
-    int32_t cand, src;  // candidate index in its group; alive record (M > 0)
+    double n1[3], n2[3];  // normals of the two faces that meet in the edge
+    int32_t cand, src;    // candidate index in its group; alive record (M > 0)
+    int32_t bld, pad_;    // the building both faces belong to when it is one building of at most DIFF_OWN_FACES faces, else -1
 };
 
+#define DIFF_OWN_FACES 48
 template <int M>
-__global__ void k_diffract_setup(const AliveRec *__restrict__ alive, const int32_t *__restrict__ edge_ids, int64_t count,
-                                 const double *__restrict__ edges, d3 tx, DiffSetup *__restrict__ out) {
+__global__ void k_diffract_setup(SceneView sc, const AliveRec *__restrict__ alive, const int32_t *__restrict__ edge_ids,
+                                 int64_t count, const double *__restrict__ edges, const int32_t *__restrict__ edge_pairs,
+                                 d3 tx, DiffSetup *__restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
     int32_t cand = (int32_t)idx;
@@ -1220,6 +1224,15 @@ __global__ void k_diffract_setup(const AliveRec *__restrict__ alive, const int32
     S.az = dot(A, fz);
     S.rhoA = sqrt((S.xe - S.ax) * (S.xe - S.ax) + (S.ye - S.ay) * (S.ye - S.ay));
     st3(S.A, A);
+    const int p1 = edge_pairs[2 * (size_t)edge_ids[cand]], p2 = edge_pairs[2 * (size_t)edge_ids[cand] + 1];
+    st3(S.n1, ld3(sc.planes + 4 * (size_t)p1));
+    st3(S.n2, ld3(sc.planes + 4 * (size_t)p2));
+    S.bld = -1;
+    S.pad_ = 0;
+    if (sc.n_bld > 0 && sc.bld_of[p1] >= 0 && sc.bld_of[p1] == sc.bld_of[p2]) {
+        const int b = sc.bld_of[p1];
+        if (sc.bld_off[b + 1] - sc.bld_off[b] <= DIFF_OWN_FACES) S.bld = b;
+    }
     S.cand = cand;
     S.src = (int32_t)idx;
     out[idx] = S;
@@ -1252,16 +1265,18 @@ __device__ __forceinline__ bool keller_point(const DiffSetup &S, d3 R, d3 &D) {
 // "point before -> edge" segments of a wave, then all "edge -> receiver" ones.
 #define DIFF_CHUNK 32
 template <int M>
-__global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ setup, const AliveRec *__restrict__ alive,
-                                                   int64_t count, int group, const double *__restrict__ rx,
-                                                   const int32_t *__restrict__ perm, int64_t rx0, int64_t rx1, Queues q) {
+__global__ __launch_bounds__(256) void k_diffract(SceneView sc, const DiffSetup *__restrict__ setup,
+                                                   const AliveRec *__restrict__ alive, int64_t count, int group,
+                                                   const double *__restrict__ rx, const int32_t *__restrict__ perm,
+                                                   int64_t rx0, int64_t rx1, Queues q, int chunk) {
+    // chunk <= DIFF_CHUNK candidates per block: fewer when the launch would otherwise have too few blocks for the chip
     __shared__ DiffSetup s_setup[DIFF_CHUNK];
     __shared__ uint16_t s_list[4][DIFF_CHUNK * 64];
     __shared__ int s_count[4];
     __shared__ long long s_base[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t c_begin = (int64_t)blockIdx.x * DIFF_CHUNK;
-    const int n_c = (int)(count - c_begin < DIFF_CHUNK ? count - c_begin : DIFF_CHUNK);
+    const int64_t c_begin = (int64_t)blockIdx.x * chunk;
+    const int n_c = (int)(count - c_begin < chunk ? count - c_begin : chunk);
     {
         const double *src = (const double *)(setup + c_begin);
         double *dst = (double *)s_setup;
@@ -1322,7 +1337,26 @@ __global__ __launch_bounds__(256) void k_diffract(const DiffSetup *__restrict__ 
     for (unsigned long long todo = reach; todo != 0; todo &= todo - 1) {
         const int c = __ffsll((long long)todo) - 1;
         d3 D;
-        const bool ok = active && keller_point(s_setup[c], R, D);
+        bool ok = active && keller_point(s_setup[c], R, D);
+        // Four pairs in ten leave the edge INTO the building the edge belongs to (the receiver lies behind both of the
+        // edge's faces).  Such a last segment is cut by another face of that building, which the obstruction walk
+        // would find in its first cells - after the path has been written to the queue and read back.  The building's
+        // faces are tested here instead, with the walk's own tests: a pair that one of them cuts is dropped, every
+        // other pair goes on as before.  (All lanes of the wave are on the same edge, hence the same faces.)
+        const int own = s_setup[c].bld;
+        if (own >= 0) {
+            const d3 ray = R - D;
+            const bool inward = ok && dot(ray, ld3(s_setup[c].n1)) < 0.0 && dot(ray, ld3(s_setup[c].n2)) < 0.0;
+            if (__any(inward)) {
+                const double pad = 1e-5 * fmax(fabs(ray.x), fmax(fabs(ray.y), fabs(ray.z))) + 1e-6;
+                const int f_end = sc.bld_off[own + 1];
+                for (int fi = sc.bld_off[own]; fi < f_end && __any(inward && ok); ++fi) {
+                    const int p = sc.bld_polys[fi];
+                    if (inward && ok && occ_pretest(sc.poly_recs + p, sc, D, ray, pad) && polygon_cuts_segment(sc, p, D, R))
+                        ok = false;
+                }
+            }
+        }
         const unsigned long long m = __ballot(ok);
         if (ok) list[n + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((c << 6) | lane);
         n += __popcll(m);
@@ -1569,15 +1603,18 @@ static bool launch_reflect_tiled(rt_scene *s, const rt_candidates *cand, d3 tx, 
 template <int M>
 static void launch_diffract(rt_scene *s, const DiffSetup *setup, const AliveRec *alive, int64_t count, int group,
                             const double *rx, const int32_t *perm, int64_t rx0, int64_t rx1, const Queues &q) {
-    dim3 grid(blocks_for(count, DIFF_CHUNK), blocks_for(rx1 - rx0, 256));
-    hipLaunchKernelGGL(k_diffract<M>, grid, dim3(256), 0, s->stream, setup, alive, count, group, rx, perm, rx0, rx1, q);
+    int chunk = DIFF_CHUNK;
+    while (chunk > 4 && blocks_for(count, chunk) * blocks_for(rx1 - rx0, 256) < 8192) chunk >>= 1;
+    dim3 grid(blocks_for(count, chunk), blocks_for(rx1 - rx0, 256));
+    hipLaunchKernelGGL(k_diffract<M>, grid, dim3(256), 0, s->stream, s->view, setup, alive, count, group, rx, perm, rx0, rx1, q,
+                       chunk);
 }
 
 template <int M>
 static void launch_diffract_setup(rt_scene *s, const AliveRec *alive, const int32_t *edge_ids, int64_t count,
-                                  const double *edges, d3 tx, DiffSetup *out) {
-    hipLaunchKernelGGL(k_diffract_setup<M>, dim3(blocks_for(count, 256)), dim3(256), 0, s->stream, alive, edge_ids, count,
-                       edges, tx, out);
+                                  const double *edges, const int32_t *edge_pairs, d3 tx, DiffSetup *out) {
+    hipLaunchKernelGGL(k_diffract_setup<M>, dim3(blocks_for(count, 256)), dim3(256), 0, s->stream, s->view, alive, edge_ids,
+                       count, edges, edge_pairs, tx, out);
 }
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1727,10 +1764,10 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         SOLVE_PTR(diff_setup[m]);
         timer.begin(1);
         switch (m) {
-            case 0: launch_diffract_setup<0>(scene, nullptr, g.edge_ids, cnt, cand->d_edges, TX, diff_setup[m]); break;
-            case 1: launch_diffract_setup<1>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, TX, diff_setup[m]); break;
-            case 2: launch_diffract_setup<2>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, TX, diff_setup[m]); break;
-            default: launch_diffract_setup<3>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, TX, diff_setup[m]); break;
+            case 0: launch_diffract_setup<0>(scene, nullptr, g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
+            case 1: launch_diffract_setup<1>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
+            case 2: launch_diffract_setup<2>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
+            default: launch_diffract_setup<3>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
         }
         timer.end(1);
     }
