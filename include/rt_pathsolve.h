@@ -40,7 +40,10 @@ int rt_device_count(void);
  * vert_off[N+1] CSR offsets, verts[Vtot*3], planes[N*4] = OrientedPolygon.get_parametric() of each polygon
  * (geometry.py:1747-1765, with the sign fix-ups of geometry.py:2360-2363 already applied), material_id[N] index into
  * the ITU material table (materials_properties.py:47-104), building_id[N] (geometry.py:2139).  Host pointers.
- * Frames (geometry.py:1819-1853) and bounding boxes (geometry.py:1437-1465) are derived inside. */
+ * Frames (geometry.py:1819-1853) and bounding boxes (geometry.py:1437-1465) are derived inside.
+ * material_id and building_id may be NULL (concrete; no buildings).  building_id changes no result: polygons with the
+ * same id are taken to be the faces of one building, and a diffracted path that leaves an edge into its own building is
+ * tested against those faces before it is queued (same tests, same paths, a seventh of the lln map's step saved). */
 rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *vert_off, const double *verts,
                           const double *planes, const int32_t *material_id, const int32_t *building_id);
 void rt_scene_destroy(rt_scene *scene);
