@@ -1191,7 +1191,8 @@ struct DiffSetup {
     double A[3];
     double n1[3], n2[3];  // normals of the two faces that meet in the edge
     int32_t cand, src;    // candidate index in its group; alive record (M > 0)
-    int32_t bld, pad_;    // the building both faces belong to when it is one building of at most DIFF_OWN_FACES faces, else -1
+    int32_t bld, cell;    // the building both faces belong to when it is one building of at most DIFF_OWN_FACES faces, else -1;
+                          // the grid cell of the edge's middle
 };
 
 #define DIFF_OWN_FACES 48
@@ -1228,7 +1229,13 @@ __global__ void k_diffract_setup(SceneView sc, const AliveRec *__restrict__ aliv
     st3(S.n1, ld3(sc.planes + 4 * (size_t)p1));
     st3(S.n2, ld3(sc.planes + 4 * (size_t)p2));
     S.bld = -1;
-    S.pad_ = 0;
+    {
+        const d3 mid = 0.5 * (P0 + P1);
+        int ci = (int)floor((mid.x - sc.gx0) * sc.ginv), cj = (int)floor((mid.y - sc.gy0) * sc.ginv);
+        ci = ci < 0 ? 0 : (ci >= sc.gnx ? sc.gnx - 1 : ci);
+        cj = cj < 0 ? 0 : (cj >= sc.gny ? sc.gny - 1 : cj);
+        S.cell = cj * sc.gnx + ci;
+    }
     if (sc.n_bld > 0 && sc.bld_of[p1] >= 0 && sc.bld_of[p1] == sc.bld_of[p2]) {
         const int b = sc.bld_of[p1];
         if (sc.bld_off[b + 1] - sc.bld_off[b] <= DIFF_OWN_FACES) S.bld = b;
@@ -1355,6 +1362,17 @@ __global__ __launch_bounds__(256) void k_diffract(SceneView sc, const DiffSetup 
                     if (inward && ok && occ_pretest(sc.poly_recs + p, sc, D, ray, pad) && polygon_cuts_segment(sc, p, D, R))
                         ok = false;
                 }
+            }
+        }
+        // the polygons registered in the grid cell of the edge's middle: what the walk would look at first
+        if (__any(ok)) {
+            const OccCell cell = sc.cells[s_setup[c].cell];
+            const d3 ray = R - D;
+            const double pad = 1e-5 * fmax(fabs(ray.x), fmax(fabs(ray.y), fabs(ray.z))) + 1e-6;
+            const int k_end = cell.end - cell.begin > 64 ? cell.begin + 64 : cell.end;
+            for (int kk = cell.begin; kk < k_end && __any(ok); ++kk) {
+                const OccRec *r = sc.cell_recs + kk;
+                if (ok && occ_pretest(r, sc, D, ray, pad) && polygon_cuts_segment(sc, r->poly, D, R)) ok = false;
             }
         }
         const unsigned long long m = __ballot(ok);
