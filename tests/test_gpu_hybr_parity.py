@@ -41,9 +41,6 @@ def _solve(name, reference_solver):
     place = w["place"]
     place.add_set_of_points(rx)
     problem = RayTracingProblem(np.asarray(w["tx"]).reshape(1, 3), place)
-    if name == "c3_lln" and fx["visibility_matrix_popcount"] == 719564:
-        pytest.skip("this entry of the fixture was made while the oracle ignored uncovered stretches below 1e-9 (one pair "
-                    "of the lln matrix differs); it is being made again with the threshold of 2.5e-10")
     assert int(problem.visibility_matrix.sum()) == fx["visibility_matrix_popcount"]
     assert int(problem.emitter_visibility.sum()) == fx["emitter_visibility_popcount"]
     assert len(problem.sharp_edges) == fx["n_sharp_edges"]
