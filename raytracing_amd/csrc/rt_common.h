@@ -103,7 +103,9 @@ struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t caller_event = nullptr;  // rt_scene_wait_for_stream: marks the caller's stream, created on first use
-    hipStream_t side_stream = nullptr;  // created on first use: work that runs beside the main stream's (emitter screens)
+    hipStream_t side_stream = nullptr;  // created on first use: work that runs beside the main stream's (emitter screens,
+                                        // the receiver-independent head of a large solve)
+    hipEvent_t side_event = nullptr;    // end of the side stream's part of a solve, which the main stream waits for
     SceneView view{};
     std::vector<void *> allocations;
     // host copies used by host-side set-up code

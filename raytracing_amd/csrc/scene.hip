@@ -372,6 +372,7 @@ extern "C" void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->caller_event) (void)hipEventDestroy(s->caller_event);
+    if (s->side_event) (void)hipEventDestroy(s->side_event);
     if (s->side_stream) {
         (void)hipStreamSynchronize(s->side_stream);
         (void)hipStreamDestroy(s->side_stream);

@@ -1670,6 +1670,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     auto temp_alloc = [&](size_t bytes) -> void * { return rt_scene_temp(scene, bytes); };
     auto free_temps = [&]() {
         (void)hipStreamSynchronize(st);  // nothing queued may still be using them
+        if (scene->side_stream) (void)hipStreamSynchronize(scene->side_stream);
         rt_scene_temp_release_all(scene);
     };
 #define SOLVE_HIP(call)                                                                                   \
@@ -1693,6 +1694,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     unsigned long long *h_counters_dev = nullptr;  // the same words as the device addresses them
     SOLVE_HIP(hipHostGetDevicePointer((void **)&h_counters_dev, h_counters, 0));
     // the final filter of a chunk leaves the queue counters at zero; only a solve that was cut short does not
+    const bool counters_were_reset = scene->counters_dirty;
     if (scene->counters_dirty) SOLVE_HIP(hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 16, st));
     if (on_device) {
         out.rx = out_rx;
@@ -1718,78 +1720,86 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
 
     EventTimer timer(scene);
 
-    // ---- receiver-independent half of the reflection+diffraction groups -------------------------------------
     const int mo = cand->max_order;
     std::vector<AliveRec *> alive(mo, nullptr);
     std::vector<int64_t> alive_count(mo, 0);
-    for (int m = 1; m < mo; ++m) {
-        const CandGroup &g = cand->groups[mo + m];
-        if (g.count == 0) continue;
-        AliveRec *a0 = (AliveRec *)temp_alloc(sizeof(AliveRec) * g.count);
-        AliveRec *a1 = (AliveRec *)temp_alloc(sizeof(AliveRec) * g.count);
-        double *segs = (double *)temp_alloc(sizeof(double) * 6 * g.count * m);
-        uint8_t *hit = (uint8_t *)temp_alloc((size_t)g.count * m);
-        SOLVE_PTR(a0);
-        SOLVE_PTR(a1);
-        SOLVE_PTR(segs);
-        SOLVE_PTR(hit);
-        unsigned long long *cnt = d_counters + 4;
-        SOLVE_HIP(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), st));
-        timer.begin(1);
-        dim3 grid(blocks_for(g.count, 256));
-        switch (m) {
-            case 1: hipLaunchKernelGGL(k_rd_prepare<1>, grid, dim3(256), 0, st, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
-            case 2: hipLaunchKernelGGL(k_rd_prepare<2>, grid, dim3(256), 0, st, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
-            default: hipLaunchKernelGGL(k_rd_prepare<3>, grid, dim3(256), 0, st, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
-        }
-        timer.end(1);
-        unsigned long long n0 = 0;
-        SOLVE_HIP(hipMemcpyAsync(&n0, cnt, sizeof(n0), hipMemcpyDeviceToHost, st));
-        SOLVE_HIP(hipStreamSynchronize(st));
-        if (n0 == 0) continue;
-        timer.begin(2);
-        if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, 0, nullptr, 0, true, nullptr, nullptr, nullptr)) {
-            free_temps();
-            return -1;
-        }
-        timer.end(2);
-        scene->last_segments += (int64_t)n0 * m;
-        timer.begin(3);
-        switch (m) {
-            case 1: hipLaunchKernelGGL(k_rd_filter<1>, dim3(blocks_for(n0, 256)), dim3(256), 0, st, a0, hit, (int64_t)n0, a1, cnt + 1); break;
-            case 2: hipLaunchKernelGGL(k_rd_filter<2>, dim3(blocks_for(n0, 256)), dim3(256), 0, st, a0, hit, (int64_t)n0, a1, cnt + 1); break;
-            default: hipLaunchKernelGGL(k_rd_filter<3>, dim3(blocks_for(n0, 256)), dim3(256), 0, st, a0, hit, (int64_t)n0, a1, cnt + 1); break;
-        }
-        timer.end(3);
-        unsigned long long n1 = 0;
-        SOLVE_HIP(hipMemcpyAsync(&n1, cnt + 1, sizeof(n1), hipMemcpyDeviceToHost, st));
-        SOLVE_HIP(hipStreamSynchronize(st));
-        alive[m] = a1;
-        alive_count[m] = (int64_t)n1;
-    }
-
-    // ---- receiver-independent part of every diffraction candidate (edge frames) ------------------------------
     std::vector<DiffSetup *> diff_setup(mo, nullptr);
     std::vector<int64_t> diff_count(mo, 0);
     bool any_diffraction = false;
-    for (int m = 0; m < mo; ++m) {
-        const CandGroup &g = cand->groups[mo + m];
-        const int64_t cnt = m == 0 ? g.count : alive_count[m];
-        diff_count[m] = cnt;
-        if (cnt == 0) continue;
-        any_diffraction = true;
-        diff_setup[m] = (DiffSetup *)temp_alloc(sizeof(DiffSetup) * cnt);
-        SOLVE_PTR(diff_setup[m]);
-        timer.begin(1);
-        switch (m) {
-            case 0: launch_diffract_setup<0>(scene, nullptr, g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
-            case 1: launch_diffract_setup<1>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
-            case 2: launch_diffract_setup<2>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
-            default: launch_diffract_setup<3>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
+    // The receiver-independent half of the diffraction groups (reflection points aimed at the edge, their segments
+    // tested, edge frames) is independent of the reflection launch.  On a large solve it runs on the scene's side
+    // stream (same priority) beside the first chunk's reflection kernel, which is queued first: its two host waits
+    // then cost nothing, where they used to leave the GPU idle for a quarter of a millisecond at the start of every
+    // solve.  The main stream waits for it, on the device, before the diffraction kernels.
+    auto diffraction_head = [&]() -> int {
+        // ---- receiver-independent half of the reflection+diffraction groups -------------------------------------
+        for (int m = 1; m < mo; ++m) {
+            const CandGroup &g = cand->groups[mo + m];
+            if (g.count == 0) continue;
+            AliveRec *a0 = (AliveRec *)temp_alloc(sizeof(AliveRec) * g.count);
+            AliveRec *a1 = (AliveRec *)temp_alloc(sizeof(AliveRec) * g.count);
+            double *segs = (double *)temp_alloc(sizeof(double) * 6 * g.count * m);
+            uint8_t *hit = (uint8_t *)temp_alloc((size_t)g.count * m);
+            SOLVE_PTR(a0);
+            SOLVE_PTR(a1);
+            SOLVE_PTR(segs);
+            SOLVE_PTR(hit);
+            unsigned long long *cnt = d_counters + 4;
+            SOLVE_HIP(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), scene->stream));
+            timer.begin(1);
+            dim3 grid(blocks_for(g.count, 256));
+            switch (m) {
+                case 1: hipLaunchKernelGGL(k_rd_prepare<1>, grid, dim3(256), 0, scene->stream, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
+                case 2: hipLaunchKernelGGL(k_rd_prepare<2>, grid, dim3(256), 0, scene->stream, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
+                default: hipLaunchKernelGGL(k_rd_prepare<3>, grid, dim3(256), 0, scene->stream, scene->view, g.chains, g.edge_ids, g.count, cand->d_edges, TX, a0, segs, g.count, cnt); break;
+            }
+            timer.end(1);
+            unsigned long long n0 = 0;
+            SOLVE_HIP(hipMemcpyAsync(&n0, cnt, sizeof(n0), hipMemcpyDeviceToHost, scene->stream));
+            SOLVE_HIP(hipStreamSynchronize(scene->stream));
+            if (n0 == 0) continue;
+            timer.begin(2);
+            if (rt_launch_obstruct(scene, segs, (int64_t)n0 * m, nullptr, 0, hit, nullptr, 0, 0, nullptr, 0, true, nullptr, nullptr, nullptr)) {
+                free_temps();
+                return -1;
+            }
+            timer.end(2);
+            scene->last_segments += (int64_t)n0 * m;
+            timer.begin(3);
+            switch (m) {
+                case 1: hipLaunchKernelGGL(k_rd_filter<1>, dim3(blocks_for(n0, 256)), dim3(256), 0, scene->stream, a0, hit, (int64_t)n0, a1, cnt + 1); break;
+                case 2: hipLaunchKernelGGL(k_rd_filter<2>, dim3(blocks_for(n0, 256)), dim3(256), 0, scene->stream, a0, hit, (int64_t)n0, a1, cnt + 1); break;
+                default: hipLaunchKernelGGL(k_rd_filter<3>, dim3(blocks_for(n0, 256)), dim3(256), 0, scene->stream, a0, hit, (int64_t)n0, a1, cnt + 1); break;
+            }
+            timer.end(3);
+            unsigned long long n1 = 0;
+            SOLVE_HIP(hipMemcpyAsync(&n1, cnt + 1, sizeof(n1), hipMemcpyDeviceToHost, scene->stream));
+            SOLVE_HIP(hipStreamSynchronize(scene->stream));
+            alive[m] = a1;
+            alive_count[m] = (int64_t)n1;
         }
-        timer.end(1);
-    }
 
+        // ---- receiver-independent part of every diffraction candidate (edge frames) ------------------------------
+        for (int m = 0; m < mo; ++m) {
+            const CandGroup &g = cand->groups[mo + m];
+            const int64_t cnt = m == 0 ? g.count : alive_count[m];
+            diff_count[m] = cnt;
+            if (cnt == 0) continue;
+            any_diffraction = true;
+            diff_setup[m] = (DiffSetup *)temp_alloc(sizeof(DiffSetup) * cnt);
+            SOLVE_PTR(diff_setup[m]);
+            timer.begin(1);
+            switch (m) {
+                case 0: launch_diffract_setup<0>(scene, nullptr, g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
+                case 1: launch_diffract_setup<1>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
+                case 2: launch_diffract_setup<2>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
+                default: launch_diffract_setup<3>(scene, alive[m], g.edge_ids, cnt, cand->d_edges, cand->d_edge_pairs, TX, diff_setup[m]); break;
+            }
+            timer.end(1);
+        }
+
+        return 0;
+    };
     // ---- receivers, in chunks whose survivors fit the workspace ---------------------------------------------
     // One host synchronisation per chunk: the kernels after the candidate kernels take their sizes from the device
     // counters (their grids are sized from what the previous call needed and stride over the rest), and the host
@@ -1846,6 +1856,11 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         timer.end(0);
         tiles = RxTiles{rxs, perm, boxes};
     }
+    bool head_done = false;
+    if (!tiled) {
+        if (diffraction_head()) return -1;
+        head_done = true;
+    }
     unsigned long long found_before = 0;
     // what the next solve sizes its launches from: the largest chunk of this one, not its last
     int64_t seen_paths = 0, seen_segments = 0, seen_clear = 0;
@@ -1894,6 +1909,22 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
             timer.begin(3);
             hipLaunchKernelGGL(k_los_emit, dim3(blocks_for(nr, 256)), dim3(256), 0, st, TX, d_rx, r0, nr, q);
             timer.end(3);
+        }
+        if (!head_done) {
+            // beside the reflection launch just queued: the head on the side stream, then the main stream waits for it
+            if (!scene->side_stream) SOLVE_HIP(hipStreamCreateWithFlags(&scene->side_stream, hipStreamNonBlocking));
+            if (!scene->side_event) SOLVE_HIP(hipEventCreateWithFlags(&scene->side_event, hipEventDisableTiming));
+            if (counters_were_reset) {
+                // (the reset of all counters queued on the main stream at the start must not land on the head's two)
+                SOLVE_HIP(hipStreamSynchronize(st));
+            }
+            scene->stream = scene->side_stream;
+            const int rc_head = diffraction_head();
+            scene->stream = st;
+            if (rc_head) return -1;
+            SOLVE_HIP(hipEventRecord(scene->side_event, scene->side_stream));
+            SOLVE_HIP(hipStreamWaitEvent(st, scene->side_event, 0));
+            head_done = true;
         }
         // diffractions
         if (any_diffraction) {
