@@ -287,7 +287,7 @@ def main():
         stamps[name] = round(time.perf_counter() - since, 4)
         return time.perf_counter()
 
-    place, tx, rx = scenarios.lln_grid(args.n_side)
+    place, tx = scenarios.lln_place()
     polygons = place.get_polygons_list()
     arrays = geom.scene_arrays_of(polygons)
     t = stamp("scene_file_s", t_wall)
@@ -296,8 +296,22 @@ def main():
     t = stamp("device_scene_and_sharp_edges_s", t)
     cube = geom.Cube.by_point_and_side_length(tx, 0.2)
     screens = [(s.points, s.get_parametric(), -1) for s in cube.polygons]
-    # matrix rows and emitter screens dealt to the ranks, one all-gather (one rank: everything here)
-    vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg)
+    # the receivers of the map are placed (host work: a lattice minus the buildings' footprints) while the GPU paints
+    # the matrix: the library call releases the interpreter lock.  With several ranks the painting ends in a
+    # collective, which stays on the main thread; the lattice is then made first.
+    if world == 1:
+        import threading
+
+        made = {}
+        worker = threading.Thread(target=lambda: made.update(rx=scenarios.lattice_receivers(place, args.n_side, 1.5)))
+        worker.start()
+        vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg)
+        worker.join()
+        rx = made["rx"]
+    else:
+        rx = scenarios.lattice_receivers(place, args.n_side, 1.5)
+        t = stamp("receiver_lattice_s", t)
+        vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg)
     vis_timing = scene.visibility_timing()
     ev = np.logical_or.reduce(screen_vis)
     t = stamp("visibility_matrix_and_emitter_screens_s", t)

@@ -144,7 +144,9 @@ class Candidates:
         lib = require_gpu()
         self.scene = scene
         self.max_order = int(max_order)
-        vis8 = np.ascontiguousarray(vis, dtype=np.uint8)
+        vis = np.asarray(vis)
+        # (a bool matrix is passed as it is: of lln's 58 MB a copy takes longer than the enumeration)
+        vis8 = vis.view(np.uint8) if vis.dtype == np.bool_ and vis.flags.c_contiguous else np.ascontiguousarray(vis, dtype=np.uint8)
         ev8 = np.ascontiguousarray(ev, dtype=np.uint8)
         n = scene.n
         if vis8.shape != (n, n) or ev8.shape != (n,):
@@ -365,7 +367,7 @@ class Scene:
         _check(load().rt_visibility_with_faces(self.handle, n_rows, r_ptr, int(bool(strict)), _ptr(r_out), len(faces),
                                                _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs), int(bool(faces_strict)),
                                                _ptr(f_out)), "rt_visibility_with_faces")
-        return r_out.astype(bool), f_out.astype(bool)
+        return r_out.view(bool), f_out.view(bool)  # the kernels write 0 and 1 only: no copy
 
     def visibility_rows(self, row_ids, strict=False):
         """Rows of the visibility matrix before symmetrisation: bool [len(row_ids), N]."""
@@ -373,12 +375,12 @@ class Scene:
         out = np.zeros((len(rows), self.n), dtype=np.uint8)
         _check(load().rt_visibility_rows(self.handle, len(rows), _ptr(rows), int(bool(strict)), _ptr(out)),
                "rt_visibility_rows")
-        return out.astype(bool)
+        return out.view(bool)
 
     def visibility_matrix(self, strict=False):
         out = np.zeros((self.n, self.n), dtype=np.uint8)
         _check(load().rt_visibility_matrix(self.handle, int(bool(strict)), _ptr(out), 0), "rt_visibility_matrix")
-        return out.astype(bool)
+        return out.view(bool)
 
     def sharp_edges(self, min_angle=10.0):
         cap = 2 * len(self.arrays.verts) + 16

@@ -136,11 +136,16 @@ def levant_grid(n_side=32):
     return place, tx, lattice_receivers(place, n_side, 1.2)
 
 
-def lln_grid(n_side=100):
-    """Config 3: data/lln.geojson, TX above the scene centre at 30 m, n_side² receivers at 1.5 m."""
+def lln_place():
+    """The scene and the emitter of config 3 (data/lln.geojson, TX above the scene centre at 30 m), without receivers."""
     place = geom.load_place(os.path.join(DATA_DIR, "lln.geojson"))
     lo, hi = place.get_domain()
-    tx = emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
+    return place, emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
+
+
+def lln_grid(n_side=100):
+    """Config 3: data/lln.geojson, TX above the scene centre at 30 m, n_side² receivers at 1.5 m."""
+    place, tx = lln_place()
     return place, tx, lattice_receivers(place, n_side, 1.5)
 
 
