@@ -356,14 +356,15 @@ class Scene:
         verts = _f64(np.concatenate([np.asarray(f[0], dtype=float).reshape(-1, 3) for f in faces]))
         normals = _f64(np.array([np.asarray(f[1], dtype=float)[:3] for f in faces]))
         selfs = np.array([int(f[2]) for f in faces], dtype=np.int32)
-        f_out = np.zeros((len(faces), self.n), dtype=np.uint8)
+        # (the library copies whole buffers out: nothing of them has to be cleared first)
+        f_out = np.empty((len(faces), self.n), dtype=np.uint8)
         if row_ids is None:
             rows, n_rows, r_ptr = None, 0, None
-            r_out = np.zeros((self.n, self.n), dtype=np.uint8)
+            r_out = np.empty((self.n, self.n), dtype=np.uint8)
         else:
             rows = np.ascontiguousarray(row_ids, dtype=np.int32)
             n_rows, r_ptr = len(rows), _ptr(rows)
-            r_out = np.zeros((len(rows), self.n), dtype=np.uint8)
+            r_out = np.empty((len(rows), self.n), dtype=np.uint8)
         _check(load().rt_visibility_with_faces(self.handle, n_rows, r_ptr, int(bool(strict)), _ptr(r_out), len(faces),
                                                _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs), int(bool(faces_strict)),
                                                _ptr(f_out)), "rt_visibility_with_faces")
