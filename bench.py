@@ -305,13 +305,13 @@ def main():
         made = {}
         worker = threading.Thread(target=lambda: made.update(rx=scenarios.lattice_receivers(place, args.n_side, 1.5)))
         worker.start()
-        vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg)
+        vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg, on_device=True)
         worker.join()
         rx = made["rx"]
     else:
         rx = scenarios.lattice_receivers(place, args.n_side, 1.5)
         t = stamp("receiver_lattice_s", t)
-        vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg)
+        vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg, on_device=True)
     vis_timing = scene.visibility_timing()
     ev = np.logical_or.reduce(screen_vis)
     t = stamp("visibility_matrix_and_emitter_screens_s", t)

@@ -102,10 +102,13 @@ int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, 
  * as rt_visibility_rows) together with the visibility vectors of n_faces extra faces (faces_out[n_faces*N], arguments as
  * rt_faces_visibility): the two steps RayTracingProblem.precompute takes one after the other (ray_tracing.py:208, then
  * :210-228 for the emitter's screens).  The screens are painted on a stream of their own while the matrix is painted,
- * instead of holding six compute units busy afterwards.  Host pointers.  Same results as the separate calls. */
+ * instead of holding six compute units busy afterwards.  Host pointers, except that with rows_on_device != 0 (whole
+ * matrix only) rows_out is memory of the scene's GPU: the matrix then never visits the host and rt_enumerate can read
+ * it there (vis_on_device).  Same results as the separate calls. */
 int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *rows_out,
                              int32_t n_faces, const int32_t *face_off, const double *face_verts,
-                             const double *face_normals, const int32_t *self_index, int faces_strict, uint8_t *faces_out);
+                             const double *face_normals, const int32_t *self_index, int faces_strict, uint8_t *faces_out,
+                             int rows_on_device);
 /* Obstruction tests either walk every polygon (mode 1) or a uniform grid over the scene (mode 2); mode 0, the
  * default, picks by scene size.  Both give the same flags; the switch exists so that tests can check one against the
  * other (no reference counterpart). */
@@ -161,14 +164,16 @@ int rt_solve_reflections_diffraction(int device, const double *origin, const dou
 
 /* ---- candidate enumeration: the depth-first loops of RayTracingProblem.solve (ray_tracing.py:299-388) -------------
  * vis[N*N] (visibility matrix), ev[N] (emitter visibility), edge_pairs[n_edges*2] / edges[n_edges*6] (sharp edges in
- * dictionary order) — host pointers.  Groups, in the order the reference visits them:
+ * dictionary order) — host pointers; with vis_on_device != 0 vis is memory of the scene's GPU instead, read during the
+ * call only.  Groups, in the order the reference visits them:
  *   group g = 0 .. max_order-1            : g+1 reflections                 (ray_tracing.py:324-327)
  *   group max_order                       : 1 diffraction                   (ray_tracing.py:334-350)
  *   group max_order + m, m = 1..max_order-1 : m reflections + 1 diffraction (ray_tracing.py:355-388)
  * Within a group candidates are in the reference's visiting order.  with_diffraction = 0 leaves the diffraction
  * groups empty (reflection-only workloads). */
 rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, const uint8_t *ev, const int32_t *edge_pairs,
-                            const double *edges, int64_t n_edges, int32_t max_order, int with_diffraction);
+                            const double *edges, int64_t n_edges, int32_t max_order, int with_diffraction,
+                            int vis_on_device);
 void rt_candidates_destroy(rt_candidates *cand);
 int32_t rt_candidates_group_count(const rt_candidates *cand);
 /* counts[group_count] = candidates per group */

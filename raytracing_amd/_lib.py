@@ -43,7 +43,7 @@ _SIGNATURES = {
     "rt_visibility_rows": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p]),
     "rt_faces_visibility": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_visibility_with_faces": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_int, c_void_p]),
+                                         c_void_p, c_int, c_void_p, c_int]),
     "rt_debug_visibility_stats": (c_int, [c_void_p]),
     "rt_debug_set_occlusion_mode": (c_int, [c_void_p, c_int]),
     "rt_debug_set_visibility_tiling": (c_int, [c_void_p, c_int32, c_int32]),
@@ -60,7 +60,7 @@ _SIGNATURES = {
     "rt_solve_reflections": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "rt_solve_reflections_diffraction": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
                                                  c_void_p, c_void_p]),
-    "rt_enumerate": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int]),
+    "rt_enumerate": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_int]),
     "rt_candidates_destroy": (None, [c_void_p]),
     "rt_candidates_group_count": (c_int32, [c_void_p]),
     "rt_candidates_counts": (c_int, [c_void_p, c_void_p]),
@@ -133,6 +133,15 @@ def _ptr(a):
     return a.ctypes.data if a is not None else None
 
 
+def _device_matrix_ptr(t, n, device):
+    """Address of a device-resident N x N byte matrix (a contiguous uint8 or bool torch tensor on GPU ``device``)."""
+    if not getattr(t, "is_cuda", False) or t.device.index != device:
+        raise ValueError(f"the matrix must be a tensor on GPU {device}")
+    if tuple(t.shape) != (n, n) or t.element_size() != 1 or not t.is_contiguous():
+        raise ValueError("the matrix must be a contiguous N x N tensor of bytes")
+    return t.data_ptr()
+
+
 def default_device():
     return int(os.environ.get("LOCAL_RANK", "0")) % max(1, load().rt_device_count())
 
@@ -144,17 +153,24 @@ class Candidates:
         lib = require_gpu()
         self.scene = scene
         self.max_order = int(max_order)
-        vis = np.asarray(vis)
-        # (a bool matrix is passed as it is: of lln's 58 MB a copy takes longer than the enumeration)
-        vis8 = vis.view(np.uint8) if vis.dtype == np.bool_ and vis.flags.c_contiguous else np.ascontiguousarray(vis, dtype=np.uint8)
-        ev8 = np.ascontiguousarray(ev, dtype=np.uint8)
         n = scene.n
-        if vis8.shape != (n, n) or ev8.shape != (n,):
-            raise ValueError("visibility matrix / emitter visibility do not match the scene")
+        ev8 = np.ascontiguousarray(ev, dtype=np.uint8)
+        if hasattr(vis, "data_ptr"):
+            # a matrix that was painted into device memory (Scene.visibility_with_faces(matrix_out=...)) is read there
+            vis_ptr, on_device = _device_matrix_ptr(vis, n, scene.device), 1
+        else:
+            vis = np.asarray(vis)
+            # (a bool matrix is passed as it is: of lln's 58 MB a copy takes longer than the enumeration)
+            vis8 = vis.view(np.uint8) if vis.dtype == np.bool_ and vis.flags.c_contiguous else np.ascontiguousarray(vis, dtype=np.uint8)
+            if vis8.shape != (n, n):
+                raise ValueError("visibility matrix does not match the scene")
+            vis_ptr, on_device = _ptr(vis8), 0
+        if ev8.shape != (n,):
+            raise ValueError("emitter visibility does not match the scene")
         self.edge_pairs = np.ascontiguousarray(edge_pairs, dtype=np.int32).reshape(-1, 2)
         self.edges = _f64(edges).reshape(-1, 2, 3)
-        self.handle = lib.rt_enumerate(scene.handle, _ptr(vis8), _ptr(ev8), _ptr(self.edge_pairs), _ptr(self.edges),
-                                       len(self.edge_pairs), self.max_order, 1 if with_diffraction else 0)
+        self.handle = lib.rt_enumerate(scene.handle, vis_ptr, _ptr(ev8), _ptr(self.edge_pairs), _ptr(self.edges),
+                                       len(self.edge_pairs), self.max_order, 1 if with_diffraction else 0, on_device)
         if not self.handle:
             raise RtError(f"rt_enumerate: {lib.rt_last_error().decode()}")
         self.n_groups = lib.rt_candidates_group_count(self.handle)
@@ -348,9 +364,11 @@ class Scene:
                                           int(bool(strict)), _ptr(out)), "rt_faces_visibility")
         return out.astype(bool)
 
-    def visibility_with_faces(self, faces, row_ids=None, strict=False, faces_strict=False):
+    def visibility_with_faces(self, faces, row_ids=None, strict=False, faces_strict=False, matrix_out=None):
         """The visibility matrix (``row_ids`` None) or the listed unsymmetrised rows, and the visibility vectors of
-        ``faces`` (as ``faces_visibility`` takes them), painted side by side: returns (matrix or rows, face vectors)."""
+        ``faces`` (as ``faces_visibility`` takes them), painted side by side: returns (matrix or rows, face vectors).
+        ``matrix_out`` (whole matrix only): an N x N byte tensor on this scene's GPU that receives the matrix instead of
+        a host array; it is returned in the matrix's place and ``enumerate`` takes it as it is."""
         off = np.zeros(len(faces) + 1, dtype=np.int32)
         np.cumsum([len(f[0]) for f in faces], out=off[1:])
         verts = _f64(np.concatenate([np.asarray(f[0], dtype=float).reshape(-1, 3) for f in faces]))
@@ -358,16 +376,25 @@ class Scene:
         selfs = np.array([int(f[2]) for f in faces], dtype=np.int32)
         # (the library copies whole buffers out: nothing of them has to be cleared first)
         f_out = np.empty((len(faces), self.n), dtype=np.uint8)
-        if row_ids is None:
+        if matrix_out is not None:
+            if row_ids is not None:
+                raise ValueError("matrix_out goes with the whole matrix, not with row_ids")
+            rows, n_rows, r_ptr = None, 0, None
+            out_ptr = _device_matrix_ptr(matrix_out, self.n, self.device)
+        elif row_ids is None:
             rows, n_rows, r_ptr = None, 0, None
             r_out = np.empty((self.n, self.n), dtype=np.uint8)
+            out_ptr = _ptr(r_out)
         else:
             rows = np.ascontiguousarray(row_ids, dtype=np.int32)
             n_rows, r_ptr = len(rows), _ptr(rows)
             r_out = np.empty((len(rows), self.n), dtype=np.uint8)
-        _check(load().rt_visibility_with_faces(self.handle, n_rows, r_ptr, int(bool(strict)), _ptr(r_out), len(faces),
+            out_ptr = _ptr(r_out)
+        _check(load().rt_visibility_with_faces(self.handle, n_rows, r_ptr, int(bool(strict)), out_ptr, len(faces),
                                                _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs), int(bool(faces_strict)),
-                                               _ptr(f_out)), "rt_visibility_with_faces")
+                                               _ptr(f_out), 0 if matrix_out is None else 1), "rt_visibility_with_faces")
+        if matrix_out is not None:
+            return matrix_out, f_out.view(bool)
         return r_out.view(bool), f_out.view(bool)  # the kernels write 0 and 1 only: no copy
 
     def visibility_rows(self, row_ids, strict=False):

@@ -226,7 +226,7 @@ extern "C" int rt_channel_stats(int device, int64_t n_groups, const int64_t *gro
     if (n_strongest < 0 || !(power_percent > 0.0 && power_percent <= 1.0)) RT_FAIL("rt_channel_stats: bad parameter");
     if (n_groups == 0) return 0;
     if (n_groups > 0x7fffffffLL) RT_FAIL("rt_channel_stats: too many receivers");
-    RT_HIP(hipSetDevice(device));
+    RT_HIP(rt_use_device(device));
     int64_t n_paths = 0;
     int64_t *d_off = nullptr;
     double *d_val = nullptr, *d_out = nullptr, *d_dist = nullptr;

@@ -774,7 +774,7 @@ extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group,
     if (!path_group || !path_cand || !out_kind || !out_chain || !out_edge_polys || !out_edge_points)
         RT_FAIL("rt_describe_paths: null array");
     rt_scene *scene = cand->scene;
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     hipStream_t st = scene->stream;
     const int ng = (int)cand->groups.size();
     std::vector<int> h_refl(ng ? ng : 1), h_edge(ng ? ng : 1);
@@ -888,7 +888,7 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
                 RT_FAIL("rt_fields: edge polygon index out of range");
         }
     }
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     hipStream_t st = scene->stream;
     FreqTable ft{};
     ft.n_freq = n_freq;
@@ -1127,7 +1127,7 @@ extern "C" int rt_receiver_records(rt_scene *scene, int64_t n_rx, int32_t n_freq
     if (n_rx < 0 || n_paths < 0 || n_freq < 1) RT_FAIL("rt_receiver_records: bad size");
     if (n_rx == 0) return 0;
     if (!power_db || !out || (n_paths > 0 && (!path_rx || !path_kind))) RT_FAIL("rt_receiver_records: null array");
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     hipStream_t st = scene->stream;
     const int bytes = rt_receiver_record_bytes(n_freq);
     hipLaunchKernelGGL(k_records_start, dim3((unsigned)((n_rx + 255) / 256)), dim3(256), 0, st, n_rx, n_freq, power_db, out, bytes);

@@ -696,7 +696,7 @@ extern "C" int rt_obstruct_segments(rt_scene *scene, const double *segs, int64_t
     if (n_seg < 0) RT_FAIL("rt_obstruct_segments: negative count");
     if (n_seg == 0) return 0;
     if (!segs || !out) RT_FAIL("rt_obstruct_segments: null array");
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     if (on_device) {
         if (rt_launch_obstruct(scene, segs, n_seg, mask, n_seg, out, nullptr, 0, 0, nullptr, 0, true, nullptr, nullptr, nullptr)) return -1;
         RT_HIP(hipStreamSynchronize(scene->stream));
@@ -732,7 +732,7 @@ __global__ void k_segment_hits(SceneView sc, d3 A, d3 B, uint8_t *__restrict__ o
 
 extern "C" int rt_segment_hits(rt_scene *scene, const double *seg, uint8_t *out) {
     if (!scene || !seg || !out) RT_FAIL("rt_segment_hits: null argument");
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     uint8_t *d_out = nullptr;
     RT_HIP(hipMalloc(&d_out, scene->view.n));
     hipLaunchKernelGGL(k_segment_hits, dim3((scene->view.n + 255) / 256), dim3(256), 0, scene->stream, scene->view,
@@ -757,7 +757,7 @@ extern "C" int rt_contains_points(rt_scene *scene, int32_t polygon, const double
     if (n_points < 0) RT_FAIL("rt_contains_points: negative count");
     if (n_points == 0) return 0;
     if (!points || !out) RT_FAIL("rt_contains_points: null array");
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     const unsigned grid = (unsigned)((n_points + 255) / 256);
     if (on_device) {
         hipLaunchKernelGGL(k_contains, dim3(grid), dim3(256), 0, scene->stream, scene->view, polygon, points, n_points,
@@ -831,7 +831,7 @@ extern "C" int rt_obstruct_segments_noalloc(rt_scene *scene, const double *d_seg
     if (!d_segs || !d_out) RT_FAIL("rt_obstruct_segments_noalloc: null array");
     NoAllocScratch *scr = scene->device >= 0 && scene->device < RT_NOALLOC_MAX_DEVICES ? g_scratch_of_device[scene->device] : nullptr;
     if (!scr) RT_FAIL("rt_obstruct_segments_noalloc: no scratch array on device " + std::to_string(scene->device));
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     hipStream_t st = (hipStream_t)stream;
     const int block = 256;
     int64_t grid = (n_seg + block - 1) / block;

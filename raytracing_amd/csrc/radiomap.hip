@@ -120,7 +120,7 @@ extern "C" int rt_radiomap(int device, int64_t n_points, const double *values, i
     int ndev = 0;
     RT_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) RT_FAIL("rt_radiomap: no such device");
-    RT_HIP(hipSetDevice(device));
+    RT_HIP(rt_use_device(device));
     Buf d_query, d_values, d_tris, d_transform, d_recs, d_out, d_ring, d_inside;
     if (d_query.alloc(sizeof(double) * 2 * n_query)) RT_FAIL("rt_radiomap: out of device memory");
     RT_HIP(hipMemcpy(d_query.p, query, sizeof(double) * 2 * n_query, hipMemcpyHostToDevice));

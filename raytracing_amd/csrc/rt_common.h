@@ -26,6 +26,15 @@ void rt_set_error(const std::string &msg);
         }                                                                                                 \
     } while (0)
 
+// Makes `device` current and forgets an error that another user of the HIP runtime in this process left behind:
+// hipGetLastError reports the last failure of any call on the thread (PyTorch's included) until somebody reads it, and a
+// check after one of this library's launches must speak of that launch only.
+static inline hipError_t rt_use_device(int device) {
+    const hipError_t e = hipSetDevice(device);
+    (void)hipGetLastError();
+    return e;
+}
+
 #define RT_HIP_NULL(call)                                                                                 \
     do {                                                                                                  \
         hipError_t e_ = (call);                                                                           \

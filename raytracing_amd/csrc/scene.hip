@@ -216,7 +216,7 @@ extern "C" int rt_scene_set_timing(rt_scene *s, int on) {
 
 extern "C" int rt_scene_wait_for_stream(rt_scene *s, void *stream) {
     if (!s) RT_FAIL("rt_scene_wait_for_stream: null scene");
-    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(rt_use_device(s->device));
     if (!s->caller_event) RT_HIP(hipEventCreateWithFlags(&s->caller_event, hipEventDisableTiming));
     RT_HIP(hipEventRecord(s->caller_event, static_cast<hipStream_t>(stream)));
     RT_HIP(hipStreamWaitEvent(s->stream, s->caller_event, 0));
@@ -231,7 +231,7 @@ extern "C" int rt_scene_set_deferred_sync(rt_scene *s, int on) {
 
 extern "C" int rt_scene_synchronize(rt_scene *s) {
     if (!s) RT_FAIL("rt_scene_synchronize: null scene");
-    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(rt_use_device(s->device));
     RT_HIP(hipStreamSynchronize(s->stream));
     if (s->fields_events_pending && s->event_pool.size() >= 4) {
         float t = 0;
@@ -272,7 +272,7 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
             return nullptr;
         }
     }
-    RT_HIP_NULL(hipSetDevice(device));
+    RT_HIP_NULL(rt_use_device(device));
     g_pending.clear();
     g_pending_copies.clear();
     rt_scene *s = new rt_scene();
@@ -370,7 +370,7 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
 
 extern "C" void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
-    (void)hipSetDevice(s->device);
+    (void)rt_use_device(s->device);
     if (s->caller_event) (void)hipEventDestroy(s->caller_event);
     if (s->side_event) (void)hipEventDestroy(s->side_event);
     if (s->side_stream) {

@@ -98,7 +98,7 @@ extern "C" int rt_sharp_edges(rt_scene *scene, double min_angle_deg, int32_t *pa
                               int64_t *count) {
     if (!scene || !count) RT_FAIL("rt_sharp_edges: null argument");
     if (capacity < 0 || (capacity > 0 && (!pairs || !edges))) RT_FAIL("rt_sharp_edges: bad output arrays");
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     const int n = scene->view.n;
     if (n > 65535) RT_FAIL("rt_sharp_edges: more than 65535 polygons");
     int64_t cap = std::max<int64_t>(capacity, 2 * (int64_t)scene->view.vtot + 16);

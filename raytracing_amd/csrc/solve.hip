@@ -256,7 +256,7 @@ static const int64_t MAX_GROUP_CANDIDATES = (1ll << 31) - 1;
 
 extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, const uint8_t *ev,
                                        const int32_t *edge_pairs, const double *edges, int64_t n_edges,
-                                       int32_t max_order, int with_diffraction) {
+                                       int32_t max_order, int with_diffraction, int vis_on_device) {
     if (!scene || !vis || !ev) {
         rt_set_error("rt_enumerate: null argument");
         return nullptr;
@@ -276,7 +276,7 @@ extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, cons
             return nullptr;
         }
     }
-    if (hipSetDevice(scene->device) != hipSuccess) {
+    if (rt_use_device(scene->device) != hipSuccess) {
         rt_set_error("rt_enumerate: hipSetDevice failed");
         return nullptr;
     }
@@ -288,11 +288,16 @@ extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, cons
     const int n_groups = max_order == 0 ? 0 : 2 * max_order;
     c->groups.resize(n_groups);
 
-    uint8_t *d_vis = cand_alloc<uint8_t>(c, (size_t)n * n);
-    CAND_CHECK(d_vis);
+    // a matrix already on this GPU is read where it lies (only inside this call: the candidates keep no pointer to it)
+    const uint8_t *d_vis = vis;
+    if (!vis_on_device) {
+        uint8_t *copy = cand_alloc<uint8_t>(c, (size_t)n * n);
+        CAND_CHECK(copy);
+        CAND_HIP(hipMemcpyAsync(copy, vis, (size_t)n * n, hipMemcpyHostToDevice, st));
+        d_vis = copy;
+    }
     c->d_ev = cand_alloc<uint8_t>(c, n);
     CAND_CHECK(c->d_ev);
-    CAND_HIP(hipMemcpyAsync(d_vis, vis, (size_t)n * n, hipMemcpyHostToDevice, st));
     CAND_HIP(hipMemcpyAsync(c->d_ev, ev, n, hipMemcpyHostToDevice, st));
     c->d_edges = cand_alloc<double>(c, 6 * (size_t)n_edges);
     c->d_edge_pairs = cand_alloc<int32_t>(c, 2 * (size_t)n_edges);
@@ -450,7 +455,7 @@ extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, cons
 
 extern "C" void rt_candidates_destroy(rt_candidates *c) {
     if (!c) return;
-    if (c->scene) (void)hipSetDevice(c->scene->device);
+    if (c->scene) (void)rt_use_device(c->scene->device);
     for (void *p : c->allocations) (void)hipFree(p);
     delete c;
 }
@@ -467,7 +472,7 @@ extern "C" int rt_candidates_group(const rt_candidates *c, int32_t group, int32_
     if (!c) RT_FAIL("rt_candidates_group: null handle");
     if (group < 0 || group >= (int)c->groups.size()) RT_FAIL("rt_candidates_group: group out of range");
     const CandGroup &g = c->groups[group];
-    RT_HIP(hipSetDevice(c->scene->device));
+    RT_HIP(rt_use_device(c->scene->device));
     if (chains && g.n_refl > 0 && g.count > 0) {
         if (g.chains) {
             RT_HIP(hipMemcpy(chains, g.chains, sizeof(int32_t) * g.count * g.n_refl, hipMemcpyDeviceToHost));
@@ -1646,7 +1651,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     if (n_rx > 0 && !rx) RT_FAIL("rt_solve_paths: null receivers");
     if (capacity > 0 && (!out_rx || !out_group || !out_cand || !out_points)) RT_FAIL("rt_solve_paths: null output");
     if (n_rx > 0x7fffffffLL) RT_FAIL("rt_solve_paths: too many receivers");
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     hipStream_t st = scene->stream;
     const d3 TX = ld3(tx);
     const int n = scene->view.n;
@@ -2093,7 +2098,7 @@ static int solve_standalone(int device, const double *origin, const double *dest
     if (!origin || (n_dest > 0 && (!dests || !out_points || !out_ok))) RT_FAIL("rt_solve_*: null argument");
     if (k < 0 || k > RT_MAX_ORDER || (k > 0 && !planes)) RT_FAIL("rt_solve_*: bad plane count");
     if (n_dest <= 0) return 0;
-    RT_HIP(hipSetDevice(device));
+    RT_HIP(rt_use_device(device));
     const int npts = k + (edge ? 1 : 0);
     if (npts == 0) RT_FAIL("rt_solve_*: nothing to solve");
     double *d_dest = nullptr, *d_planes = nullptr, *d_edge = nullptr, *d_out = nullptr;

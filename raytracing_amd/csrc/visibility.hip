@@ -2182,7 +2182,7 @@ extern "C" int rt_faces_visibility(rt_scene *scene, int32_t n_faces, const int32
         if (self_index && (self_index[f] < -1 || self_index[f] >= scene->view.n))
             RT_FAIL("rt_faces_visibility: self_index out of range");
     }
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     std::vector<int32_t> a_off(face_off, face_off + n_faces + 1), a_self(n_faces, -1);
     if (self_index) a_self.assign(self_index, self_index + n_faces);
     std::vector<double> a_verts(face_verts, face_verts + 3 * (size_t)face_off[n_faces]);
@@ -2209,7 +2209,7 @@ extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t
     if (n_rows < 0) RT_FAIL("rt_visibility_rows: negative count");
     if (n_rows == 0) return 0;
     const int n = scene->view.n;
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     for (int k = 0; k < n_rows; ++k)
         if (row_ids[k] < 0 || row_ids[k] >= n) RT_FAIL("rt_visibility_rows: row index out of range");
     DevBuf d_out;
@@ -2241,7 +2241,7 @@ extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t
 
 extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_device) {
     if (!scene || !out) RT_FAIL("rt_visibility_matrix: null argument");
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     const SceneView &sc = scene->view;
     const int n = sc.n;
     DevBuf d_rows, d_sym;
@@ -2285,15 +2285,19 @@ extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, i
 // screens occupy a few compute units for as long as the whole matrix takes the rest of the chip, so the screens are
 // painted on a stream of their own while the matrix is painted on the scene's.
 // row_ids null: rows_out[N*N] = the symmetrised matrix (rt_visibility_matrix); otherwise rows_out[n_rows*N] = the
-// listed rows as rt_visibility_rows gives them.
+// listed rows as rt_visibility_rows gives them.  rows_on_device (whole matrix only): rows_out is device memory of the
+// scene's GPU and the matrix never visits the host -- copying lln's 58 MB into pageable memory takes 33 ms, a sixth of
+// what painting it takes, and rt_enumerate can read it where it lies.
 extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict,
                                         uint8_t *rows_out, int32_t n_faces, const int32_t *face_off,
                                         const double *face_verts, const double *face_normals, const int32_t *self_index,
-                                        int faces_strict, uint8_t *faces_out) {
+                                        int faces_strict, uint8_t *faces_out, int rows_on_device) {
     if (!scene || !rows_out) RT_FAIL("rt_visibility_with_faces: null argument");
     if (n_faces < 0 || (row_ids && n_rows < 0)) RT_FAIL("rt_visibility_with_faces: negative count");
+    if (row_ids && rows_on_device) RT_FAIL("rt_visibility_with_faces: only the whole matrix can stay on the device");
+    rows_on_device = rows_on_device ? 1 : 0;
     if (n_faces == 0) return row_ids ? rt_visibility_rows(scene, n_rows, row_ids, strict, rows_out)
-                                     : rt_visibility_matrix(scene, strict, rows_out, 0);
+                                     : rt_visibility_matrix(scene, strict, rows_out, rows_on_device);
     if (!face_off || !face_verts || !face_normals || !faces_out) RT_FAIL("rt_visibility_with_faces: null argument");
     if (n_faces > 65535) RT_FAIL("rt_visibility_with_faces: at most 65535 faces per call");
     if (face_off[0] != 0) RT_FAIL("rt_visibility_with_faces: face_off must start at 0");
@@ -2302,7 +2306,7 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
         if (self_index && (self_index[f] < -1 || self_index[f] >= scene->view.n))
             RT_FAIL("rt_visibility_with_faces: self_index out of range");
     }
-    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt_use_device(scene->device));
     // a second stream of the default priority (streams of different priorities are not used anywhere in this library)
     if (!scene->side_stream) RT_HIP(hipStreamCreateWithFlags(&scene->side_stream, hipStreamNonBlocking));
     const size_t n = (size_t)scene->view.n;
@@ -2317,7 +2321,7 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
                                      (uint8_t *)d_faces.p, job);
     if (rc == 0)
         rc = row_ids ? rt_visibility_rows(scene, n_rows, row_ids, strict, rows_out)
-                     : rt_visibility_matrix(scene, strict, rows_out, 0);
+                     : rt_visibility_matrix(scene, strict, rows_out, rows_on_device);
     const hipError_t e = hipStreamSynchronize(scene->side_stream);
     for (int k = 4; k < 8; ++k) scene->last_vis_ms[k] = 0;
     if (rc == 0 && e == hipSuccess) job.add_times(scene->last_vis_ms + 4);

@@ -106,16 +106,23 @@ def gather_visibility_rows(rows_of, n, dist=None):
     return (rows | rows.T).cpu().numpy().astype(bool)
 
 
-def sharded_visibility(scene, screens, strict=False, dist=None):
+def sharded_visibility(scene, screens, strict=False, dist=None, on_device=False):
     """The visibility matrix of ``scene`` and the visibility vectors of the emitter's ``screens`` (as
     ``Scene.faces_visibility`` takes them) with the work dealt to the ranks: the matrix rows AND the screens are rows
     of one list, dealt out interleaved, each rank painting its matrix rows and its screens side by side; one
     all-gather.  A screen of a large scene costs as much as hundreds of matrix rows, so the screens must not be
-    repeated on every rank.  Returns (matrix bool [N, N], screen vectors bool [len(screens), N])."""
+    repeated on every rank.  Returns (matrix bool [N, N], screen vectors bool [len(screens), N]); with ``on_device`` the
+    matrix is a byte tensor on the scene's GPU instead, which ``Scene.enumerate`` reads there (the matrix of a large
+    scene takes longer to bring to the host than a sixth of its painting, and nothing on the host needs it)."""
     n = scene.n
     dist = dist or _dist()
     if dist is None or dist.get_world_size() == 1:
         # one rank paints everything: matrix (symmetrised on the device) and screens side by side
+        if on_device:
+            import torch
+
+            matrix = torch.empty((n, n), dtype=torch.uint8, device=torch.device("cuda", scene.device))
+            return scene.visibility_with_faces(screens, strict=strict, matrix_out=matrix)
         return scene.visibility_with_faces(screens, strict=strict)
 
     def rows_of(ids):
@@ -136,6 +143,12 @@ def sharded_visibility(scene, screens, strict=False, dist=None):
     rows = _gather_dealt_rows_tensor(rows_of, n + len(screens), n, dist)
     matrix = rows[:n]
     matrix = matrix | matrix.T
+    if on_device:
+        import torch
+
+        matrix = matrix.to(torch.device("cuda", scene.device)).contiguous()
+        torch.cuda.synchronize(matrix.device)  # the library reads it on a stream of its own
+        return matrix, rows[n:].cpu().numpy().astype(bool)
     return matrix.cpu().numpy().astype(bool), rows[n:].cpu().numpy().astype(bool)
 
 

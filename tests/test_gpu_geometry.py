@@ -372,6 +372,30 @@ def test_matrix_and_screens_in_one_call_equal_the_separate_calls(places, name):
     r0, v4 = scene.visibility_with_faces(screens, row_ids=np.zeros(0, np.int32))
     assert r0.shape == (0, len(polygons))
     np.testing.assert_array_equal(v4, vectors)
+    # the matrix left in device memory is the same matrix, and the candidates enumerated from it there are those
+    # enumerated from the host's copy
+    import torch
+
+    n = len(polygons)
+    d_matrix = torch.full((n, n), 7, dtype=torch.uint8, device=f"cuda:{scene.device}")
+    m5, v5 = scene.visibility_with_faces(screens, matrix_out=d_matrix)
+    assert m5 is d_matrix
+    np.testing.assert_array_equal(d_matrix.cpu().numpy().astype(bool), matrix)
+    np.testing.assert_array_equal(v5, vectors)
+    ev = np.logical_or.reduce(vectors)
+    pairs, edges = scene.sharp_edges()
+    from_host = scene.enumerate(matrix, ev, pairs, edges, 2)
+    from_device = scene.enumerate(d_matrix, ev, pairs, edges, 2)
+    np.testing.assert_array_equal(from_device.counts, from_host.counts)
+    assert from_host.counts.sum() > 0
+    for g in range(from_host.n_groups):
+        a, b = from_host.group(g), from_device.group(g)
+        np.testing.assert_array_equal(b[0], a[0])
+        np.testing.assert_array_equal(b[1], a[1])
+    with pytest.raises(ValueError):
+        scene.visibility_with_faces(screens, row_ids=ids, matrix_out=d_matrix)
+    with pytest.raises(ValueError):
+        scene.enumerate(d_matrix[:-1], ev, pairs, edges, 2)
     scene.close()
 
 
