@@ -256,12 +256,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     pg = None
-    if world > 1:
+    # (RT_BENCH_GROUP=1 with WORLD_SIZE=1 sets the process group up for one rank as well: a rehearsal of the RCCL
+    # branches -- device-tensor gathers, barriers, reductions -- on a box with one GPU)
+    use_group = world > 1 or os.environ.get("RT_BENCH_GROUP") == "1"
+    if use_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL writes a version banner to stdout when its first communicator comes up; stdout carries the one JSON line
+        # and nothing else, so file descriptor 1 points at stderr until the group has done its first collective
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.init_process_group(args.backend)
+                dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         pg = dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -272,7 +290,7 @@ def main():
     from raytracing_amd import multithread_solve as mts
 
     def barrier():
-        if world > 1:
+        if use_group:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -360,7 +378,7 @@ def main():
     segments /= n_ev
     rec = dp.unpack_records(records.cpu().numpy(), 1)
     attempted_local = float(block.n_attempted)
-    if world > 1:
+    if use_group:
         cdev = dev if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed, precompute_s], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -422,7 +440,7 @@ def main():
                        "candidates_per_receiver": 1 + int(sum(counts)), "candidates_by_group": counts,
                        "path_solves_per_step": int(attempted_all), "valid_paths_rank0": int(block.n_paths),
                        "valid_paths_all_gpus": int(rec["n_paths"].sum()), "frequency_hz": FREQUENCY_HZ,
-                       "record_bytes_per_receiver": dp.record_bytes(1), "backend": args.backend if world > 1 else None},
+                       "record_bytes_per_receiver": dp.record_bytes(1), "backend": args.backend if use_group else None},
             "coverage_map_wall_s": round(precompute_s + ms_step * 1e-3, 4),
             "coverage_map": {"precompute_s": round(precompute_s, 4), "precompute_breakdown_rank0": stamps,
                              "visibility_kernels_ms_rank0": vis_timing, "step_s": round(ms_step * 1e-3, 5),
@@ -448,10 +466,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(place, tx, rx, chains2)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)  # (flushed: nothing after this line may cost the line)
     cand.close()
     scene.close()
-    if world > 1:
+    if use_group:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -183,7 +183,7 @@ def all_gather_records(local, n_total, dist=None):
 
     from .multithread_solve import shard_bounds
 
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None:
         assert local.shape[0] == n_total
         return local
     world = dist.get_world_size()
