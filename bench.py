@@ -309,27 +309,22 @@ def main():
     polygons = place.get_polygons_list()
     arrays = geom.scene_arrays_of(polygons)
     t = stamp("scene_file_s", t_wall)
+    # the receivers of the map are placed (host work: a lattice minus the buildings' footprints) on a second thread while
+    # the scene goes to the GPU and the GPU paints: the library calls release the interpreter lock.  The thread makes no
+    # GPU call and no collective (with several ranks the painting ends in an all-gather, which stays on this thread).
+    import threading
+
+    made = {}
+    worker = threading.Thread(target=lambda: made.update(rx=scenarios.lattice_receivers(place, args.n_side, 1.5)))
+    worker.start()
     scene = _lib.Scene(arrays, device=local_rank)
     pairs, edges = scene.sharp_edges()
     t = stamp("device_scene_and_sharp_edges_s", t)
     cube = geom.Cube.by_point_and_side_length(tx, 0.2)
     screens = [(s.points, s.get_parametric(), -1) for s in cube.polygons]
-    # the receivers of the map are placed (host work: a lattice minus the buildings' footprints) while the GPU paints
-    # the matrix: the library call releases the interpreter lock.  With several ranks the painting ends in a
-    # collective, which stays on the main thread; the lattice is then made first.
-    if world == 1:
-        import threading
-
-        made = {}
-        worker = threading.Thread(target=lambda: made.update(rx=scenarios.lattice_receivers(place, args.n_side, 1.5)))
-        worker.start()
-        vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg, on_device=True)
-        worker.join()
-        rx = made["rx"]
-    else:
-        rx = scenarios.lattice_receivers(place, args.n_side, 1.5)
-        t = stamp("receiver_lattice_s", t)
-        vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg, on_device=True)
+    vis, screen_vis = mts.sharded_visibility(scene, screens, dist=pg, on_device=True)
+    worker.join()
+    rx = made["rx"]
     vis_timing = scene.visibility_timing()
     ev = np.logical_or.reduce(screen_vis)
     t = stamp("visibility_matrix_and_emitter_screens_s", t)
