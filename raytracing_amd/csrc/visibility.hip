@@ -2025,13 +2025,27 @@ struct RowsJob {
     }
 };
 
+// Faces f0 .. f0 + n_faces - 1 of the scene itself as a batch: offsets from the first of them, unit normals, own indices
+// (their vertices are the scene's, in place).
+__global__ void k_scene_faces(SceneView sc, int f0, int n_faces, int32_t *off, double *normal, int32_t *self) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f > n_faces) return;
+    off[f] = sc.vert_off[f0 + f] - sc.vert_off[f0];
+    if (f == n_faces) return;
+    for (int k = 0; k < 3; ++k) normal[3 * f + k] = sc.planes[4 * (size_t)(f0 + f) + k];
+    self[f] = f0 + f;
+}
+
 // Queues, on stream st, the kernels that write the visibility rows of a batch of faces into d_out[n_faces*n] (zeroed
-// here).  Nothing is waited for: the caller synchronises st before it lets go of job and of the host arrays.
+// here).  scene_f0 >= 0: the batch is the scene's own faces scene_f0 .. scene_f0 + scene_count - 1, taken from the
+// device's copy of the scene (the host arrays are not looked at: nothing of the geometry crosses the bus again).  Nothing is waited for: the caller synchronises st before it lets go of job and of the host arrays.
 static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::vector<int32_t> &a_off,
                                    const std::vector<double> &a_verts, const std::vector<double> &a_normal,
-                                   const std::vector<int32_t> &a_self, int strict, uint8_t *d_out, RowsJob &job) {
+                                   const std::vector<int32_t> &a_self, int strict, uint8_t *d_out, RowsJob &job,
+                                   int scene_f0 = -1, int scene_count = 0) {
     const SceneView &sc = scene->view;
-    const int n_faces = (int)a_self.size();
+    const bool resident = scene_f0 >= 0;
+    const int n_faces = resident ? scene_count : (int)a_self.size();
     if (n_faces == 0) return 0;
     DevBuf &b_off = job.b_off, &b_verts = job.b_verts, &b_normal = job.b_normal, &b_self = job.b_self, &b_sph = job.b_sph,
            &b_meta = job.b_meta, &b_list = job.b_list, &b_canvas = job.b_canvas, &b_cbox = job.b_cbox, &b_splits = job.b_splits,
@@ -2046,8 +2060,8 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     // few faces: sixteen waves per face (the canvas edges of a candidate are dealt to them), otherwise four
     const int waves_per_face = n_faces <= 256 ? 16 : 4;
     const size_t n_waves = (size_t)n_blocks * waves_per_face;
-    if (b_off.alloc(sizeof(int32_t) * a_off.size()) || b_verts.alloc(sizeof(double) * a_verts.size()) ||
-        b_normal.alloc(sizeof(double) * a_normal.size()) || b_self.alloc(sizeof(int32_t) * a_self.size()) ||
+    if (b_off.alloc(sizeof(int32_t) * ((size_t)n_faces + 1)) || (!resident && b_verts.alloc(sizeof(double) * a_verts.size())) ||
+        b_normal.alloc(sizeof(double) * 3 * (size_t)n_faces) || b_self.alloc(sizeof(int32_t) * (size_t)n_faces) ||
         b_sph.alloc(sizeof(double) * 2 * (size_t)sc.vtot * n_faces) || b_meta.alloc(sizeof(PolyMeta) * (size_t)sc.n * n_faces) ||
         b_list.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) || b_canvas.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) ||
         b_cbox.alloc(sizeof(double) * 4 * (size_t)sc.n * n_blocks) || b_splits.alloc(sizeof(double) * (size_t)split_cap * n_waves) ||
@@ -2057,10 +2071,20 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         job.b_bounds.alloc(sizeof(double) * (VIS_MAX_TILES + 1) * (size_t)n_faces) ||
         job.b_ntiles.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_itemoff.alloc(sizeof(int32_t) * ((size_t)n_faces + 1)))
         RT_FAIL("visibility: out of device memory");
-    RT_HIP(hipMemcpyAsync(b_off.p, a_off.data(), sizeof(int32_t) * a_off.size(), hipMemcpyHostToDevice, st));
-    RT_HIP(hipMemcpyAsync(b_verts.p, a_verts.data(), sizeof(double) * a_verts.size(), hipMemcpyHostToDevice, st));
-    RT_HIP(hipMemcpyAsync(b_normal.p, a_normal.data(), sizeof(double) * a_normal.size(), hipMemcpyHostToDevice, st));
-    RT_HIP(hipMemcpyAsync(b_self.p, a_self.data(), sizeof(int32_t) * a_self.size(), hipMemcpyHostToDevice, st));
+    const double *d_face_verts;
+    if (resident) {
+        hipLaunchKernelGGL(k_scene_faces, dim3((n_faces + 256) / 256), dim3(256), 0, st, sc, scene_f0, n_faces,
+                           (int32_t *)b_off.p, (double *)b_normal.p, (int32_t *)b_self.p);
+        d_face_verts = sc.verts + 3 * (size_t)scene->h_vert_off[scene_f0];
+    } else {
+        if (a_off.size() != (size_t)n_faces + 1 || a_normal.size() != 3 * (size_t)n_faces)
+            RT_FAIL("visibility: face arrays of different lengths");
+        RT_HIP(hipMemcpyAsync(b_off.p, a_off.data(), sizeof(int32_t) * a_off.size(), hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(b_verts.p, a_verts.data(), sizeof(double) * a_verts.size(), hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(b_normal.p, a_normal.data(), sizeof(double) * a_normal.size(), hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(b_self.p, a_self.data(), sizeof(int32_t) * a_self.size(), hipMemcpyHostToDevice, st));
+        d_face_verts = (const double *)b_verts.p;
+    }
     // the polygons that are prepared one per wave
     // the polygons that are not prepared one per thread by k_vis_prepare, by size: up to 8, 16 and VIS_MID_POLY vertices
     // (a thread per face with the polygon shared by the wave), then the rest (a wave per polygon)
@@ -2080,8 +2104,7 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     if (!big.empty()) RT_HIP(hipMemcpyAsync(job.b_big.p, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemsetAsync(b_counter.p, 0, sizeof(unsigned long long), st));
     RT_HIP(hipMemsetAsync(d_out, 0, (size_t)sc.n * n_faces, st));
-    FaceBatch fb{n_faces, (const int32_t *)b_off.p, (const double *)b_verts.p, (const double *)b_normal.p,
-                 (const int32_t *)b_self.p};
+    FaceBatch fb{n_faces, (const int32_t *)b_off.p, d_face_verts, (const double *)b_normal.p, (const int32_t *)b_self.p};
     if (scene->timing) {
         for (hipEvent_t &e : job.ev) RT_HIP(hipEventCreate(&e));
         RT_HIP(hipEventRecord(job.ev[0], st));
@@ -2159,9 +2182,10 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
 // times are added to ms4 (mapping, sorting, painting, all)
 static int visibility_rows(rt_scene *scene, const std::vector<int32_t> &a_off, const std::vector<double> &a_verts,
                            const std::vector<double> &a_normal, const std::vector<int32_t> &a_self, int strict,
-                           uint8_t *d_out, double *ms4) {
+                           uint8_t *d_out, double *ms4, int scene_f0 = -1, int scene_count = 0) {
     RowsJob job;
-    if (visibility_rows_enqueue(scene, scene->stream, a_off, a_verts, a_normal, a_self, strict, d_out, job)) {
+    if (visibility_rows_enqueue(scene, scene->stream, a_off, a_verts, a_normal, a_self, strict, d_out, job, scene_f0,
+                                scene_count)) {
         (void)hipStreamSynchronize(scene->stream);
         return -1;
     }
@@ -2254,18 +2278,11 @@ extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, i
     for (int k = 0; k < 4; ++k) scene->last_vis_ms[k] = 0;
     for (int f0 = 0; f0 < n; f0 += batch) {
         const int f1 = std::min(n, f0 + batch);
-        std::vector<int32_t> a_off, a_self;
-        std::vector<double> a_verts, a_normal;
-        a_off.push_back(0);
-        for (int f = f0; f < f1; ++f) {
-            const int v0 = scene->h_vert_off[f], v1 = scene->h_vert_off[f + 1];
-            a_verts.insert(a_verts.end(), scene->h_verts.begin() + 3 * (size_t)v0, scene->h_verts.begin() + 3 * (size_t)v1);
-            a_off.push_back((int32_t)(a_verts.size() / 3));
-            a_normal.insert(a_normal.end(), scene->h_planes.begin() + 4 * (size_t)f, scene->h_planes.begin() + 4 * (size_t)f + 3);
-            a_self.push_back(f);
-        }
-        if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_rows.p + (size_t)f0 * n,
-                            scene->last_vis_ms))
+        // the faces are the scene's own polygons: read from the device's copy of the scene
+        const std::vector<int32_t> no_ints;
+        const std::vector<double> no_doubles;
+        if (visibility_rows(scene, no_ints, no_doubles, no_doubles, no_ints, strict, (uint8_t *)d_rows.p + (size_t)f0 * n,
+                            scene->last_vis_ms, f0, f1 - f0))
             return -1;
     }
     uint8_t *d_dst = out;
