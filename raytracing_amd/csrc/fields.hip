@@ -639,54 +639,71 @@ __global__ __launch_bounds__(1024) void k_rx_offsets(const int32_t *__restrict__
     }
     if (threadIdx.x == 0) off[n_rx] = carry;
 }
+// What the reference's row order looks at, per path, in the order it looks at it: kind (0 line of sight, 1.. reflections,
+// 256.. diffractions by the reflections before them), the reflecting polygons, the edge's two polygons, and the path's
+// own index last.  Entries a kind does not have are zero, so that the order is the lexicographic order of the eight.
+struct PathKey {
+    int32_t v[8];
+};
+static_assert(RT_MAX_ORDER == 4, "PathKey holds kind, four chain entries, two edge polygons and the index");
 __global__ void k_rx_path_fill(PathArrays pa, const int64_t *__restrict__ off, int32_t *__restrict__ cursor,
-                               int32_t *__restrict__ order) {
+                               int32_t *__restrict__ order, PathKey *__restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pa.n) return;
     const int r = pa.rx[i];
-    order[off[r] + atomicAdd(&cursor[r], 1)] = (int32_t)i;
+    const int64_t slot = off[r] + atomicAdd(&cursor[r], 1);
+    order[slot] = (int32_t)i;
+    PathKey key;
+    const int kind = pa.kind[i], n_refl = kind & 255;
+    key.v[0] = kind;
+    for (int k = 0; k < RT_MAX_ORDER; ++k) key.v[1 + k] = k < n_refl ? pa.chain[(size_t)i * RT_MAX_ORDER + k] : 0;
+    for (int k = 0; k < 2; ++k) key.v[5 + k] = (kind >> 8) ? pa.edge_polys[2 * (size_t)i + k] : 0;
+    key.v[7] = (int32_t)i;
+    keys[slot] = key;
 }
-// is path a before path b in the reference's row order?
-__device__ inline bool path_before(const PathArrays &pa, int a, int b) {
-    const int ka = pa.kind[a], kb = pa.kind[b];
-    if (ka != kb) return ka < kb;  // 0 line of sight, 1.. reflections, 256.. diffractions by reflections before them
-    const int n_refl = ka & 255;
-    for (int k = 0; k < n_refl; ++k) {
-        const int ca = pa.chain[(size_t)a * RT_MAX_ORDER + k], cb = pa.chain[(size_t)b * RT_MAX_ORDER + k];
-        if (ca != cb) return ca < cb;
-    }
-    if (ka >> 8) {
-        for (int k = 0; k < 2; ++k) {
-            const int ea = pa.edge_polys[2 * (size_t)a + k], eb = pa.edge_polys[2 * (size_t)b + k];
-            if (ea != eb) return ea < eb;
-        }
-    }
-    return a < b;
+__device__ inline bool key_before(const PathKey &a, const PathKey &b) {
+    for (int k = 0; k < 7; ++k)
+        if (a.v[k] != b.v[k]) return a.v[k] < b.v[k];
+    return a.v[7] < b.v[7];
 }
 // place of every path among its receiver's paths in that order: one thread per path counts the paths before it (a
-// receiver has a handful to a few hundred), instead of one thread per receiver sorting its list
-__global__ void k_rx_path_rank(PathArrays pa, const int64_t *__restrict__ off, const int32_t *__restrict__ unordered,
+// receiver has a handful to a few hundred), instead of one thread per receiver sorting its list.  Threads go by the
+// place in the unordered list, so that neighbouring lanes are paths of the same receiver and read the same keys, which
+// lie one after the other (reading kind, chain and edge of the other path through its index took three times as long).
+__global__ void k_rx_path_rank(PathArrays pa, const int64_t *__restrict__ off, const PathKey *__restrict__ keys,
                                int32_t *__restrict__ ordered) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pa.n) return;
-    const int r = pa.rx[i];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pa.n) return;
+    const PathKey mine = keys[t];
+    const int r = pa.rx[mine.v[7]];
     const int64_t b = off[r], e = off[r + 1];
     int rank = 0;
     for (int64_t q = b; q < e; ++q) {
-        const int other = unordered[q];
-        if (other != (int)i && path_before(pa, other, (int)i)) ++rank;
+        const PathKey other = keys[q];
+        if (key_before(other, mine)) ++rank;
     }
-    ordered[b + rank] = (int32_t)i;
+    ordered[b + rank] = mine.v[7];
 }
-__global__ void k_rx_power_sum(const int64_t *__restrict__ off, const int32_t *__restrict__ ordered, int64_t n_rx, int n_freq,
-                               const double *__restrict__ power, double *__restrict__ power_sum) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_rx * n_freq) return;
-    const int64_t r = t / n_freq;
-    const int f = (int)(t - r * n_freq);
-    double sum = 0.0;
-    for (int64_t q = off[r]; q < off[r + 1]; ++q) sum += power[(size_t)ordered[q] * n_freq + f];
-    power_sum[t] = sum;
+// Sum of the powers of a receiver's paths in row order (the order fixes the rounding): one wave per receiver, the lanes
+// fetch 64 powers at once, the additions go one after the other on values handed round from lane to lane.
+__global__ __launch_bounds__(256) void k_rx_power_sum(const int64_t *__restrict__ off, const int32_t *__restrict__ ordered,
+                                                       int64_t n_rx, int n_freq, const double *__restrict__ power,
+                                                       double *__restrict__ power_sum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rx) return;  // (whole waves leave)
+    const int64_t b = off[r], e = off[r + 1];
+    for (int f = 0; f < n_freq; ++f) {
+        double sum = 0.0;
+        for (int64_t base = b; base < e; base += 64) {
+            const int cnt = (int)(e - base < 64 ? e - base : 64);
+            const double v = lane < cnt ? power[(size_t)ordered[base + lane] * n_freq + f] : 0.0;
+            const int v_lo = __double2loint(v), v_hi = __double2hiint(v);
+            for (int q = 0; q < cnt; ++q)
+                sum += __hiloint2double(__builtin_amdgcn_readlane(v_hi, q), __builtin_amdgcn_readlane(v_lo, q));
+        }
+        if (lane == 0) power_sum[r * n_freq + f] = sum;
+    }
 }
 
 #define STATUS_UNSET 0x7f7f7f7f /* what hipMemset(0x7f) leaves: larger than any (frequency, status) key */
@@ -997,11 +1014,12 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
     int32_t *rx_counts = (int32_t *)dalloc(sizeof(int32_t) * 2 * n_rx);
     int64_t *rx_off = (int64_t *)dalloc(sizeof(int64_t) * (n_rx + 1));
     int32_t *rx_order = (int32_t *)dalloc(sizeof(int32_t) * 2 * np_);  // as filled, then in the reference's order
+    PathKey *rx_keys = (PathKey *)dalloc(sizeof(PathKey) * np_);
     int32_t *cls_lists = (int32_t *)dalloc(sizeof(int32_t) * 3 * np_);
     TreeHits *los_trees = (TreeHits *)dalloc(sizeof(TreeHits) * np_);
     unsigned long long *cls_counts = scene->d_counters + 13;  // [13], [14], [15]
     F_PTR(fo.power_sum); F_PTR(best_len); F_PTR(best_idx); F_PTR(rx_counts); F_PTR(rx_off); F_PTR(rx_order);
-    F_PTR(cls_lists); F_PTR(los_trees);
+    F_PTR(cls_lists); F_PTR(los_trees); F_PTR(rx_keys);
     // everything that has to start from a fixed value, in one launch (six fills used to go one by one)
     {
         const int64_t most = std::max<int64_t>((int64_t)(n_rx * nf), std::max<int64_t>(2 * n_rx, (int64_t)np_));
@@ -1032,9 +1050,10 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         hipLaunchKernelGGL(k_status_final, dim3(grid), dim3(256), 0, st, fo.status, (int64_t)n_paths);
         hipLaunchKernelGGL(k_rx_path_count, dim3(grid), dim3(256), 0, st, pa, rx_counts);
         hipLaunchKernelGGL(k_rx_offsets, dim3(1), dim3(1024), 0, st, rx_counts, (int64_t)n_rx, rx_off);
-        hipLaunchKernelGGL(k_rx_path_fill, dim3(grid), dim3(256), 0, st, pa, rx_off, rx_counts + n_rx, rx_order);
-        hipLaunchKernelGGL(k_rx_path_rank, dim3(grid), dim3(256), 0, st, pa, rx_off, rx_order, rx_order + np_);
-        hipLaunchKernelGGL(k_rx_power_sum, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, rx_off, rx_order + np_,
+        hipLaunchKernelGGL(k_rx_path_fill, dim3(grid), dim3(256), 0, st, pa, rx_off, rx_counts + n_rx, rx_order,
+                           rx_keys);
+        hipLaunchKernelGGL(k_rx_path_rank, dim3(grid), dim3(256), 0, st, pa, rx_off, rx_keys, rx_order + np_);
+        hipLaunchKernelGGL(k_rx_power_sum, dim3((unsigned)((n_rx + 3) / 4)), dim3(256), 0, st, rx_off, rx_order + np_,
                            (int64_t)n_rx, n_freq, fo.power, fo.power_sum);
     }
     hipLaunchKernelGGL(k_power_db, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, fo.power_sum,
