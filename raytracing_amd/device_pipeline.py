@@ -191,6 +191,15 @@ def all_gather_records(local, n_total, dist=None):
     pad = (int(n_total) + world - 1) // world
     on_device = dist.get_backend() == "nccl"
     mine = local if on_device else local.cpu()
+    if int(n_total) % world == 0:
+        # equal blocks: the gathered tensor is the answer as it stands (no padding to add, nothing to cut out)
+        assert mine.shape[0] == pad
+        out = torch.empty((world * pad, width), dtype=torch.uint8, device=mine.device)
+        if on_device:
+            dist.all_gather_into_tensor(out, mine.contiguous())
+        else:
+            dist.all_gather(list(out.view(world, pad, width).unbind(0)), mine.contiguous())
+        return out
     buf = torch.zeros((pad, width), dtype=torch.uint8, device=mine.device)
     buf[:mine.shape[0]] = mine
     out = torch.empty((world * pad, width), dtype=torch.uint8, device=mine.device)
