@@ -297,6 +297,13 @@ def main():
     # ---- precompute: scene file -> candidates (once per scene and emitter) ----------------------------------------
     # (the HIP runtime's own first allocation and first launch, ~0.15 s per process, are not the pipeline's: done here)
     torch.zeros(1, device=dev).add_(1)
+    # (likewise the library's own first use in a process -- its code object is loaded on its first launch, its streams
+    # are made with its first scene, ~15 ms -- on a scene of a few polygons that has nothing to do with the map)
+    from raytracing_amd import place_utils
+
+    warm = _lib.Scene(geom.scene_arrays_of(place_utils.create_small_place()[0].get_polygons_list()), device=local_rank)
+    warm.sharp_edges()
+    warm.close()
     barrier()
     t_wall = time.perf_counter()
     stamps = {}

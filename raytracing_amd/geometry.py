@@ -205,13 +205,23 @@ class OrientedGeometry:
 
     def __init__(self, **attributes):
         self.attributes = attributes
-        self.id = attributes.pop("id", None)
-        if self.id is None:
-            self.id = _random_id()
+        self._id = attributes.pop("id", None)  # None: a random one, made when it is first asked for
         self.domain = None
         self.centroid = None
         self.visibility_matrix = None
         self.sharp_edges = None
+
+    @property
+    def id(self):
+        """The identifier given at construction, or a random one (reference :1117-1123).  A scene holds ten thousand
+        geometries whose identifiers nobody reads: the random ones are drawn on first use."""
+        if self._id is None:
+            self._id = _random_id()
+        return self._id
+
+    @id.setter
+    def id(self, value):
+        self._id = value
 
     def __eq__(self, other):
         """Same id and same sharp edges (reference :1142-1147); the subclasses add their own members."""
@@ -309,12 +319,21 @@ class OrientedPolygon(OrientedGeometry):
     def get_parametric(self, force=False):
         """[a, b, c, d] with unit normal from the first three vertices, d = -n·p2 (reference :1747-1765)."""
         if force or self.parametric is None:
+            # (a scene computes thousands of these: the cross product on Python floats, which are the same IEEE
+            # operations in the same order as on NumPy scalars; norm and dot product stay NumPy's, whose rounding is
+            # the BLAS routine's)
             p = self.points
-            a, b = p[1] - p[0], p[2] - p[1]
-            normal = np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
-            normal = normal / np.linalg.norm(normal)
-            d = -np.dot(normal, p[2])
-            self.parametric = np.array([normal[0], normal[1], normal[2], d])
+            (x0, y0, z0), (x1, y1, z1), (x2, y2, z2) = p[:3].tolist()
+            ax, ay, az = x1 - x0, y1 - y0, z1 - z0
+            bx, by, bz = x2 - x1, y2 - y1, z2 - z1
+            out = np.empty(4)
+            normal = out[:3]
+            normal[0] = ay * bz - az * by
+            normal[1] = az * bx - ax * bz
+            normal[2] = ax * by - ay * bx
+            normal /= math.sqrt(normal.dot(normal))
+            out[3] = -normal.dot(p[2])
+            self.parametric = out
         return self.parametric
 
     def get_normal(self):
