@@ -304,6 +304,14 @@ def main():
     warm = _lib.Scene(geom.scene_arrays_of(place_utils.create_small_place()[0].get_polygons_list()), device=local_rank)
     warm.sharp_edges()
     warm.close()
+    if use_group:
+        # (and the process group's first all-gather: the collective library sets its channels up on first use)
+        cdev0 = dev if args.backend == "nccl" else torch.device("cpu")
+        first = torch.zeros(8, dtype=torch.uint8, device=cdev0)
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(torch.empty(8 * world, dtype=torch.uint8, device=cdev0), first)
+        else:
+            dist.all_gather([torch.empty_like(first) for _ in range(world)], first)
     barrier()
     t_wall = time.perf_counter()
     stamps = {}
