@@ -102,13 +102,14 @@ int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, 
  * as rt_visibility_rows) together with the visibility vectors of n_faces extra faces (faces_out[n_faces*N], arguments as
  * rt_faces_visibility): the two steps RayTracingProblem.precompute takes one after the other (ray_tracing.py:208, then
  * :210-228 for the emitter's screens).  The screens are painted on a stream of their own while the matrix is painted,
- * instead of holding six compute units busy afterwards.  Host pointers, except that with rows_on_device != 0 (whole
- * matrix only) rows_out is memory of the scene's GPU: the matrix then never visits the host and rt_enumerate can read
- * it there (vis_on_device).  Same results as the separate calls. */
+ * instead of holding six compute units busy afterwards.  Host pointers, except the outputs named by outputs_on_device:
+ * bit 0 -- rows_out, bit 1 -- faces_out is memory of the scene's GPU, written in place (the matrix then never visits
+ * the host and rt_enumerate can read it there, vis_on_device; a rank of a sharded run has its rows and screens painted
+ * straight into the buffer its all-gather sends).  Same results as the separate calls. */
 int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *rows_out,
                              int32_t n_faces, const int32_t *face_off, const double *face_verts,
                              const double *face_normals, const int32_t *self_index, int faces_strict, uint8_t *faces_out,
-                             int rows_on_device);
+                             int outputs_on_device);
 /* Obstruction tests either walk every polygon (mode 1) or a uniform grid over the scene (mode 2); mode 0, the
  * default, picks by scene size.  Both give the same flags; the switch exists so that tests can check one against the
  * other (no reference counterpart). */

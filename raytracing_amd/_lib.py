@@ -133,13 +133,19 @@ def _ptr(a):
     return a.ctypes.data if a is not None else None
 
 
-def _device_matrix_ptr(t, n, device):
-    """Address of a device-resident N x N byte matrix (a contiguous uint8 or bool torch tensor on GPU ``device``)."""
+def _device_bytes_ptr(t, shape, device):
+    """Address of a device-resident byte array of the given shape (a contiguous uint8 or bool torch tensor on GPU
+    ``device``)."""
     if not getattr(t, "is_cuda", False) or t.device.index != device:
-        raise ValueError(f"the matrix must be a tensor on GPU {device}")
-    if tuple(t.shape) != (n, n) or t.element_size() != 1 or not t.is_contiguous():
-        raise ValueError("the matrix must be a contiguous N x N tensor of bytes")
+        raise ValueError(f"the array must be a tensor on GPU {device}")
+    if tuple(t.shape) != tuple(shape) or t.element_size() != 1 or not t.is_contiguous():
+        raise ValueError(f"the array must be a contiguous tensor of bytes of shape {tuple(shape)}")
     return t.data_ptr()
+
+
+def _device_matrix_ptr(t, n, device):
+    """Address of a device-resident N x N byte matrix."""
+    return _device_bytes_ptr(t, (n, n), device)
 
 
 def default_device():
@@ -364,38 +370,49 @@ class Scene:
                                           int(bool(strict)), _ptr(out)), "rt_faces_visibility")
         return out.astype(bool)
 
-    def visibility_with_faces(self, faces, row_ids=None, strict=False, faces_strict=False, matrix_out=None):
+    def visibility_with_faces(self, faces, row_ids=None, strict=False, faces_strict=False, matrix_out=None, rows_out=None,
+                              faces_out=None):
         """The visibility matrix (``row_ids`` None) or the listed unsymmetrised rows, and the visibility vectors of
         ``faces`` (as ``faces_visibility`` takes them), painted side by side: returns (matrix or rows, face vectors).
-        ``matrix_out`` (whole matrix only): an N x N byte tensor on this scene's GPU that receives the matrix instead of
-        a host array; it is returned in the matrix's place and ``enumerate`` takes it as it is."""
+        ``matrix_out`` (whole matrix) / ``rows_out`` (listed rows) / ``faces_out``: byte tensors on this scene's GPU,
+        [N, N] / [len(row_ids), N] / [len(faces), N], that receive the result instead of a host array; each is
+        returned in its result's place (``enumerate`` takes such a matrix as it is)."""
         off = np.zeros(len(faces) + 1, dtype=np.int32)
         np.cumsum([len(f[0]) for f in faces], out=off[1:])
-        verts = _f64(np.concatenate([np.asarray(f[0], dtype=float).reshape(-1, 3) for f in faces]))
-        normals = _f64(np.array([np.asarray(f[1], dtype=float)[:3] for f in faces]))
+        verts = _f64(np.concatenate([np.asarray(f[0], dtype=float).reshape(-1, 3) for f in faces])) if faces else np.zeros((0, 3))
+        normals = _f64(np.array([np.asarray(f[1], dtype=float)[:3] for f in faces])) if faces else np.zeros((0, 3))
         selfs = np.array([int(f[2]) for f in faces], dtype=np.int32)
         # (the library copies whole buffers out: nothing of them has to be cleared first)
-        f_out = np.empty((len(faces), self.n), dtype=np.uint8)
-        if matrix_out is not None:
-            if row_ids is not None:
-                raise ValueError("matrix_out goes with the whole matrix, not with row_ids")
-            rows, n_rows, r_ptr = None, 0, None
-            out_ptr = _device_matrix_ptr(matrix_out, self.n, self.device)
-        elif row_ids is None:
-            rows, n_rows, r_ptr = None, 0, None
-            r_out = np.empty((self.n, self.n), dtype=np.uint8)
-            out_ptr = _ptr(r_out)
+        on_device = 0
+        if faces_out is not None:
+            f_ptr, on_device = _device_bytes_ptr(faces_out, (len(faces), self.n), self.device), 2
         else:
+            f_out = np.empty((len(faces), self.n), dtype=np.uint8)
+            f_ptr = _ptr(f_out)
+        if row_ids is None:
+            if rows_out is not None:
+                raise ValueError("rows_out goes with row_ids; the whole matrix goes into matrix_out")
+            rows, n_rows, r_ptr = None, 0, None
+            if matrix_out is not None:
+                out_ptr, on_device = _device_matrix_ptr(matrix_out, self.n, self.device), on_device | 1
+            else:
+                r_out = np.empty((self.n, self.n), dtype=np.uint8)
+                out_ptr = _ptr(r_out)
+        else:
+            if matrix_out is not None:
+                raise ValueError("matrix_out goes with the whole matrix, not with row_ids")
             rows = np.ascontiguousarray(row_ids, dtype=np.int32)
             n_rows, r_ptr = len(rows), _ptr(rows)
-            r_out = np.empty((len(rows), self.n), dtype=np.uint8)
-            out_ptr = _ptr(r_out)
+            if rows_out is not None:
+                out_ptr, on_device = _device_bytes_ptr(rows_out, (len(rows), self.n), self.device), on_device | 1
+            else:
+                r_out = np.empty((len(rows), self.n), dtype=np.uint8)
+                out_ptr = _ptr(r_out)
         _check(load().rt_visibility_with_faces(self.handle, n_rows, r_ptr, int(bool(strict)), out_ptr, len(faces),
                                                _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs), int(bool(faces_strict)),
-                                               _ptr(f_out), 0 if matrix_out is None else 1), "rt_visibility_with_faces")
-        if matrix_out is not None:
-            return matrix_out, f_out.view(bool)
-        return r_out.view(bool), f_out.view(bool)  # the kernels write 0 and 1 only: no copy
+                                               f_ptr, on_device), "rt_visibility_with_faces")
+        first = matrix_out if matrix_out is not None else (rows_out if rows_out is not None else r_out.view(bool))
+        return first, (faces_out if faces_out is not None else f_out.view(bool))  # (0 and 1 only: viewed, not copied)
 
     def visibility_rows(self, row_ids, strict=False):
         """Rows of the visibility matrix before symmetrisation: bool [len(row_ids), N]."""

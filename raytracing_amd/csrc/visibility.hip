@@ -2228,7 +2228,8 @@ extern "C" int rt_face_visibility(rt_scene *scene, const double *face_verts, int
 // Rows of the visibility matrix before symmetrisation: row k of `out` = what polygon row_ids[k] sees
 // (geometry.py:1036-1046 restricted to some i).  The full matrix is the OR of all rows with their transpose; a node
 // shares the rows out over its GPUs and all-gathers them.
-extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *out) {
+static int visibility_listed_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *out,
+                                  int on_device) {
     if (!scene || (n_rows > 0 && (!row_ids || !out))) RT_FAIL("rt_visibility_rows: null argument");
     if (n_rows < 0) RT_FAIL("rt_visibility_rows: negative count");
     if (n_rows == 0) return 0;
@@ -2236,8 +2237,9 @@ extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t
     RT_HIP(rt_use_device(scene->device));
     for (int k = 0; k < n_rows; ++k)
         if (row_ids[k] < 0 || row_ids[k] >= n) RT_FAIL("rt_visibility_rows: row index out of range");
-    DevBuf d_out;
-    if (d_out.alloc((size_t)n * n_rows)) RT_FAIL("rt_visibility_rows: out of device memory");
+    DevBuf d_own;
+    if (!on_device && d_own.alloc((size_t)n * n_rows)) RT_FAIL("rt_visibility_rows: out of device memory");
+    uint8_t *d_dst = on_device ? out : (uint8_t *)d_own.p;  // a destination on the device is painted into directly
     const size_t per_face = sizeof(double) * 2 * (size_t)scene->view.vtot + (sizeof(PolyMeta) + 8) * (size_t)n;
     int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_rows, ((size_t)24 << 30) / per_face));
     batch = std::min(batch, 65535);
@@ -2254,13 +2256,16 @@ extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t
             a_normal.insert(a_normal.end(), scene->h_planes.begin() + 4 * (size_t)i, scene->h_planes.begin() + 4 * (size_t)i + 3);
             a_self.push_back(i);
         }
-        if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, (uint8_t *)d_out.p + (size_t)k0 * n,
-                            scene->last_vis_ms))
+        if (visibility_rows(scene, a_off, a_verts, a_normal, a_self, strict, d_dst + (size_t)k0 * n, scene->last_vis_ms))
             return -1;
     }
     RT_HIP(hipStreamSynchronize(scene->stream));
-    RT_HIP(hipMemcpy(out, d_out.p, (size_t)n * n_rows, hipMemcpyDeviceToHost));
+    if (!on_device) RT_HIP(hipMemcpy(out, d_dst, (size_t)n * n_rows, hipMemcpyDeviceToHost));
     return 0;
+}
+
+extern "C" int rt_visibility_rows(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict, uint8_t *out) {
+    return visibility_listed_rows(scene, n_rows, row_ids, strict, out, 0);
 }
 
 extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, int on_device) {
@@ -2302,18 +2307,19 @@ extern "C" int rt_visibility_matrix(rt_scene *scene, int strict, uint8_t *out, i
 // screens occupy a few compute units for as long as the whole matrix takes the rest of the chip, so the screens are
 // painted on a stream of their own while the matrix is painted on the scene's.
 // row_ids null: rows_out[N*N] = the symmetrised matrix (rt_visibility_matrix); otherwise rows_out[n_rows*N] = the
-// listed rows as rt_visibility_rows gives them.  rows_on_device (whole matrix only): rows_out is device memory of the
-// scene's GPU and the matrix never visits the host -- copying lln's 58 MB into pageable memory takes 33 ms, a sixth of
-// what painting it takes, and rt_enumerate can read it where it lies.
+// listed rows as rt_visibility_rows gives them.  outputs_on_device: bit 0 -- rows_out, bit 1 -- faces_out is device
+// memory of the scene's GPU and that result never visits the host: copying lln's 58 MB into pageable memory takes
+// 33 ms, a sixth of what painting it takes; rt_enumerate can read the matrix where it lies, and a rank of a sharded
+// run has its rows and screens painted straight into the buffer that the all-gather sends.
 extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const int32_t *row_ids, int strict,
                                         uint8_t *rows_out, int32_t n_faces, const int32_t *face_off,
                                         const double *face_verts, const double *face_normals, const int32_t *self_index,
-                                        int faces_strict, uint8_t *faces_out, int rows_on_device) {
+                                        int faces_strict, uint8_t *faces_out, int outputs_on_device) {
     if (!scene || !rows_out) RT_FAIL("rt_visibility_with_faces: null argument");
     if (n_faces < 0 || (row_ids && n_rows < 0)) RT_FAIL("rt_visibility_with_faces: negative count");
-    if (row_ids && rows_on_device) RT_FAIL("rt_visibility_with_faces: only the whole matrix can stay on the device");
-    rows_on_device = rows_on_device ? 1 : 0;
-    if (n_faces == 0) return row_ids ? rt_visibility_rows(scene, n_rows, row_ids, strict, rows_out)
+    if (outputs_on_device < 0 || outputs_on_device > 3) RT_FAIL("rt_visibility_with_faces: outputs_on_device must be 0..3");
+    const int rows_on_device = outputs_on_device & 1, faces_on_device = (outputs_on_device >> 1) & 1;
+    if (n_faces == 0) return row_ids ? visibility_listed_rows(scene, n_rows, row_ids, strict, rows_out, rows_on_device)
                                      : rt_visibility_matrix(scene, strict, rows_out, rows_on_device);
     if (!face_off || !face_verts || !face_normals || !faces_out) RT_FAIL("rt_visibility_with_faces: null argument");
     if (n_faces > 65535) RT_FAIL("rt_visibility_with_faces: at most 65535 faces per call");
@@ -2332,19 +2338,20 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
     std::vector<double> a_verts(face_verts, face_verts + 3 * (size_t)face_off[n_faces]);
     std::vector<double> a_normal(face_normals, face_normals + 3 * (size_t)n_faces);
     DevBuf d_faces;
-    if (d_faces.alloc(n * n_faces)) RT_FAIL("rt_visibility_with_faces: out of device memory");
+    if (!faces_on_device && d_faces.alloc(n * n_faces)) RT_FAIL("rt_visibility_with_faces: out of device memory");
+    uint8_t *d_faces_dst = faces_on_device ? faces_out : (uint8_t *)d_faces.p;
     RowsJob job;  // after d_faces and the host arrays: the stream is waited for before any of them goes
-    int rc = visibility_rows_enqueue(scene, scene->side_stream, a_off, a_verts, a_normal, a_self, faces_strict,
-                                     (uint8_t *)d_faces.p, job);
+    int rc = visibility_rows_enqueue(scene, scene->side_stream, a_off, a_verts, a_normal, a_self, faces_strict, d_faces_dst,
+                                     job);
     if (rc == 0)
-        rc = row_ids ? rt_visibility_rows(scene, n_rows, row_ids, strict, rows_out)
+        rc = row_ids ? visibility_listed_rows(scene, n_rows, row_ids, strict, rows_out, rows_on_device)
                      : rt_visibility_matrix(scene, strict, rows_out, rows_on_device);
     const hipError_t e = hipStreamSynchronize(scene->side_stream);
     for (int k = 4; k < 8; ++k) scene->last_vis_ms[k] = 0;
     if (rc == 0 && e == hipSuccess) job.add_times(scene->last_vis_ms + 4);
     if (rc) return -1;
     if (e != hipSuccess) RT_FAIL(std::string("rt_visibility_with_faces: ") + hipGetErrorString(e));
-    RT_HIP(hipMemcpy(faces_out, d_faces.p, n * n_faces, hipMemcpyDeviceToHost));
+    if (!faces_on_device) RT_HIP(hipMemcpy(faces_out, d_faces_dst, n * n_faces, hipMemcpyDeviceToHost));
     return 0;
 }
 

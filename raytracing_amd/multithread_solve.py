@@ -96,7 +96,7 @@ def _gather_dealt_rows_tensor(rows_of, n_rows, n_cols, dist):
     buf[:len(mine)] = torch.from_numpy(local).to(dev)
     gathered = torch.empty((world, pad, n_cols), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(gathered.view(world * pad, n_cols), buf)
-    return gathered.permute(1, 0, 2).reshape(world * pad, n_cols)[:n_rows]
+    return dealt_rows_in_order(gathered, n_rows)
 
 
 def gather_visibility_rows(rows_of, n, dist=None):
@@ -104,6 +104,33 @@ def gather_visibility_rows(rows_of, n, dist=None):
     matrix = rows | rows^T (geometry.py:1036-1048)."""
     rows = _gather_dealt_rows_tensor(rows_of, n, n, dist or _dist())
     return (rows | rows.T).cpu().numpy().astype(bool)
+
+
+def paint_dealt_block_on_device(scene, screens, strict, world, rank):
+    """This rank's share of the list [matrix rows 0..N-1, screens] dealt out interleaved (items rank, rank + W, ...),
+    painted into one zero-padded uint8 tensor [ceil((N + len(screens)) / W), N] on the scene's GPU: its matrix rows
+    first, then its screens (the screens are the last items of the list), which is the order the items have."""
+    import torch
+
+    n = scene.n
+    n_items = n + len(screens)
+    ids = np.arange(rank, n_items, world, dtype=np.int64)
+    row_ids = ids[ids < n].astype(np.int32)
+    mine = [screens[int(i) - n] for i in ids[ids >= n]]
+    pad = (n_items + world - 1) // world
+    dev = torch.device("cuda", scene.device)
+    block = torch.zeros((pad, n), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)  # the library writes on a stream of its own
+    scene.visibility_with_faces(mine, row_ids=row_ids, strict=strict, rows_out=block[:len(row_ids)],
+                                faces_out=block[len(row_ids):len(ids)])
+    return block
+
+
+def dealt_rows_in_order(gathered, n_items):
+    """The items of the dealt list in order, from the gathered blocks [W, pad, n_cols]: rank r's k-th item is item
+    k * W + r, so the blocks with their first two axes swapped are the items one after the other."""
+    world, pad, n_cols = gathered.shape
+    return gathered.permute(1, 0, 2).reshape(world * pad, n_cols)[:n_items]
 
 
 def sharded_visibility(scene, screens, strict=False, dist=None, on_device=False):
@@ -116,7 +143,8 @@ def sharded_visibility(scene, screens, strict=False, dist=None, on_device=False)
     scene takes longer to bring to the host than a sixth of its painting, and nothing on the host needs it)."""
     n = scene.n
     dist = dist or _dist()
-    if dist is None or dist.get_world_size() == 1:
+    # (a group of one rank over RCCL goes through the collective all the same: a rehearsal of that branch on one GPU)
+    if dist is None or (dist.get_world_size() == 1 and dist.get_backend() != "nccl"):
         # one rank paints everything: matrix (symmetrised on the device) and screens side by side
         if on_device:
             import torch
@@ -140,7 +168,17 @@ def sharded_visibility(scene, screens, strict=False, dist=None, on_device=False)
 
     # put in order and symmetrised where the collective left the rows (on the GPU for RCCL: the host took 0.2 s to
     # scatter 58 MB of interleaved rows and OR them with their transpose, more than an eighth of the painting takes)
-    rows = _gather_dealt_rows_tensor(rows_of, n + len(screens), n, dist)
+    if dist.get_backend() == "nccl":
+        # painted straight into the buffer the collective sends: the rows never visit the host
+        import torch
+
+        world = dist.get_world_size()
+        block = paint_dealt_block_on_device(scene, screens, strict, world, dist.get_rank())
+        gathered = torch.empty((world,) + tuple(block.shape), dtype=torch.uint8, device=block.device)
+        dist.all_gather_into_tensor(gathered.view(world * block.shape[0], n), block)
+        rows = dealt_rows_in_order(gathered, n + len(screens))
+    else:
+        rows = _gather_dealt_rows_tensor(rows_of, n + len(screens), n, dist)
     matrix = rows[:n]
     matrix = matrix | matrix.T
     if on_device:

@@ -53,6 +53,15 @@ def test_rows_and_records_gathered_over_rccl_are_those_of_the_single_process(pla
     np.testing.assert_array_equal(matrix.cpu().numpy().astype(bool), want_matrix)
     np.testing.assert_array_equal(mts.gather_visibility_rows(lambda ids: scene.visibility_rows(ids), n, dist), want_matrix)
 
+    # the sharded call itself: rows and screens painted into the buffer the all-gather sends, matrix left on the device
+    d_matrix, got_screens = mts.sharded_visibility(scene, screens, dist=dist, on_device=True)
+    assert d_matrix.is_cuda
+    np.testing.assert_array_equal(d_matrix.cpu().numpy().astype(bool), want_matrix)
+    np.testing.assert_array_equal(got_screens, want_screens)
+    h_matrix, got_screens = mts.sharded_visibility(scene, screens, dist=dist)
+    np.testing.assert_array_equal(h_matrix, want_matrix)
+    np.testing.assert_array_equal(got_screens, want_screens)
+
     # the device matrix goes into the enumeration as it is; one record per receiver through the collective
     ev = np.logical_or.reduce(want_screens)
     pairs, edges = scene.sharp_edges()
