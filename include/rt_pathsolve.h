@@ -186,7 +186,7 @@ int rt_candidates_group(const rt_candidates *cand, int32_t group, int32_t *chain
 /* ---- the solve: LOS + every (receiver, candidate) (ray_tracing.py:232-237, 243-390) ---------------------------------
  * tx[3], rx[n_rx*3].  Valid paths are appended, in no particular order, to
  *   out_rx[cap] receiver index, out_group[cap] group (-1 = line of sight), out_cand[cap] index inside the group,
- *   out_points[cap*RT_MAX_ORDER*3] interaction points (first n of each row used).
+ *   out_points[cap*RT_MAX_ORDER*3] interaction points (first n of each row used, the rest zero).
  * *n_found = number of valid paths (if > capacity the surplus was dropped: call again with more room);
  * *n_attempted = n_rx * (1 + total candidates), the path-solve count of the metric.
  * on_device selects where rx and the out_* arrays live; the two counters are always host. */

@@ -1495,7 +1495,10 @@ __global__ __launch_bounds__(256) void k_finalize(const PathRec *__restrict__ pa
             out.rx[slot] = p.rx;
             out.group[slot] = p.group;
             out.cand[slot] = p.cand;
-            for (int k = 0; k < RT_MAX_ORDER * 3; ++k) out.pts[slot * RT_MAX_ORDER * 3 + k] = p.pts[k];
+            // (the slots past the path's own points are written as zeros: a record of the queue keeps what an earlier
+            // solve left there)
+            for (int k = 0; k < RT_MAX_ORDER * 3; ++k)
+                out.pts[slot * RT_MAX_ORDER * 3 + k] = k < 3 * p.npts ? p.pts[k] : 0.0;
         }
     }
     __syncthreads();
