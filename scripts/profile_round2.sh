@@ -1,4 +1,4 @@
-# Kernel statistics and counter passes of the round-2 bench line (run on the GPU box from the repository root):
+# Kernel statistics and counter passes of the bench line, written as r2_* (run on the GPU box from the repository root):
 #   bash scripts/profile_round2.sh   -> gpurun_out/r2_*  (scripts/counters_json.py turns the passes into
 #   profiles/r2_counters.json; copy what is to be kept into profiles/)
 set -e
