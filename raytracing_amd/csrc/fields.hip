@@ -417,75 +417,97 @@ __global__ __launch_bounds__(256) void k_field_classes(PathArrays pa, int32_t *_
 }
 
 // Lines of sight are only known to be clear of the polygons the emitter sees (ray_tracing.py:232-237), so the reference's
-// tree loss looks at every polygon of the scene for them (electromagnetism.py:669).  One wave per line of sight, lanes =
-// polygons, the crossed ones gathered in ascending order, then the grouping of geometry.py:886-895 by one lane.
+// tree loss looks at every polygon of the scene for them (electromagnetism.py:669).  One workgroup per line of sight at
+// a time (the workgroups stride over the list, whose length only the device knows): its four waves take a quarter of
+// the polygons each, lanes = polygons, the crossed ones gathered per wave in ascending order -- so the waves' lists one
+// after the other are in ascending order too --, then the grouping of geometry.py:886-895 by one lane.  (One wave per
+// line of sight left two waves on a SIMD with nothing to hide the record reads behind: 100 us for lln's 2 000 lines.)
 #define LOS_HIT_CAP 128
 __global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, d3 tx, const double *__restrict__ rx,
                                                     const int32_t *__restrict__ los_list, const unsigned long long *los_count,
                                                     TreeHits *__restrict__ out) {
     __shared__ int32_t s_hits[4][LOS_HIT_CAP];
+    __shared__ int s_n[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
-    if (j >= (int64_t)*los_count) return;
-    const int64_t i = los_list[j];
-    const d3 A = pa.origin ? ld3(pa.origin + 3 * (size_t)i) : tx;
-    const d3 B = ld3(rx + 3 * (size_t)pa.rx[i]);
-    const d3 V = B - A;
-    const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
-    int n_hits = 0;  // wave-uniform
-    for (int base = 0; base < sc.n; base += 64) {
-        const int p = base + lane;
-        const bool hit = p < sc.n && occ_pretest(sc.poly_recs + p, sc, A, V, pad) && polygon_cuts_segment(sc, p, A, B);
-        const unsigned long long mk = __ballot(hit);
-        if (hit) {
-            const int at = n_hits + __popcll(mk & ((1ull << lane) - 1));
-            if (at < LOS_HIT_CAP) s_hits[wave][at] = p;
-        }
-        n_hits += __popcll(mk);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane != 0) return;
-    TreeHits h;
-    h.n = 0;
-    h.concave = n_hits > LOS_HIT_CAP ? 1 : 0;  // (a segment through more than 128 polygons: not a line of sight of any scene)
-    int first = -1, second = -1, count = 0;
-    auto flush = [&]() {
-        if (count == 2) {
-            // geometry.py:89-106 for both polygons
-            const d3 dir = vv_normalize(B - A);
-            d3 pts[2];
-            const int idx[2] = {first, second};
-            for (int q = 0; q < 2; ++q) {
-                const d3 n = ld3(sc.planes + 4 * (size_t)idx[q]);
-                const d3 pp = ld3(sc.verts + 3 * ((size_t)sc.vert_off[idx[q]] + 1));
-                const d3 w = A - pp;
-                const double s = -dot(w, n) / dot(dir, n);
-                pts[q] = (w + s * dir) + pp;
+    const int64_t n_los = (int64_t)*los_count;
+    const int per_wave = ((sc.n + 3) / 4 + 63) & ~63;  // polygons per wave, whole trips of 64
+    for (int64_t j = blockIdx.x; j < n_los; j += gridDim.x) {
+        const int64_t i = los_list[j];
+        const d3 A = pa.origin ? ld3(pa.origin + 3 * (size_t)i) : tx;
+        const d3 B = ld3(rx + 3 * (size_t)pa.rx[i]);
+        const d3 V = B - A;
+        const double pad = 1e-5 * fmax(fabs(V.x), fmax(fabs(V.y), fabs(V.z))) + 1e-6;
+        int n_mine = 0;  // wave-uniform
+        const int p_end = (wave + 1) * per_wave < sc.n ? (wave + 1) * per_wave : sc.n;
+        for (int base = wave * per_wave; base < p_end; base += 64) {
+            const int p = base + lane;
+            const bool hit = p < p_end && occ_pretest(sc.poly_recs + p, sc, A, V, pad) && polygon_cuts_segment(sc, p, A, B);
+            const unsigned long long mk = __ballot(hit);
+            if (hit) {
+                const int at = n_mine + __popcll(mk & ((1ull << lane) - 1));
+                if (at < LOS_HIT_CAP) s_hits[wave][at] = p;
             }
-            const double d = norm3(pts[0] - pts[1]);
-            if (d > 0) {
-                if (h.n < TREE_MAX_GROUPS) h.d[h.n++] = d; else h.concave = 1;
+            n_mine += __popcll(mk);
+        }
+        if (lane == 0) s_n[wave] = n_mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n_hits = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+            // the q-th crossed polygon in ascending order (q below LOS_HIT_CAP, which bounds what is looked at)
+            auto hit_at = [&](int q) -> int {
+                int w = 0;
+                while (q >= s_n[w]) q -= s_n[w++];
+                return s_hits[w][q];
+            };
+            TreeHits h;
+            h.n = 0;
+            h.concave = 0;
+            int first = -1, second = -1, count = 0;
+            auto flush = [&]() {
+                if (count == 2) {
+                    // geometry.py:89-106 for both polygons
+                    const d3 dir = vv_normalize(B - A);
+                    d3 pts[2];
+                    const int idx[2] = {first, second};
+                    for (int q = 0; q < 2; ++q) {
+                        const d3 n = ld3(sc.planes + 4 * (size_t)idx[q]);
+                        const d3 pp = ld3(sc.verts + 3 * ((size_t)sc.vert_off[idx[q]] + 1));
+                        const d3 w = A - pp;
+                        const double s = -dot(w, n) / dot(dir, n);
+                        pts[q] = (w + s * dir) + pp;
+                    }
+                    const double d = norm3(pts[0] - pts[1]);
+                    if (d > 0) {
+                        if (h.n < TREE_MAX_GROUPS) h.d[h.n++] = d; else h.concave = 1;
+                    }
+                } else if (count > 2) {
+                    h.concave = 1;
+                }
+            };
+            // (a wave that finds more than LOS_HIT_CAP on its own has kept its first LOS_HIT_CAP; the path is then marked as
+            // not to be trusted below, and what is grouped does not matter)
+            const bool too_many = n_hits > LOS_HIT_CAP || s_n[0] > LOS_HIT_CAP || s_n[1] > LOS_HIT_CAP || s_n[2] > LOS_HIT_CAP ||
+                                  s_n[3] > LOS_HIT_CAP;
+            const int m = too_many ? 0 : n_hits;
+            for (int q = 0; q < m; ++q) {
+                const int p = hit_at(q);
+                if (count == 0) {
+                    first = p;
+                    count = 1;
+                } else if (sc.building[first] == sc.building[p]) {
+                    if (count == 1) second = p;
+                    ++count;
+                } else {
+                    flush();  // geometry.py:890-892: the group is closed and the polygon that closed it is dropped
+                    count = 0;
+                }
             }
-        } else if (count > 2) {
-            h.concave = 1;
+            flush();
+            if (too_many) h.concave = 1;  // (a segment through more than 128 polygons: not a line of sight of any scene)
+            out[j] = h;
         }
-    };
-    const int m = n_hits < LOS_HIT_CAP ? n_hits : LOS_HIT_CAP;
-    for (int q = 0; q < m; ++q) {
-        const int p = s_hits[wave][q];
-        if (count == 0) {
-            first = p;
-            count = 1;
-        } else if (sc.building[first] == sc.building[p]) {
-            if (count == 1) second = p;
-            ++count;
-        } else {
-            flush();  // geometry.py:890-892: the group is closed and the polygon that closed it is dropped
-            count = 0;
-        }
+        __syncthreads();  // the lists are free for the next line of sight
     }
-    flush();
-    out[j] = h;
 }
 
 struct FieldOut {
@@ -1038,8 +1060,8 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         // blocks past the end of a list leave at once
         const dim3 fgrid((unsigned)((n_paths + 127) / 128), (unsigned)n_freq);
         if (!pa.e_in)
-            hipLaunchKernelGGL(k_los_trees, dim3((unsigned)((n_paths + 3) / 4)), dim3(256), 0, st, scene->view, pa, TX, d_rx,
-                               cls_lists, cls_counts, los_trees);
+            hipLaunchKernelGGL(k_los_trees, dim3((unsigned)std::min<int64_t>((int64_t)n_paths, 4096)), dim3(256), 0, st,
+                               scene->view, pa, TX, d_rx, cls_lists, cls_counts, los_trees);
         hipLaunchKernelGGL(k_fields<0>, fgrid, dim3(128), 0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx, cls_lists,
                            cls_counts, los_trees, fo);
         hipLaunchKernelGGL(k_fields<1>, fgrid, dim3(128), 0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx,
