@@ -103,6 +103,12 @@ class DevicePipeline:
         self.scene.wait_for_stream(handle)
         if self.field_scene is not self.scene:
             self.field_scene.wait_for_stream(handle)
+        # (everything the host can do ahead of the solve's result is done ahead of it: between the solve's last kernel
+        # and the description's first the GPU has nothing queued)
+        power_db = torch.empty((n_rx, len(freqs)), dtype=torch.float64, device=self.device)
+        rec = None
+        if records and fields and n_rx:
+            rec = torch.empty((n_rx, record_bytes(len(freqs))), dtype=torch.uint8, device=self.device)
         while True:
             b = self.b
             found, attempted = self.scene.solve_paths_device(self.cand, self.tx, d_rx.data_ptr(), n_rx, b["rx"].data_ptr(),
@@ -111,11 +117,8 @@ class DevicePipeline:
             if found <= self.capacity:
                 break
             self._grow(found + found // 8 + 1024, len(freqs))
-        solve_timing = self.scene.last_timing()
         n = int(found)
-        power_db = torch.empty((n_rx, len(freqs)), dtype=torch.float64, device=self.device)
         fields_timing = None
-        rec = None
         if fields and n_rx:
             # one stream for all three steps: queued without waiting in between (two scenes have two streams, and the
             # description then has to be waited for before the other scene's field step)
@@ -131,7 +134,6 @@ class DevicePipeline:
                                          b["angles"].data_ptr(), b["time"].data_ptr(), b["status"].data_ptr(),
                                          power_db.data_ptr(), n_late_polygons=self.n_late_polygons, **antenna)
                 if records:
-                    rec = torch.empty((n_rx, record_bytes(len(freqs))), dtype=torch.uint8, device=self.device)
                     self.field_scene.receiver_records_device(n_rx, len(freqs), power_db.data_ptr(), n, b["rx"].data_ptr(),
                                                              b["kind"].data_ptr(), b["status"].data_ptr(), rec.data_ptr())
             finally:
@@ -139,6 +141,7 @@ class DevicePipeline:
                     self.scene.set_deferred_sync(False)
                     self.scene.synchronize()
             fields_timing = self.field_scene.fields_timing()
+        solve_timing = self.scene.last_timing()  # (kept by the library until the next solve)
         views = {k: v[:n] for k, v in b.items()}
         return PathBlock(scene=self.field_scene, n_rx=n_rx, n_paths=n, n_attempted=int(attempted), power_db=power_db,
                          frequencies=freqs, records=rec,
