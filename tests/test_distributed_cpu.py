@@ -194,3 +194,22 @@ def test_two_rank_visibility_rows(tmp_path, n):
     assert sorted(asked.tolist()) == list(range(n))
     # without a process group: one rank does every row
     np.testing.assert_array_equal(mts.gather_visibility_rows(lambda ids: full[ids], n), want)
+
+
+@pytest.mark.parametrize("world,n_items", [(1, 7), (2, 7), (3, 7), (4, 8), (8, 7621), (5, 3)])
+def test_dealt_blocks_come_back_in_order(world, n_items):
+    """Items dealt out interleaved (rank r holds items r, r + W, ...) in zero-padded blocks of equal length, stacked as an
+    all-gather leaves them: ``dealt_rows_in_order`` gives the items 0 .. n_items - 1 one after the other."""
+    import torch
+
+    from raytracing_amd import multithread_solve as mts
+
+    n_cols = 3
+    pad = (n_items + world - 1) // world
+    blocks = torch.zeros((world, pad, n_cols), dtype=torch.int64)
+    for r in range(world):
+        ids = torch.arange(r, n_items, world)
+        blocks[r, :len(ids)] = ids[:, None] * 10 + torch.arange(n_cols)[None, :]
+    rows = mts.dealt_rows_in_order(blocks, n_items)
+    want = torch.arange(n_items)[:, None] * 10 + torch.arange(n_cols)[None, :]
+    assert rows.shape == (n_items, n_cols) and torch.equal(rows, want)
