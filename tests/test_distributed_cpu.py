@@ -208,7 +208,7 @@ def test_dealt_blocks_come_back_in_order(world, n_items):
     pad = (n_items + world - 1) // world
     blocks = torch.zeros((world, pad, n_cols), dtype=torch.int64)
     for r in range(world):
-        ids = torch.arange(r, n_items, world)
+        ids = torch.from_numpy(np.arange(r, n_items, world))  # (empty for a rank beyond the last item)
         blocks[r, :len(ids)] = ids[:, None] * 10 + torch.arange(n_cols)[None, :]
     rows = mts.dealt_rows_in_order(blocks, n_items)
     want = torch.arange(n_items)[:, None] * 10 + torch.arange(n_cols)[None, :]
