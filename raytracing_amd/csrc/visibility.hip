@@ -2150,6 +2150,14 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         if (tile_min < 0) {
             tile_min = n_faces <= 256 ? 512 : 0;
             tile_size = n_faces <= 256 ? 48 : 0;
+            // A sixth of a large scene's faces or less (a rank's share of a sharded matrix on six GPUs or more): the
+            // batch lasts as long as its longest faces while most workgroups have long run out of faces, so the
+            // faces that see half the scene go in large sectors (lln, an eighth of the rows: 115 -> 85 ms; with a
+            // quarter or more of the rows the sectors' extra work costs more than the idle workgroups were worth).
+            if (n_faces > 256 && (int64_t)n_faces * 6 <= (int64_t)sc.n) {
+                tile_min = 4096;
+                tile_size = 1024;
+            }
         }
         hipLaunchKernelGGL(k_vis_tiles, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,
                            (const int32_t *)b_order.p, m_stride, (const int32_t *)b_counts.p, tile_min, tile_size,

@@ -400,7 +400,7 @@ def test_matrix_and_screens_in_one_call_equal_the_separate_calls(places, name):
 
 
 @pytest.mark.parametrize("name,world", [("small", 1), ("small", 3), ("place_levant", 2), ("place_levant", 8),
-                                        ("place_levant", 5)])
+                                        ("place_levant", 5), ("lln", 8)])
 def test_blocks_painted_on_the_device_rank_by_rank_give_the_matrix_and_the_screens(places, name, world):
     """What each rank of a sharded run paints straight into its all-gather buffer (its matrix rows, then its screens,
     device memory), for every rank of a world in turn on the one GPU: the blocks stacked as the collective would leave
