@@ -66,9 +66,20 @@ else:
         out = scene.fields(tx, rx, res["rx"], kind, chain, epolys, epts, res["points"], freqs)
         t_fields = time.perf_counter() - t
         total_pf += n * len(freqs)
+        # the field kernels alone (device time) as path-frequencies per second, and against HBM by the byte model of the
+        # field step: per path its points, chain and edge in (24 (k + 2) + 4 k + 104 B), per path and frequency the field
+        # and the power out (56 B)
+        k_inter = (kind & 255) + (kind >> 8)
+        model_bytes = float((24.0 * (k_inter + 2) + 4.0 * k_inter + 104.0).sum()) + 56.0 * n * len(freqs)
+        kernel_ms = scene.fields_timing()["kernel"]
+        total_kernel_ms = locals().get("total_kernel_ms", 0.0) + kernel_ms
+        total_bytes = locals().get("total_bytes", 0.0) + model_bytes
         db = out["power_db"]
         print(f"  tx {np.round(tx,1)}: {res['n_attempted']:.3e} path-solves, {n} paths, emitter visibility + enumerate + solve {t_solve:.3f}s, "
               f"fields {t_fields*1e3:.1f} ms, status ok {(out['status']==0).mean():.3f}, covered receivers {int(np.isfinite(db[:,0]).sum())}, "
               f"median dB at {freqs[0]/1e9:g} / {freqs[-1]/1e9:g} GHz: {np.median(db[np.isfinite(db[:,0]),0]):.1f} / {np.median(db[np.isfinite(db[:,-1]),-1]):.1f}", flush=True)
         cand.close()
     print(f"  all emitters: {time.perf_counter()-t_all:.2f}s, {total_pf} path-frequencies", flush=True)
+    print(f"  field kernels: {total_kernel_ms:.2f} ms device time = {total_pf / (total_kernel_ms * 1e-3):.3e} path-frequencies/s, "
+          f"{total_bytes / (total_kernel_ms * 1e-3) / 1e9:.1f} GB/s of the byte model = {total_bytes / (total_kernel_ms * 1e-3) / 8e12:.4f} of HBM peak",
+          flush=True)
