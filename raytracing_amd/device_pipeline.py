@@ -32,8 +32,19 @@ def record_bytes(n_freq):
 class PathBlock:
     """Result of one ``DevicePipeline.run``: views of the pipeline's device tensors (valid until its next run)."""
 
-    def __init__(self, **kw):
+    def __init__(self, buffers=None, **kw):
         self.__dict__.update(kw)
+        self._buffers = buffers or {}
+
+    def __getattr__(self, name):
+        # the per-path arrays (rx, group, cand, points, kind, chain, ...): the first n_paths rows of the pipeline's
+        # buffers, cut when first asked for (a dozen slices per step were a tenth of the host's share of a small step)
+        buffers = self.__dict__.get("_buffers")
+        if buffers is not None and name in buffers:
+            view = buffers[name][:self.n_paths]
+            self.__dict__[name] = view
+            return view
+        raise AttributeError(name)
 
     def to_host(self):
         """The per-path arrays as NumPy arrays, sorted by (receiver, group, candidate): the reference's row order
@@ -142,10 +153,9 @@ class DevicePipeline:
                     self.scene.synchronize()
             fields_timing = self.field_scene.fields_timing()
         solve_timing = self.scene.last_timing()  # (kept by the library until the next solve)
-        views = {k: v[:n] for k, v in b.items()}
-        return PathBlock(scene=self.field_scene, n_rx=n_rx, n_paths=n, n_attempted=int(attempted), power_db=power_db,
-                         frequencies=freqs, records=rec,
-                         solve_timing=solve_timing, fields_timing=fields_timing, **views)
+        return PathBlock(buffers=b, scene=self.field_scene, n_rx=n_rx, n_paths=n, n_attempted=int(attempted),
+                         power_db=power_db, frequencies=freqs, records=rec, solve_timing=solve_timing,
+                         fields_timing=fields_timing)
 
 
 def receiver_records(block):
