@@ -239,6 +239,11 @@ def main():
     ap.add_argument("--n-side", type=int, default=100, help="receivers per side of the lattice (100 = the 10k-RX map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary config-2 block")
+    ap.add_argument("--solver-mode", choices=("reference", "exact"), default="reference",
+                    help="reference: a found path is kept only when the reference's own solver call (SciPy hybr, restated "
+                         "on the GPU) reports success and its points pass the reference's checks, i.e. the reference's path "
+                         "set; exact: every path that has a root is kept")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the secondary block timed in the other solver mode")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 (rehearsal on a one-GPU box)")
     args = ap.parse_args()
@@ -364,34 +369,51 @@ def main():
         return block, records
 
     # ---- the timed steps ---------------------------------------------------------------------------------------------
-    scene.set_timing(False)  # the event pairs around every launch are kept out of the timed region
-    for _ in range(args.warmup):
-        block, records = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        block, records = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # the same steps again with the per-launch events on: kernel times of the rooflines
-    scene.set_timing(True)
-    fam = {"reflect": 0.0, "diffract": 0.0, "obstruct": 0.0, "finalize": 0.0, "fields": 0.0, "fields_call": 0.0}
-    launches = {"reflect": 0, "diffract": 0, "obstruct": 0, "finalize": 0}
-    segments = 0
+    def timed_steps(n_warm, n_steps, n_ev):
+        """n_warm untimed and n_steps timed steps without the per-launch events, then n_ev more with them (kernel times)."""
+        scene.set_timing(False)  # the event pairs around every launch are kept out of the timed region
+        for _ in range(n_warm):
+            block, records = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            block, records = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        scene.set_timing(True)
+        fam = {"reflect": 0.0, "diffract": 0.0, "obstruct": 0.0, "finalize": 0.0, "rejudge": 0.0, "fields": 0.0,
+               "fields_call": 0.0}
+        launches = {"reflect": 0, "diffract": 0, "obstruct": 0, "finalize": 0}
+        segments = 0
+        rejudged = [0, 0]
+        t1 = time.perf_counter()
+        for _ in range(n_ev):
+            block, records = step()
+            for k in launches:
+                fam[k] += block.solve_timing["ms"][k] / n_ev
+                launches[k] += block.solve_timing["launches"][k]
+            fam["rejudge"] += block.solve_timing["rejudge"]["ms"] / n_ev
+            rejudged = [block.solve_timing["rejudge"]["n_in"], block.solve_timing["rejudge"]["n_kept"]]
+            fam["fields"] += block.fields_timing["kernel"] / n_ev
+            fam["fields_call"] += block.fields_timing["call"] / n_ev
+            segments += block.solve_timing["segments"]
+        torch.cuda.synchronize()
+        ms_with_events = 1e3 * (time.perf_counter() - t1) / n_ev
+        launches = {k: v / n_ev for k, v in launches.items()}
+        return elapsed, fam, launches, segments / n_ev, rejudged, ms_with_events, block, records
+
     n_ev = max(1, min(args.steps, 10))
-    t1 = time.perf_counter()
-    for _ in range(n_ev):
-        block, records = step()
-        for k in launches:
-            fam[k] += block.solve_timing["ms"][k] / n_ev
-            launches[k] += block.solve_timing["launches"][k]
-        fam["fields"] += block.fields_timing["kernel"] / n_ev
-        fam["fields_call"] += block.fields_timing["call"] / n_ev
-        segments += block.solve_timing["segments"]
-    torch.cuda.synchronize()
-    ms_with_events = 1e3 * (time.perf_counter() - t1) / n_ev
-    launches = {k: v / n_ev for k, v in launches.items()}
-    segments /= n_ev
+    other_mode = None
+    if world == 1 and not args.no_other_mode:
+        # the other solver mode first, as a secondary block: the headline is measured last, on the state it leaves
+        other = "exact" if args.solver_mode == "reference" else "reference"
+        scene.set_reference_solver(other == "reference")
+        o_elapsed, o_fam, _, _, o_rej, _, o_block, _ = timed_steps(args.warmup, args.steps, n_ev)
+        other_mode = {"solver_mode": other, "steps": args.steps, "ms_per_step": 1e3 * o_elapsed / max(1, args.steps),
+                      "path_solves_per_s": float(o_block.n_attempted) * max(1, args.steps) / o_elapsed,
+                      "valid_paths": int(o_block.n_paths), "kernel_ms_per_step": o_fam}
+    scene.set_reference_solver(args.solver_mode == "reference")
+    elapsed, fam, launches, segments, rejudged, ms_with_events, block, records = timed_steps(args.warmup, args.steps, n_ev)
     rec = dp.unpack_records(records.cpu().numpy(), 1)
     attempted_local = float(block.n_attempted)
     if use_group:
@@ -456,7 +478,13 @@ def main():
                        "candidates_per_receiver": 1 + int(sum(counts)), "candidates_by_group": counts,
                        "path_solves_per_step": int(attempted_all), "valid_paths_rank0": int(block.n_paths),
                        "valid_paths_all_gpus": int(rec["n_paths"].sum()), "frequency_hz": FREQUENCY_HZ,
-                       "record_bytes_per_receiver": dp.record_bytes(1), "backend": args.backend if use_group else None},
+                       "record_bytes_per_receiver": dp.record_bytes(1), "backend": args.backend if use_group else None,
+                       "solver_mode": args.solver_mode,
+                       "solver_mode_note": "reference = the reference's path set: every path the closed-form kernels find is "
+                                           "put through the reference's own solver call (SciPy hybr, restated on the GPU) and "
+                                           "kept only on its success and with its points passing the reference's checks "
+                                           "(ray_tracing.py:309-314, 345-350, 371-376); exact = every path that has a root",
+                       "paths_before_and_after_rejudge_rank0": rejudged},
             "coverage_map_wall_s": round(precompute_s + ms_step * 1e-3, 4),
             "coverage_map": {"precompute_s": round(precompute_s, 4), "precompute_breakdown_rank0": stamps,
                              "visibility_kernels_ms_rank0": vis_timing, "step_s": round(ms_step * 1e-3, 5),
@@ -473,8 +501,10 @@ def main():
                                 "runs without them)",
             "ms_per_step_with_events": ms_with_events,
             "step_host_and_collective_ms": ms_step - sum(fam[k] for k in ("reflect", "diffract", "obstruct", "finalize",
-                                                                          "fields_call")),
+                                                                          "rejudge", "fields_call")),
         }
+        if other_mode is not None:
+            out["other_solver_mode"] = other_mode
         if world == 1 and not args.no_config2:
             out["config2"] = config2_block(local_rank, dev, 200)
         if world == 1 and not args.no_cpu_baseline:

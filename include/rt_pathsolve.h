@@ -206,6 +206,11 @@ int rt_scene_set_reference_solver(rt_scene *scene, int on);
  * walked through the scene (a path that is found blocked on its last segment has its other segments never walked,
  * and they are not counted). */
 int rt_solve_last_timing(rt_scene *scene, double *ms, int64_t *launches, int64_t *segments_tested);
+/* The re-judging step of the last rt_solve_paths call in reference-compatible mode (rt_scene_set_reference_solver):
+ * *ms = device time of its kernels (HIP events on the scene's stream; zero with the timing off), *n_in = paths the
+ * closed-form solve had found, *n_kept = paths the reference's solver and checks kept (ray_tracing.py:309-314,
+ * 345-350, 371-376).  All zero when the mode is off.  Any pointer may be NULL. */
+int rt_solve_last_rejudge(rt_scene *scene, double *ms, int64_t *n_in, int64_t *n_kept);
 
 /* ---- field step: my_field_computation (electromagnetism.py:648-802) --------------------------------------------------
  * A path is described by

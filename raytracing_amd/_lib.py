@@ -68,6 +68,7 @@ _SIGNATURES = {
     "rt_solve_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_void_p, c_void_p, c_int]),
     "rt_solve_last_timing": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rt_solve_last_rejudge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "rt_fields_last_timing": (c_int, [c_void_p, c_void_p]),
     "rt_visibility_last_timing": (c_int, [c_void_p, c_void_p]),
     "rt_describe_paths": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
@@ -557,6 +558,14 @@ class Scene:
         _check(load().rt_visibility_last_timing(self.handle, _ptr(ms)), "rt_visibility_last_timing")
         names = ("prepare", "sort", "paint", "total")
         return dict(rows={k: float(v) for k, v in zip(names, ms[:4])}, faces={k: float(v) for k, v in zip(names, ms[4:])})
+
+    def rejudge_timing(self):
+        """The re-judging step of the last solve in reference-compatible mode: dict(ms, n_in, n_kept); zeros when off."""
+        ms = np.zeros(1, dtype=np.float64)
+        counts = np.zeros(2, dtype=np.int64)
+        _check(load().rt_solve_last_rejudge(self.handle, _ptr(ms), counts.ctypes.data, counts.ctypes.data + 8),
+               "rt_solve_last_rejudge")
+        return dict(ms=float(ms[0]), n_in=int(counts[0]), n_kept=int(counts[1]))
 
     def last_timing(self):
         ms = np.zeros(4, dtype=np.float64)

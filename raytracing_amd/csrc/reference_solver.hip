@@ -4,6 +4,8 @@
 // 369-376).  The reference loses valid paths to its solver (a stall on the common line of two planes reported as
 // success, a root reached but reported as failure with the hand-written derivative of geometry.py:710-713); this mode
 // loses the same ones.  The paths are few (the survivors of the obstruction tests), so one thread per path is enough.
+#include <algorithm>
+
 #include "rt_candidates.h"
 #include "rt_common.h"
 
@@ -11,40 +13,49 @@
 // the solver needs and nothing else here minds)
 #include "rt_hybrd.h"
 
+// (the run-time-sized form of the solver carries the unroll requests of the unrolled forms, which the optimiser cannot
+// honour there and says so once per loop)
+#pragma clang diagnostic ignored "-Wpass-failed"
+
 #define REJ_MAX_GROUPS (2 * RT_MAX_ORDER)
-struct RejudgeGroups {
-    int n_groups;
-    int n_refl[REJ_MAX_GROUPS], has_edge[REJ_MAX_GROUPS];
-    ChainSource chains[REJ_MAX_GROUPS];
-    const int32_t *edge_ids[REJ_MAX_GROUPS];
-};
+// evaluations after which the first pass hands a run to the second (on the lln map 97 in 100 runs of reflection +
+// diffraction systems end before, and the first pass lasts about 6 us per evaluation of its longest lane)
+#define REJ_FIRST_PASS_NFEV 96
 
-// every polygon against one segment, as the reference's check does (geometry.py:857-884)
-__device__ static bool any_polygon_cuts(const SceneView &sc, d3 A, d3 B) {
-    for (int p = 0; p < sc.n; ++p)
-        if (polygon_cuts_segment(sc, p, A, B)) return true;
-    return false;
-}
+int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, int64_t n_masked,
+                       uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
+                       const PathRec *d_paths, int round, bool clear_flags, const int32_t *d_index, const double *tx,
+                       const double *d_rx);
 
-// check_reflections / check_reflections_and_diffraction (ray_tracing.py:243-279) on the solver's own points
-__device__ static bool passes_reference_checks(const SceneView &sc, d3 tx, d3 R, const d3 *X, const int32_t *poly, int n_refl,
-                                               bool has_edge, const double *edge) {
+// The reference's checks that look at the path alone (ray_tracing.py:243-279 without the obstruction tests, which the
+// obstruction kernels run afterwards on the solver's points): every reflection point in its polygon, consecutive
+// points at least 5 mm apart, the diffraction point on its edge.
+__device__ static bool passes_point_checks(const SceneView &sc, d3 tx, d3 R, const d3 *X, const int32_t *poly, int n_refl,
+                                           bool has_edge, const double *edge) {
     const double min_distance_tol = 0.005;
-    for (int i = 0; i < n_refl; ++i)
-        if (!polygon_contains_point(sc, poly[i], X[i], true, 1e-8)) return false;
+    // (loops over the path's points run to the compile-time limit with a guard, so that they unroll and the small arrays
+    // of the caller stay in registers whatever n_refl is)
+#pragma unroll
+    for (int i = 0; i < RT_MAX_ORDER; ++i)
+        if (i < n_refl && !polygon_contains_point(sc, poly[i], X[i], true, 1e-8)) return false;
     // lines of check_reflections: the emitter, the reflection points, then the receiver or (with an edge) the
     // diffraction point
-    d3 L[RT_MAX_ORDER + 2];
-    L[0] = tx;
-    for (int i = 0; i < n_refl; ++i) L[i + 1] = X[i];
-    L[n_refl + 1] = has_edge ? X[n_refl] : R;
-    for (int i = 0; i <= n_refl; ++i)
-        if (any_polygon_cuts(sc, L[i], L[i + 1])) return false;
-    for (int i = 0; i <= n_refl; ++i)
-        if (norm3(L[i] - L[i + 1]) < min_distance_tol) return false;
+    d3 prev = tx;
+#pragma unroll
+    for (int i = 0; i <= RT_MAX_ORDER; ++i) {
+        if (i > n_refl) break;
+        d3 next = R;
+        if (i < n_refl || has_edge) next = X[i < RT_MAX_ORDER ? i : RT_MAX_ORDER - 1];
+        if (norm3(prev - next) < min_distance_tol) return false;
+        prev = next;
+    }
     if (has_edge) {
         // point_on_edge_ (geometry.py:456-479)
-        const d3 P0 = ld3(edge), P1 = ld3(edge + 3), D = X[n_refl];
+        d3 D = X[0];
+#pragma unroll
+        for (int i = 1; i < RT_MAX_ORDER; ++i)
+            if (i == n_refl) D = X[i];
+        const d3 P0 = ld3(edge), P1 = ld3(edge + 3);
         d3 fx, fy, fz;
         frame_from_vector(P1 - P0, fx, fy, fz);
         const double tol = 1e-8;
@@ -52,113 +63,316 @@ __device__ static bool passes_reference_checks(const SceneView &sc, d3 tx, d3 R,
         const double px = dot(D, fx), py = dot(D, fy), pz = dot(D, fz);
         if (!(ax - tol <= px && px <= ax + tol && ay - tol <= py && py <= ay + tol && az - tol <= pz && pz <= bz + tol))
             return false;
-        if (any_polygon_cuts(sc, D, R)) return false;
     }
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_rejudge(SceneView sc, RejudgeGroups G, const double *__restrict__ edges, d3 tx,
-                                                 const double *__restrict__ rx, const int32_t *__restrict__ p_rx,
-                                                 const int32_t *__restrict__ p_group, const int32_t *__restrict__ p_cand,
-                                                 double *__restrict__ p_pts, int64_t n, uint8_t *__restrict__ keep) {
+// The found paths sorted by the shape of their system (= their candidate group): lists[g * n ..] receives the indices
+// of the paths of group g, counts[g] how many.  A line of sight involved no solver: its record says "no segment to
+// test" and its flag "kept".  One reservation per block and group.
+__global__ __launch_bounds__(256) void k_rejudge_classify(const int32_t *__restrict__ p_rx, const int32_t *__restrict__ p_group,
+                                                          const int32_t *__restrict__ p_cand, int64_t n, int n_groups,
+                                                          int32_t *__restrict__ lists, unsigned long long *counts,
+                                                          PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
+    __shared__ int block_count[REJ_MAX_GROUPS];
+    __shared__ unsigned long long block_base[REJ_MAX_GROUPS];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int g = p_group[i];
-    if (g < 0 || g >= G.n_groups) {  // a line of sight: no solver was involved
-        keep[i] = 1;
-        return;
+    if (threadIdx.x < REJ_MAX_GROUPS) block_count[threadIdx.x] = 0;
+    __syncthreads();
+    int g = -1, slot = 0;
+    if (i < n) {
+        g = p_group[i];
+        if (g < 0 || g >= n_groups) {
+            g = -1;
+            PathRec &rec = recs[i];
+            rec.rx = p_rx[i];
+            rec.group = -1;
+            rec.cand = p_cand[i];
+            rec.nseg = 0;
+            rec.seg0 = 0;
+            rec.seg_stride = 0;
+            rec.npts = 0;
+            flags[i] = 0;
+        } else {
+            slot = atomicAdd(&block_count[g], 1);
+        }
     }
-    const int n_refl = G.n_refl[g];
-    const bool has_edge = G.has_edge[g] != 0;
+    __syncthreads();
+    if (threadIdx.x < n_groups && block_count[threadIdx.x] > 0)
+        block_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)block_count[threadIdx.x]);
+    __syncthreads();
+    if (g >= 0) lists[(size_t)g * n + block_base[g] + slot] = (int32_t)i;
+}
+
+// The reference's solver call on one path of a group, the checks on the solver's points that need no other polygon, and
+// the path's record for the obstruction kernels (flag set = dropped).  Returns false when the solver ran into
+// nfev_limit (nothing is written then).  NR, HE: the shape of the group's systems as template arguments (the method
+// then runs in registers), or -1, -1.
+template <int NR, int HE>
+__device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSource &chains, const int32_t *__restrict__ edge_ids,
+                                            int n_refl_rt, int has_edge_rt, const double *__restrict__ edges, d3 tx,
+                                            const double *__restrict__ rx, const int32_t *__restrict__ p_rx,
+                                            const int32_t *__restrict__ p_cand, int64_t i, int group, int nfev_limit,
+                                            bool write, PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
+    const int n_refl = NR >= 0 ? NR : n_refl_rt;
+    const bool has_edge = HE >= 0 ? HE != 0 : has_edge_rt != 0;
     const int64_t c = p_cand[i];
     int32_t poly[RT_MAX_ORDER];
     double planes[4 * RT_MAX_ORDER];
-    if (n_refl > 0) chain_load(G.chains[g], n_refl, c, poly);
-    for (int k = 0; k < n_refl; ++k) {
-        for (int q = 0; q < 4; ++q) planes[4 * k + q] = sc.planes[4 * (size_t)poly[k] + q];
-    }
+    if (n_refl > 0) chain_load(chains, n_refl, c, poly);
+#pragma unroll
+    for (int q = 0; q < RT_MAX_ORDER; ++q)
+        if (q < n_refl)
+            for (int w = 0; w < 4; ++w) planes[4 * q + w] = sc.planes[4 * (size_t)poly[q] + w];
     double edge[6];
     if (has_edge) {
-        const double *e = edges + 6 * (size_t)G.edge_ids[g][c];
+        const double *e = edges + 6 * (size_t)edge_ids[c];
         for (int q = 0; q < 6; ++q) edge[q] = e[q];
     }
     const double origin[3] = {tx.x, tx.y, tx.z};
-    const double *dest = rx + 3 * (size_t)p_rx[i];
+    const int32_t r = p_rx[i];
+    const double dest[3] = {rx[3 * (size_t)r], rx[3 * (size_t)r + 1], rx[3 * (size_t)r + 2]};
     double pts[3 * RT_MAX_ORDER];
     const int n_pts = n_refl + (has_edge ? 1 : 0);
-    const bool ok = rt_hybr::solve_like_reference(origin, dest, planes, n_refl, has_edge ? edge : nullptr, pts, nullptr);
-    if (!ok) {
-        keep[i] = 0;
-        return;
-    }
+    bool unfinished = false;
+    bool ok = rt_hybr::solve_shape<NR, HE>(origin, dest, planes, n_refl, has_edge ? edge : nullptr, pts, nullptr, nfev_limit,
+                                           &unfinished);
+    if (unfinished) return false;
     // The reference checks ITS solver's points (ray_tracing.py:310-313): they can sit a few 1e-7 m from the root the
     // closed form gives (the solver stops at xtol), which decides differently when the point is that close to the rim
-    // of its polygon or a segment passes that close to a corner.  So the checks are redone on them, every polygon
-    // against every segment as the reference does.
-    double *mine = p_pts + (size_t)i * RT_MAX_ORDER * 3;
-    d3 X[RT_MAX_ORDER];
-    for (int q = 0; q < n_pts; ++q) X[q] = ld3(pts + 3 * q);
-    const bool good = passes_reference_checks(sc, tx, ld3(dest), X, poly, n_refl, has_edge, edge);
-    if (good)
-        for (int q = 0; q < 3 * n_pts; ++q) mine[q] = pts[q];  // the reference stores its solver's points
-    keep[i] = good ? 1 : 0;
+    // of its polygon or a segment passes that close to a corner.  So the checks are redone on them.
+    if (ok) {
+        d3 X[RT_MAX_ORDER];
+#pragma unroll
+        for (int q = 0; q < RT_MAX_ORDER; ++q)
+            if (q < n_pts) X[q] = ld3(pts + 3 * q);
+        ok = passes_point_checks(sc, tx, ld3(dest), X, poly, n_refl, has_edge, edge);
+    }
+    if (write) {
+        PathRec &rec = recs[i];
+        rec.rx = r;
+        rec.group = group;
+        rec.cand = (int32_t)c;
+        rec.nseg = n_pts + 1;
+        rec.seg0 = 0;
+        rec.seg_stride = 0;
+        rec.npts = n_pts;
+#pragma unroll
+        for (int q = 0; q < 3 * RT_MAX_ORDER; ++q)
+            if (q < 3 * n_pts) rec.pts[q] = pts[q];  // the reference stores its solver's points
+        flags[i] = ok ? 0 : 1;
+    }
+    return true;
 }
 
-__global__ void k_rejudge_scatter(const uint8_t *__restrict__ keep, int64_t n, const int32_t *__restrict__ a_rx,
-                                  const int32_t *__restrict__ a_group, const int32_t *__restrict__ a_cand,
+// First pass: one thread per path of the group.  A solver run lasts as long as it takes evaluations (10 to 1 000), and
+// a wave as long as its longest lane, so a run that has not ended after nfev_limit evaluations is given up here and its
+// path handed to the second pass (late list: one reservation per wave).
+template <int NR, int HE>
+__global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource chains, const int32_t *__restrict__ edge_ids,
+                                                       int n_refl_rt, int has_edge_rt, const double *__restrict__ edges, d3 tx,
+                                                       const double *__restrict__ rx, const int32_t *__restrict__ p_rx,
+                                                       const int32_t *__restrict__ p_cand, const int32_t *__restrict__ list,
+                                                       const unsigned long long *__restrict__ count, int group, int nfev_limit,
+                                                       int32_t *__restrict__ late, unsigned long long *late_count,
+                                                       PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool done = true;
+    int64_t i = 0;
+    if (k < (int64_t)*count) {
+        i = list[k];
+        done = rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group,
+                                   nfev_limit, true, recs, flags);
+    }
+    const unsigned long long m = __ballot(!done);
+    if (m == 0ull) return;
+    unsigned long long base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(late_count, (unsigned long long)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (!done) late[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
+
+// Second pass: the long runs, ONE PATH PER WAVE (every lane makes the same run, lane 0 writes): lanes that run
+// different systems take each other's branches as well as their own, and a wave with three long runs lasted five times
+// as long as its longest; alone, a run of a thousand evaluations takes what its own chain of operations takes.
+template <int NR, int HE>
+__global__ __launch_bounds__(64) void k_rejudge_solve_late(SceneView sc, ChainSource chains, const int32_t *__restrict__ edge_ids,
+                                                            int n_refl_rt, int has_edge_rt, const double *__restrict__ edges,
+                                                            d3 tx, const double *__restrict__ rx,
+                                                            const int32_t *__restrict__ p_rx, const int32_t *__restrict__ p_cand,
+                                                            const int32_t *__restrict__ late,
+                                                            const unsigned long long *__restrict__ late_count, int group,
+                                                            PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
+    const unsigned long long n_late = *late_count;
+    for (unsigned long long k = blockIdx.x; k < n_late; k += gridDim.x) {
+        const int64_t i = late[k];
+        rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, 0x7fffffff,
+                            threadIdx.x == 0, recs, flags);
+    }
+}
+
+__global__ void k_rejudge_scatter(const uint8_t *__restrict__ flags, const PathRec *__restrict__ recs, int64_t n,
                                   const double *__restrict__ a_pts, int32_t *__restrict__ b_rx, int32_t *__restrict__ b_group,
                                   int32_t *__restrict__ b_cand, double *__restrict__ b_pts, unsigned long long *count) {
+    __shared__ int wave_total[4];
+    __shared__ unsigned long long block_base;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !keep[i]) return;
-    const unsigned long long at = atomicAdd(count, 1ull);
-    b_rx[at] = a_rx[i];
-    b_group[at] = a_group[i];
-    b_cand[at] = a_cand[i];
-    for (int q = 0; q < 3 * RT_MAX_ORDER; ++q) b_pts[at * 3 * RT_MAX_ORDER + q] = a_pts[(size_t)i * 3 * RT_MAX_ORDER + q];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool keep = i < n && !flags[i];
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) wave_total[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        block_base = total > 0 ? atomicAdd(count, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    if (!keep) return;
+    unsigned long long at = block_base + __popcll(mask & ((1ull << lane) - 1ull));
+    for (int q = 0; q < wave; ++q) at += wave_total[q];
+    const PathRec &rec = recs[i];
+    b_rx[at] = rec.rx;
+    b_group[at] = rec.group;
+    b_cand[at] = rec.cand;
+    // a line of sight has no points of its own: the caller's stay (zeros)
+    for (int q = 0; q < 3 * RT_MAX_ORDER; ++q)
+        b_pts[at * 3 * RT_MAX_ORDER + q] = q < 3 * rec.npts ? rec.pts[q] : a_pts[(size_t)i * 3 * RT_MAX_ORDER + q];
 }
 
-__global__ void k_rejudge_zero(unsigned long long *count) { *count = 0ull; }
+__global__ void k_rejudge_zero(unsigned long long *counts, int n) {
+    if ((int)threadIdx.x < n) counts[threadIdx.x] = 0ull;
+}
+
+// the kept paths back into the caller's arrays (the count is read on the device: no host wait between the kernels)
+__global__ void k_rejudge_copy_back(const unsigned long long *__restrict__ count, const int32_t *__restrict__ b_rx,
+                                    const int32_t *__restrict__ b_group, const int32_t *__restrict__ b_cand,
+                                    const double *__restrict__ b_pts, int32_t *__restrict__ a_rx, int32_t *__restrict__ a_group,
+                                    int32_t *__restrict__ a_cand, double *__restrict__ a_pts) {
+    const unsigned long long kept = *count;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < kept;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        a_rx[i] = b_rx[i];
+        a_group[i] = b_group[i];
+        a_cand[i] = b_cand[i];
+        for (int q = 0; q < 3 * RT_MAX_ORDER; ++q) a_pts[i * 3 * RT_MAX_ORDER + q] = b_pts[i * 3 * RT_MAX_ORDER + q];
+    }
+}
 
 // Re-judges the n paths in the output arrays (device memory) and packs the kept ones to the front; *n_kept = how many.
-// Queued on the scene's stream and waited for.
+// Queued on the scene's stream and waited for once.
 int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *tx, const double *d_rx, int32_t *d_out_rx,
                      int32_t *d_out_group, int32_t *d_out_cand, double *d_out_pts, int64_t n, int64_t *n_kept) {
     *n_kept = n;
+    scene->last_rejudge_ms = 0;
+    scene->last_rejudge_in = n;
+    scene->last_rejudge_kept = n;
     if (n <= 0) return 0;
-    if ((int)cand->groups.size() > REJ_MAX_GROUPS) RT_FAIL("rt_rejudge_paths: too many candidate groups");
+    const int n_groups = (int)cand->groups.size();
+    if (n_groups > REJ_MAX_GROUPS) RT_FAIL("rt_rejudge_paths: too many candidate groups");
+    if (n > 0x7fffffffLL) RT_FAIL("rt_rejudge_paths: too many paths");
     hipStream_t st = scene->stream;
-    RejudgeGroups G{};
-    G.n_groups = (int)cand->groups.size();
-    for (int g = 0; g < G.n_groups; ++g) {
-        G.n_refl[g] = cand->groups[g].n_refl;
-        G.has_edge[g] = cand->groups[g].has_edge;
-        G.chains[g] = cand->groups[g].source;
-        G.edge_ids[g] = cand->groups[g].edge_ids;
-    }
     const size_t np = (size_t)n;
-    uint8_t *keep = (uint8_t *)rt_scene_temp(scene, np);
+    uint8_t *flags = (uint8_t *)rt_scene_temp(scene, np);
+    PathRec *recs = (PathRec *)rt_scene_temp(scene, sizeof(PathRec) * np);
+    int32_t *lists = (int32_t *)rt_scene_temp(scene, 4 * np * (size_t)std::max(n_groups, 1));
+    int32_t *late = (int32_t *)rt_scene_temp(scene, 4 * np * (size_t)std::max(n_groups, 1));
     int32_t *b_rx = (int32_t *)rt_scene_temp(scene, 4 * np), *b_group = (int32_t *)rt_scene_temp(scene, 4 * np),
             *b_cand = (int32_t *)rt_scene_temp(scene, 4 * np);
     double *b_pts = (double *)rt_scene_temp(scene, sizeof(double) * 3 * RT_MAX_ORDER * np);
-    unsigned long long *count = scene->d_counters + 12;
-    if (!keep || !b_rx || !b_group || !b_cand || !b_pts) RT_FAIL("rt_rejudge_paths: out of device memory");
-    hipLaunchKernelGGL(k_rejudge_zero, dim3(1), dim3(1), 0, st, count);
-    hipLaunchKernelGGL(k_rejudge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, scene->view, G, cand->d_edges, ld3(tx), d_rx,
-                       d_out_rx, d_out_group, d_out_cand, d_out_pts, n, keep);
-    hipLaunchKernelGGL(k_rejudge_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keep, n, d_out_rx, d_out_group,
-                       d_out_cand, d_out_pts, b_rx, b_group, b_cand, b_pts, count);
+    // counters of this step: [0 .. n_groups) paths per group, [REJ_MAX_GROUPS] kept paths, then the paths per group
+    // handed to the second pass (a block of the scene's temporary memory)
+    unsigned long long *counts = (unsigned long long *)rt_scene_temp(scene, sizeof(unsigned long long) * (2 * REJ_MAX_GROUPS + 1));
+    if (!flags || !recs || !lists || !late || !b_rx || !b_group || !b_cand || !b_pts || !counts)
+        RT_FAIL("rt_rejudge_paths: out of device memory");
+    unsigned long long *kept_count = counts + REJ_MAX_GROUPS;
+    unsigned long long *late_counts = counts + REJ_MAX_GROUPS + 1;
+    // two events of the scene's pool around the kernels (the solve's own timer reads only the events it handed out)
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (scene->timing) {
+        for (int k = 0; k < 2; ++k) {
+            if (scene->events_used == scene->event_pool.size()) {
+                hipEvent_t e = nullptr;
+                RT_HIP(hipEventCreate(&e));
+                scene->event_pool.push_back(e);
+            }
+            ev[k] = scene->event_pool[scene->events_used++];
+        }
+        RT_HIP(hipEventRecord(ev[0], st));
+    }
+    hipLaunchKernelGGL(k_rejudge_zero, dim3(1), dim3(64), 0, st, counts, 2 * REJ_MAX_GROUPS + 1);
+    hipLaunchKernelGGL(k_rejudge_classify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out_rx, d_out_group, d_out_cand,
+                       n, n_groups, lists, counts, recs, flags);
+    const d3 TX = ld3(tx);
+    int max_nseg = 0;
+    // The groups that end with a diffraction on the scene's stream, the pure reflections beside them on its side stream
+    // (same priority): a group's second pass lasts as long as its longest run and fills a fraction of the chip, and
+    // the two kinds have about the same to do.  Each stream: first passes, then second passes.
+    if (!scene->side_stream) RT_HIP(hipStreamCreateWithFlags(&scene->side_stream, hipStreamNonBlocking));
+    if (!scene->side_event) RT_HIP(hipEventCreateWithFlags(&scene->side_event, hipEventDisableTiming));
+    if (!scene->rejudge_event) RT_HIP(hipEventCreateWithFlags(&scene->rejudge_event, hipEventDisableTiming));
+    RT_HIP(hipEventRecord(scene->rejudge_event, st));
+    RT_HIP(hipStreamWaitEvent(scene->side_stream, scene->rejudge_event, 0));
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int g = 0; g < n_groups; ++g) {
+            const CandGroup &G = cand->groups[g];
+            if (G.count == 0) continue;
+            if (pass == 0) max_nseg = std::max(max_nseg, G.n_refl + (G.has_edge ? 1 : 0) + 1);
+            hipStream_t where = G.has_edge ? st : scene->side_stream;
+            // (a group's share of the paths is known on the device only: the first pass gets a grid for all of them,
+            // and the blocks beyond the group's share end at once; the second strides over what was handed to it)
+            const dim3 grid1((unsigned)((n + 63) / 64)), grid2((unsigned)std::min<int64_t>(n, 8192)), block(64);
+#define REJ_LAUNCH(NR, HE)                                                                                                       \
+    if (pass == 0)                                                                                                               \
+        hipLaunchKernelGGL((k_rejudge_solve<NR, HE>), grid1, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,       \
+                           G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, lists + (size_t)g * np, counts + g, g,     \
+                           REJ_FIRST_PASS_NFEV, late + (size_t)g * np, late_counts + g, recs, flags);                            \
+    else                                                                                                                         \
+        hipLaunchKernelGGL((k_rejudge_solve_late<NR, HE>), grid2, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,  \
+                           G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, late + (size_t)g * np, late_counts + g, g, \
+                           recs, flags)
+            const int shape = G.n_refl * 2 + (G.has_edge ? 1 : 0);
+            switch (shape) {
+                case 1: REJ_LAUNCH(0, 1); break;
+                case 2: REJ_LAUNCH(1, 0); break;
+                case 3: REJ_LAUNCH(1, 1); break;
+                case 4: REJ_LAUNCH(2, 0); break;
+                case 5: REJ_LAUNCH(2, 1); break;
+                default: REJ_LAUNCH(-1, -1); break;
+            }
+#undef REJ_LAUNCH
+        }
+    }
     RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(scene->side_event, scene->side_stream));
+    RT_HIP(hipStreamWaitEvent(st, scene->side_event, 0));
+    // every segment of every path still standing against the whole scene (ray_tracing.py:257-262, 279), last segment
+    // first, a launch per segment place; a path found cut is skipped by the launches after
+    for (int round = 0; round < max_nseg; ++round)
+        if (rt_launch_obstruct(scene, nullptr, n, nullptr, 0, flags, nullptr, 0, 0, recs, round, false, nullptr, tx, d_rx)) return -1;
+    hipLaunchKernelGGL(k_rejudge_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flags, recs, n, d_out_pts, b_rx,
+                       b_group, b_cand, b_pts, kept_count);
+    hipLaunchKernelGGL(k_rejudge_copy_back, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, kept_count,
+                       b_rx, b_group, b_cand, b_pts, d_out_rx, d_out_group, d_out_cand, d_out_pts);
+    RT_HIP(hipGetLastError());
+    if (ev[1]) RT_HIP(hipEventRecord(ev[1], st));
     unsigned long long kept = 0;
-    RT_HIP(hipMemcpyAsync(&kept, count, sizeof(kept), hipMemcpyDeviceToHost, st));
+    RT_HIP(hipMemcpyAsync(&kept, kept_count, sizeof(kept), hipMemcpyDeviceToHost, st));
     RT_HIP(hipStreamSynchronize(st));
-    if (kept > 0) {
-        RT_HIP(hipMemcpyAsync(d_out_rx, b_rx, 4 * kept, hipMemcpyDeviceToDevice, st));
-        RT_HIP(hipMemcpyAsync(d_out_group, b_group, 4 * kept, hipMemcpyDeviceToDevice, st));
-        RT_HIP(hipMemcpyAsync(d_out_cand, b_cand, 4 * kept, hipMemcpyDeviceToDevice, st));
-        RT_HIP(hipMemcpyAsync(d_out_pts, b_pts, sizeof(double) * 3 * RT_MAX_ORDER * kept, hipMemcpyDeviceToDevice, st));
-        RT_HIP(hipStreamSynchronize(st));
+    if (ev[1]) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) scene->last_rejudge_ms = ms;
     }
     *n_kept = (int64_t)kept;
+    scene->last_rejudge_kept = (int64_t)kept;
+    return 0;
+}
+
+extern "C" int rt_solve_last_rejudge(rt_scene *scene, double *ms, int64_t *n_in, int64_t *n_kept) {
+    if (!scene) RT_FAIL("rt_solve_last_rejudge: null scene");
+    if (ms) *ms = scene->last_rejudge_ms;
+    if (n_in) *n_in = scene->last_rejudge_in;
+    if (n_kept) *n_kept = scene->last_rejudge_kept;
     return 0;
 }
 

@@ -115,6 +115,7 @@ struct rt_scene {
     hipStream_t side_stream = nullptr;  // created on first use: work that runs beside the main stream's (emitter screens,
                                         // the receiver-independent head of a large solve)
     hipEvent_t side_event = nullptr;    // end of the side stream's part of a solve, which the main stream waits for
+    hipEvent_t rejudge_event = nullptr; // what the side stream's part of the re-judging step waits for
     SceneView view{};
     std::vector<void *> allocations;
     // host copies used by host-side set-up code
@@ -149,6 +150,10 @@ struct rt_scene {
     double last_ms[4] = {0, 0, 0, 0};
     int64_t last_launches[4] = {0, 0, 0, 0};
     int64_t last_segments = 0;
+    // the reference-compatible re-judging of the last solve: device time of its kernels (zero with the timing off),
+    // paths that went in, paths kept
+    double last_rejudge_ms = 0;
+    int64_t last_rejudge_in = 0, last_rejudge_kept = 0;
     // device time of the last rt_fields call: [0] k_fields, [1] everything the call queued
     double last_fields_ms[2] = {0, 0};
     // rt_scene_set_deferred_sync: the device-pointer forms of the path description, the field step and the receiver

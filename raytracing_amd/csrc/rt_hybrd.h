@@ -15,6 +15,11 @@
 // times_matrix_t).  The iterates then agree with SciPy's bit for bit (tests/golden/solvers.json: x, success, nfev).
 //
 // Compiles for the device (hipcc) and for the host (a plain C++ compiler, for the CPU test of the restatement).
+//
+// Every routine takes the size of the system as a template argument NC as well as at run time: with NC > 0 every loop
+// bound is a compile-time constant, the loops unroll completely and the vectors and matrices of the method live in
+// registers (a thread of a GPU kernel that indexes them at run time keeps them in scratch memory and waits for every
+// element: 25 ms for one solve).  NC = 0 takes the size at run time.  The operations and their order are the same.
 #pragma once
 
 #include <math.h>
@@ -24,6 +29,14 @@
 #pragma clang fp contract(off)
 #else
 #define RT_HD
+#endif
+
+#if defined(__clang__)
+#define RT_UNROLL _Pragma("unroll")
+#define RT_NOUNROLL _Pragma("nounroll")
+#else
+#define RT_UNROLL
+#define RT_NOUNROLL
 #endif
 
 namespace rt_hybr {
@@ -78,14 +91,17 @@ struct System {
 
 // __generate__ (geometry.py:608-632) and the set-up of the three solvers (:676-687, :733-748, :802-833): fills the
 // system and the first guess x0.
-RT_HD inline void setup(System &s, const double *origin, const double *destination, const double *planes, int n_refl,
+template <int NR = -1>
+RT_HD inline void setup(System &s, const double *origin, const double *destination, const double *planes, int n_refl_rt,
                         const double *edge, double *x0) {
+    const int n_refl = NR >= 0 ? NR : n_refl_rt;
     s.n_refl = n_refl;
     s.has_edge = edge != nullptr;
     for (int k = 0; k < 3; ++k) {
         s.points[0][k] = origin[k];
         s.points[n_refl + 1][k] = destination[k];
     }
+    RT_UNROLL
     for (int i = 0; i < n_refl; ++i) {
         for (int k = 0; k < 3; ++k) s.normal[i][k] = planes[4 * i + k];
         s.d[i] = planes[4 * i + 3];
@@ -105,6 +121,7 @@ RT_HD inline void setup(System &s, const double *origin, const double *destinati
         }
         for (int k = 0; k < 3; ++k) s.points[n_refl + 1][k] = edge[k];  // geometry.py:821: stays there for the whole solve
     }
+    RT_UNROLL
     for (int i = 0; i < n_refl; ++i)
         for (int k = 0; k < 3; ++k) x0[3 * i + k] = s.points[i + 1][k];
     if (edge) x0[3 * n_refl] = edge[0];  // geometry.py:824: points[1:].flat[:-2] ends with the world x of the edge's first end
@@ -130,25 +147,29 @@ RT_HD inline double keller(const System &s, const double *pA, double x_last, dou
 }
 
 // the zero functions: f = F(x); jac only for the pure diffraction (n = 1), where the reference hands its own derivative
+template <int NR = -1, int HE = -1>
 RT_HD inline void evaluate(System &s, const double *x, double *f, double *jac) {
-    const int n = s.n_refl;
+    const int n = NR >= 0 ? NR : s.n_refl;
     if (n == 0) {
         f[0] = keller(s, s.projected_A, x[0], jac);
         return;
     }
+    RT_UNROLL
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k) s.points[i + 1][k] = x[3 * i + k];
     double v[5][3], norms[5];
+    RT_UNROLL
     for (int i = 0; i <= n; ++i) {
         for (int k = 0; k < 3; ++k) v[i][k] = s.points[i + 1][k] - s.points[i][k];
         norms[i] = norm3(v[i]);
     }
+    RT_UNROLL
     for (int i = 0; i < n; ++i) {
         const double g = norms[i] / norms[i + 1];
         const double t = 2 * (s.d[i] + dot3(s.points[i], s.normal[i]));
         for (int k = 0; k < 3; ++k) f[3 * i + k] = (g * v[i + 1][k] - v[i][k]) - t * s.normal[i][k];
     }
-    if (s.has_edge) {
+    if (HE >= 0 ? HE != 0 : s.has_edge != 0) {
         double pA[3];
         times_matrix(s.points[n], s.matrix, pA);
         f[3 * n] = keller(s, pA, x[3 * n], nullptr);
@@ -161,7 +182,9 @@ RT_HD inline void evaluate(System &s, const double *x, double *f, double *jac) {
 #define RT_EPSMCH 2.220446049250313e-16
 #define RT_GIANT 1.7976931348623157e308
 
-RT_HD inline double enorm(int n, const double *x, int stride = 1) {
+// MINPACK's enorm: the Euclidean norm with its guards against overflow and underflow (three sums: large, mid-range and
+// small components).
+RT_HD inline double enorm_guarded(int n, const double *x, int stride = 1) {
     const double rdwarf = 3.834e-20, rgiant = 1.304e19;
     double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
     const double agiant = rgiant / (double)n;
@@ -197,26 +220,78 @@ RT_HD inline double enorm(int n, const double *x, int stride = 1) {
     return x3max * sqrt(s3);
 }
 
+// The guarded form with its components passed by value, kept out of line on the device: a vector with a component
+// outside the mid range is rare, and inlined at the thirty places that take a norm the guards were a third of the code
+// of a solve (which has to stay within the instruction cache).  Components beyond n are zero and add nothing.
+#if defined(__HIPCC__)
+__device__ __noinline__
+#endif
+    inline double
+    enorm_guarded_by_value(int n, double x0, double x1, double x2, double x3, double x4, double x5, double x6, double x7,
+                           double x8, double x9, double x10, double x11, double x12) {
+    const double x[RT_HYBR_MAX_N] = {x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12};
+    return enorm_guarded(n, x);
+}
+
+// enorm as the method calls it.  When every component is zero or in the mid range, the guarded form adds their squares
+// in order and takes the root of the sum (its other two sums stay zero and drop out of its last expression exactly):
+// that is done here; anything else goes to the guarded form.
+// (n is a compile-time constant wherever the caller's loops have unrolled)
+RT_HD inline double enorm(int n, const double *x, int stride = 1) {
+    const double rdwarf = 3.834e-20, rgiant = 1.304e19;
+    const double agiant = rgiant / (double)n;
+    double s2 = 0;
+    bool plain = true;
+    RT_UNROLL
+    for (int i = 0; i < n; ++i) {
+        const double xabs = fabs(x[i * stride]);
+        plain = plain && (xabs == 0 || (xabs > rdwarf && xabs < agiant));
+        s2 += xabs * xabs;
+    }
+    if (plain) return sqrt(s2);
+#if defined(__HIP_DEVICE_COMPILE__)
+    double v[RT_HYBR_MAX_N];
+    RT_UNROLL
+    for (int i = 0; i < RT_HYBR_MAX_N; ++i) v[i] = 0;
+    RT_UNROLL
+    for (int i = 0; i < RT_HYBR_MAX_N; ++i)
+        if (i < n) v[i] = x[i * stride];
+    return enorm_guarded_by_value(n, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]);
+#else
+    return enorm_guarded(n, x, stride);
+#endif
+}
+
 // matrices are column-major with leading dimension RT_HYBR_MAX_N, as MINPACK holds them: a(i, j) = a[i + LD * j]
 #define RT_LD RT_HYBR_MAX_N
 #define A_(a, i, j) (a)[(i) + RT_LD * (j)]
+// the size of the system: the template argument when there is one, else the run-time value
+#define RT_N(NC, n_rt) ((NC) > 0 ? (NC) : (n_rt))
 
-RT_HD inline void qrfac(int n, double *a, double *rdiag, double *acnorm, double *wa) {
+template <int NC>
+RT_HD inline void qrfac(int n_rt, double *a, double *rdiag, double *acnorm, double *wa) {
+    const int n = RT_N(NC, n_rt);
+    RT_UNROLL
     for (int j = 0; j < n; ++j) {
         acnorm[j] = enorm(n, &A_(a, 0, j));
         rdiag[j] = acnorm[j];
         wa[j] = rdiag[j];
     }
+    RT_UNROLL
     for (int j = 0; j < n; ++j) {
         double ajnorm = enorm(n - j, &A_(a, j, j));
         if (ajnorm != 0) {
             if (A_(a, j, j) < 0) ajnorm = -ajnorm;
+            RT_UNROLL
             for (int i = j; i < n; ++i) A_(a, i, j) /= ajnorm;
             A_(a, j, j) += 1;
+            RT_UNROLL
             for (int k = j + 1; k < n; ++k) {
                 double sum = 0;
+                RT_UNROLL
                 for (int i = j; i < n; ++i) sum += A_(a, i, j) * A_(a, i, k);
                 const double temp = sum / A_(a, j, j);
+                RT_UNROLL
                 for (int i = j; i < n; ++i) A_(a, i, k) -= temp * A_(a, i, j);
             }
         }
@@ -224,79 +299,85 @@ RT_HD inline void qrfac(int n, double *a, double *rdiag, double *acnorm, double 
     }
 }
 
-RT_HD inline void qform(int n, double *q, double *wa) {
-    for (int j = 1; j < n; ++j)
+template <int NC>
+RT_HD inline void qform(int n_rt, double *q, double *wa) {
+    const int n = RT_N(NC, n_rt);
+    RT_UNROLL
+    for (int j = 1; j < n; ++j) {
+        RT_UNROLL
         for (int i = 0; i < j; ++i) A_(q, i, j) = 0;
+    }
+    RT_UNROLL
     for (int l = 0; l < n; ++l) {
         const int k = n - l - 1;
+        RT_UNROLL
         for (int i = k; i < n; ++i) {
             wa[i] = A_(q, i, k);
             A_(q, i, k) = 0;
         }
         A_(q, k, k) = 1;
         if (wa[k] != 0) {
+            RT_UNROLL
             for (int j = k; j < n; ++j) {
                 double sum = 0;
+                RT_UNROLL
                 for (int i = k; i < n; ++i) sum += A_(q, i, j) * wa[i];
                 const double temp = sum / wa[k];
+                RT_UNROLL
                 for (int i = k; i < n; ++i) A_(q, i, j) -= temp * wa[i];
             }
         }
     }
 }
 
-// r: upper triangle stored by rows (r[0] = r11, r12 ... r1n, r22 ...)
-RT_HD inline void dogleg(int n, const double *r, const double *diag, const double *qtb, double delta, double *x, double *wa1,
+// r: upper triangle stored by rows (r[0] = r11, r12 ... r1n, r22 ...); row j starts at j n - j (j - 1) / 2
+template <int NC>
+RT_HD inline void dogleg(int n_rt, const double *r, const double *diag, const double *qtb, double delta, double *x, double *wa1,
                          double *wa2) {
-    int jj = (n * (n + 1)) / 2;  // one past the last element (0-based)
+    const int n = RT_N(NC, n_rt);
+    RT_UNROLL
     for (int k = 1; k <= n; ++k) {
         const int j = n - k;  // 0-based row
-        jj -= k;
-        int l = jj + 1;
+        const int jj = j * n - (j * (j - 1)) / 2;  // its diagonal element
         double sum = 0;
-        for (int i = j + 1; i < n; ++i) {
-            sum += r[l] * x[i];
-            ++l;
-        }
+        RT_UNROLL
+        for (int i = j + 1; i < n; ++i) sum += r[jj + (i - j)] * x[i];
         double temp = r[jj];
         if (temp == 0) {
-            l = j;
-            for (int i = 0; i <= j; ++i) {
-                temp = fmax(temp, fabs(r[l]));
-                l += n - i - 1;
-            }
+            RT_UNROLL
+            for (int i = 0; i <= j; ++i) temp = fmax(temp, fabs(r[i * n - (i * (i - 1)) / 2 + (j - i)]));  // column j
             temp = RT_EPSMCH * temp;
             if (temp == 0) temp = RT_EPSMCH;
         }
         x[j] = (qtb[j] - sum) / temp;
     }
+    RT_UNROLL
     for (int j = 0; j < n; ++j) {
         wa1[j] = 0;
         wa2[j] = diag[j] * x[j];
     }
     const double qnorm = enorm(n, wa2);
     if (qnorm <= delta) return;
-    int l = 0;
+    RT_UNROLL
     for (int j = 0; j < n; ++j) {
         const double temp = qtb[j];
-        for (int i = j; i < n; ++i) {
-            wa1[i] += r[l] * temp;
-            ++l;
-        }
+        const int row = j * n - (j * (j - 1)) / 2;
+        RT_UNROLL
+        for (int i = j; i < n; ++i) wa1[i] += r[row + (i - j)] * temp;
         wa1[j] /= diag[j];
     }
     const double gnorm = enorm(n, wa1);
     double sgnorm = 0;
     double alpha = delta / qnorm;
     if (gnorm != 0) {
+        RT_UNROLL
         for (int j = 0; j < n; ++j) wa1[j] = (wa1[j] / gnorm) / diag[j];
-        l = 0;
+        RT_UNROLL
         for (int j = 0; j < n; ++j) {
             double sum = 0;
-            for (int i = j; i < n; ++i) {
-                sum += r[l] * wa1[i];
-                ++l;
-            }
+            const int row = j * n - (j * (j - 1)) / 2;
+            RT_UNROLL
+            for (int i = j; i < n; ++i) sum += r[row + (i - j)] * wa1[i];
             wa2[j] = sum;
         }
         double temp = enorm(n, wa2);
@@ -312,100 +393,108 @@ RT_HD inline void dogleg(int n, const double *r, const double *diag, const doubl
         }
     }
     const double temp = (1 - alpha) * fmin(sgnorm, delta);
+    RT_UNROLL
     for (int j = 0; j < n; ++j) x[j] = temp * wa1[j] + alpha * x[j];
 }
 
-RT_HD inline void r1updt(int n, double *s, const double *u, double *v, double *w, bool *sing) {
+// The rotation of r1updt that eliminates b against a: cosine, sine and the number MINPACK stores for it.  MINPACK
+// writes the two cases (|a| < |b| and the other) as two branches with the same three operations on swapped operands;
+// here the operands are swapped first and the operations written once.
+RT_HD inline void givens(double a, double b, double &cos_, double &sin_, double &tau) {
     const double p5 = 0.5, p25 = 0.25;
-    int jj = (n * (n + 1)) / 2 - 1;  // 0-based index of the last diagonal element (m = n)
-    w[n - 1] = s[jj];
+    const bool steep = fabs(a) < fabs(b);
+    const double q = steep ? a / b : b / a;  // cotangent, or tangent
+    const double first = p5 / sqrt(p25 + p25 * (q * q));
+    const double second = first * q;
+    if (steep) {
+        sin_ = first;
+        cos_ = second;
+        tau = 1;
+        if (fabs(cos_) * RT_GIANT > 1) tau = 1 / cos_;
+    } else {
+        cos_ = first;
+        sin_ = second;
+        tau = sin_;
+    }
+}
+
+// the rotation r1mpyq reads back from such a stored number
+RT_HD inline void givens_stored(double t, double &cos_, double &sin_) {
+    const bool inverse = fabs(t) > 1;
+    const double u = inverse ? 1 / t : t;
+    const double other = sqrt(1 - u * u);
+    cos_ = inverse ? u : other;
+    sin_ = inverse ? other : u;
+}
+
+template <int NC>
+RT_HD inline void r1updt(int n_rt, double *s, const double *u, double *v, double *w, bool *sing) {
+    const int n = RT_N(NC, n_rt);
+    w[n - 1] = s[(n * (n + 1)) / 2 - 1];  // the last diagonal element (m = n)
+    RT_UNROLL
     for (int j = n - 2; j >= 0; --j) {
-        jj -= n - j;
+        const int jj = j * n - (j * (j - 1)) / 2;  // diagonal element of row j
         w[j] = 0;
         if (v[j] != 0) {
             double cos_, sin_, tau;
-            if (fabs(v[n - 1]) < fabs(v[j])) {
-                const double cotan = v[n - 1] / v[j];
-                sin_ = p5 / sqrt(p25 + p25 * (cotan * cotan));
-                cos_ = sin_ * cotan;
-                tau = 1;
-                if (fabs(cos_) * RT_GIANT > 1) tau = 1 / cos_;
-            } else {
-                const double tan_ = v[j] / v[n - 1];
-                cos_ = p5 / sqrt(p25 + p25 * (tan_ * tan_));
-                sin_ = cos_ * tan_;
-                tau = sin_;
-            }
+            givens(v[n - 1], v[j], cos_, sin_, tau);
             v[n - 1] = sin_ * v[j] + cos_ * v[n - 1];
             v[j] = tau;
-            int l = jj;
+            RT_UNROLL
             for (int i = j; i < n; ++i) {
+                const int l = jj + (i - j);
                 const double temp = cos_ * s[l] - sin_ * w[i];
                 w[i] = sin_ * s[l] + cos_ * w[i];
                 s[l] = temp;
-                ++l;
             }
         }
     }
+    RT_UNROLL
     for (int i = 0; i < n; ++i) w[i] += v[n - 1] * u[i];
     *sing = false;
+    RT_UNROLL
     for (int j = 0; j < n - 1; ++j) {
+        const int jj = j * n - (j * (j - 1)) / 2;
         if (w[j] != 0) {
             double cos_, sin_, tau;
-            if (fabs(s[jj]) < fabs(w[j])) {
-                const double cotan = s[jj] / w[j];
-                sin_ = p5 / sqrt(p25 + p25 * (cotan * cotan));
-                cos_ = sin_ * cotan;
-                tau = 1;
-                if (fabs(cos_) * RT_GIANT > 1) tau = 1 / cos_;
-            } else {
-                const double tan_ = w[j] / s[jj];
-                cos_ = p5 / sqrt(p25 + p25 * (tan_ * tan_));
-                sin_ = cos_ * tan_;
-                tau = sin_;
-            }
-            int l = jj;
+            givens(s[jj], w[j], cos_, sin_, tau);
+            RT_UNROLL
             for (int i = j; i < n; ++i) {
+                const int l = jj + (i - j);
                 const double temp = cos_ * s[l] + sin_ * w[i];
                 w[i] = -sin_ * s[l] + cos_ * w[i];
                 s[l] = temp;
-                ++l;
             }
             w[j] = tau;
         }
         if (s[jj] == 0) *sing = true;
-        jj += n - j;
     }
-    s[jj] = w[n - 1];
-    if (s[jj] == 0) *sing = true;
+    const int last = (n * (n + 1)) / 2 - 1;
+    s[last] = w[n - 1];
+    if (s[last] == 0) *sing = true;
 }
 
-// a: m rows (row stride rs, column stride cs), n columns
-RT_HD inline void r1mpyq(int m, int n, double *a, int rs, int cs, const double *v, const double *w) {
+// a: M rows (row stride rs, column stride cs), n columns
+template <int NC, int MC>
+RT_HD inline void r1mpyq(int m_rt, int n_rt, double *a, int rs, int cs, const double *v, const double *w) {
+    const int n = RT_N(NC, n_rt);
+    const int m = RT_N(MC, m_rt);
+    RT_UNROLL
     for (int j = n - 2; j >= 0; --j) {
         double cos_, sin_;
-        if (fabs(v[j]) > 1) {
-            cos_ = 1 / v[j];
-            sin_ = sqrt(1 - cos_ * cos_);
-        } else {
-            sin_ = v[j];
-            cos_ = sqrt(1 - sin_ * sin_);
-        }
+        givens_stored(v[j], cos_, sin_);
+        RT_UNROLL
         for (int i = 0; i < m; ++i) {
             const double temp = cos_ * a[i * rs + j * cs] - sin_ * a[i * rs + (n - 1) * cs];
             a[i * rs + (n - 1) * cs] = sin_ * a[i * rs + j * cs] + cos_ * a[i * rs + (n - 1) * cs];
             a[i * rs + j * cs] = temp;
         }
     }
+    RT_UNROLL
     for (int j = 0; j < n - 1; ++j) {
         double cos_, sin_;
-        if (fabs(w[j]) > 1) {
-            cos_ = 1 / w[j];
-            sin_ = sqrt(1 - cos_ * cos_);
-        } else {
-            sin_ = w[j];
-            cos_ = sqrt(1 - sin_ * sin_);
-        }
+        givens_stored(w[j], cos_, sin_);
+        RT_UNROLL
         for (int i = 0; i < m; ++i) {
             const double temp = cos_ * a[i * rs + j * cs] + sin_ * a[i * rs + (n - 1) * cs];
             a[i * rs + (n - 1) * cs] = -sin_ * a[i * rs + j * cs] + cos_ * a[i * rs + (n - 1) * cs];
@@ -415,13 +504,19 @@ RT_HD inline void r1mpyq(int m, int n, double *a, int rs, int cs, const double *
 }
 
 struct Result {
-    int info;  // 1 = converged (what SciPy reports as success)
+    int info;  // 1 = converged (what SciPy reports as success); -1 = stopped at the caller's evaluation limit, unfinished
     int nfev;
 };
 
-// hybrd (finite-difference Jacobian) or, with user_jac, hybrj (the system hands its own Jacobian; n = 1 here)
-RT_HD inline Result hybr(System &sys, double *x, bool user_jac) {
-    const int n = sys.n_unknowns();
+// hybrd (finite-difference Jacobian) or, with user_jac, hybrj (the system hands its own Jacobian; n = 1 here).
+// NR reflections and HE (ends with a diffraction) as template arguments (then NC = 3 NR + HE unknowns), or -1, -1 for a
+// system whose shape is known at run time only.
+// nfev_limit: a run that has made this many evaluations without ending is given up (info -1); the caller then runs it
+// again without a limit.  A GPU kernel uses it to set the few long runs apart from the many short ones.
+template <int NR, int HE>
+RT_HD inline Result hybr(System &sys, double *x, bool user_jac, int nfev_limit = 0x7fffffff) {
+    constexpr int NC = NR >= 0 ? 3 * NR + HE : 0;
+    const int n = RT_N(NC, sys.n_unknowns());
     const double xtol = 1.49012e-08, factor = 100.0;
     const double p1 = 0.1, p5 = 0.5, p001 = 1e-3, p0001 = 1e-4;
     const int maxfev = (user_jac ? 100 : 200) * (n + 1);
@@ -430,7 +525,7 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac) {
     double fjac[RT_HYBR_MAX_N * RT_HYBR_MAX_N], r[(RT_HYBR_MAX_N * (RT_HYBR_MAX_N + 1)) / 2];
     Result res{0, 0};
     double jac1 = 0;
-    evaluate(sys, x, fvec, user_jac ? &jac1 : nullptr);
+    evaluate<NR, HE>(sys, x, fvec, user_jac ? &jac1 : nullptr);
     res.nfev = 1;
     double fnorm = enorm(n, fvec);
     int iter = 1, ncsuc = 0, ncfail = 0, nslow1 = 0, nslow2 = 0;
@@ -439,54 +534,73 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac) {
     while (true) {
         bool jeval = true;
         if (user_jac) {
-            evaluate(sys, x, wa1, &jac1);  // n = 1: the Jacobian is the one number
+            evaluate<NR, HE>(sys, x, wa1, &jac1);  // n = 1: the Jacobian is the one number
             A_(fjac, 0, 0) = jac1;
         } else {
+            // (the loop over the columns is not unrolled, so that the zero function is in the code once: column j is
+            // picked out of x and put into the matrix with comparisons against j, which keep every index a constant)
+            RT_NOUNROLL
             for (int j = 0; j < n; ++j) {
-                const double temp = x[j];
+                double temp = 0;
+                RT_UNROLL
+                for (int i = 0; i < n; ++i)
+                    if (i == j) temp = x[i];
                 double h = eps * fabs(temp);
                 if (h == 0) h = eps;
-                x[j] = temp + h;
-                evaluate(sys, x, wa1, nullptr);
-                x[j] = temp;
-                for (int i = 0; i < n; ++i) A_(fjac, i, j) = (wa1[i] - fvec[i]) / h;
+                RT_UNROLL
+                for (int i = 0; i < n; ++i) wa2[i] = i == j ? temp + h : x[i];
+                evaluate<NR, HE>(sys, wa2, wa1, nullptr);
+                RT_UNROLL
+                for (int i = 0; i < n; ++i) wa3[i] = (wa1[i] - fvec[i]) / h;
+                RT_UNROLL
+                for (int k = 0; k < n; ++k)
+                    if (k == j) {
+                        RT_UNROLL
+                        for (int i = 0; i < n; ++i) A_(fjac, i, k) = wa3[i];
+                    }
             }
             res.nfev += n;
         }
-        qrfac(n, fjac, wa1, wa2, wa3);
+        qrfac<NC>(n, fjac, wa1, wa2, wa3);
         if (iter == 1) {
+            RT_UNROLL
             for (int j = 0; j < n; ++j) {
                 diag[j] = wa2[j];
                 if (wa2[j] == 0) diag[j] = 1;
             }
+            RT_UNROLL
             for (int j = 0; j < n; ++j) wa3[j] = diag[j] * x[j];
             xnorm = enorm(n, wa3);
             delta = factor * xnorm;
             if (delta == 0) delta = factor;
         }
+        RT_UNROLL
         for (int i = 0; i < n; ++i) qtf[i] = fvec[i];
+        RT_UNROLL
         for (int j = 0; j < n; ++j) {
             if (A_(fjac, j, j) != 0) {
                 double sum = 0;
+                RT_UNROLL
                 for (int i = j; i < n; ++i) sum += A_(fjac, i, j) * qtf[i];
                 const double temp = -sum / A_(fjac, j, j);
+                RT_UNROLL
                 for (int i = j; i < n; ++i) qtf[i] += A_(fjac, i, j) * temp;
             }
         }
         bool sing = false;
+        RT_UNROLL
         for (int j = 0; j < n; ++j) {
-            int l = j;
-            for (int i = 0; i < j; ++i) {
-                r[l] = A_(fjac, i, j);
-                l += n - i - 1;
-            }
-            r[l] = wa1[j];
+            RT_UNROLL
+            for (int i = 0; i < j; ++i) r[i * n - (i * (i - 1)) / 2 + (j - i)] = A_(fjac, i, j);  // column j above the diagonal
+            r[j * n - (j * (j - 1)) / 2] = wa1[j];
             if (wa1[j] == 0) sing = true;
         }
-        qform(n, fjac, wa1);
+        qform<NC>(n, fjac, wa1);
+        RT_UNROLL
         for (int j = 0; j < n; ++j) diag[j] = fmax(diag[j], wa2[j]);
         while (true) {
-            dogleg(n, r, diag, qtf, delta, wa1, wa2, wa3);
+            dogleg<NC>(n, r, diag, qtf, delta, wa1, wa2, wa3);
+            RT_UNROLL
             for (int j = 0; j < n; ++j) {
                 wa1[j] = -wa1[j];
                 wa2[j] = x[j] + wa1[j];
@@ -494,7 +608,7 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac) {
             }
             const double pnorm = enorm(n, wa3);
             if (iter == 1) delta = fmin(delta, pnorm);
-            evaluate(sys, wa2, wa4, nullptr);
+            evaluate<NR, HE>(sys, wa2, wa4, nullptr);
             ++res.nfev;
             const double fnorm1 = enorm(n, wa4);
             double actred = -1;
@@ -502,13 +616,12 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac) {
                 const double q = fnorm1 / fnorm;
                 actred = 1 - q * q;
             }
-            int l = 0;
+            RT_UNROLL
             for (int i = 0; i < n; ++i) {
                 double sum = 0;
-                for (int j = i; j < n; ++j) {
-                    sum += r[l] * wa1[j];
-                    ++l;
-                }
+                const int row = i * n - (i * (i - 1)) / 2;
+                RT_UNROLL
+                for (int j = i; j < n; ++j) sum += r[row + (j - i)] * wa1[j];
                 wa3[i] = qtf[i] + sum;
             }
             const double temp = enorm(n, wa3);
@@ -530,6 +643,7 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac) {
                 if (fabs(ratio - 1) <= p1) delta = pnorm / p5;
             }
             if (ratio >= p0001) {
+                RT_UNROLL
                 for (int j = 0; j < n; ++j) {
                     x[j] = wa2[j];
                     wa2[j] = diag[j] * x[j];
@@ -545,36 +659,49 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac) {
             if (actred >= p1) nslow2 = 0;
             if (delta <= xtol * xnorm || fnorm == 0) res.info = 1;
             if (res.info != 0) return res;
+            if (res.nfev >= nfev_limit) {
+                res.info = -1;
+                return res;
+            }
             if (res.nfev >= maxfev) res.info = 2;
             if (p1 * fmax(p1 * delta, pnorm) <= RT_EPSMCH * xnorm) res.info = 3;
             if (nslow2 == 5) res.info = 4;
             if (nslow1 == 10) res.info = 5;
             if (res.info != 0) return res;
             if (ncfail == 2) break;
+            RT_UNROLL
             for (int j = 0; j < n; ++j) {
                 double sum = 0;
+                RT_UNROLL
                 for (int i = 0; i < n; ++i) sum += A_(fjac, i, j) * wa4[i];
                 wa2[j] = (sum - wa3[j]) / pnorm;
                 wa1[j] = diag[j] * ((diag[j] * wa1[j]) / pnorm);
                 if (ratio >= p0001) qtf[j] = sum;
             }
-            r1updt(n, r, wa1, wa2, wa3, &sing);
-            r1mpyq(n, n, fjac, 1, RT_LD, wa2, wa3);
-            r1mpyq(1, n, qtf, 0, 1, wa2, wa3);
+            r1updt<NC>(n, r, wa1, wa2, wa3, &sing);
+            r1mpyq<NC, NC>(n, n, fjac, 1, RT_LD, wa2, wa3);
+            r1mpyq<NC, 1>(1, n, qtf, 0, 1, wa2, wa3);
             jeval = false;
         }
     }
 }
 
 // What the reference's solver call returns for one candidate: the solver's points (n_refl reflection points, then the
-// diffraction point) and whether SciPy would report success.
-RT_HD inline bool solve_like_reference(const double *origin, const double *destination, const double *planes, int n_refl,
-                                       const double *edge, double *out_points, int *nfev) {
+// diffraction point) and whether SciPy would report success.  NR, HE: the shape of the system as template arguments
+// (n_refl and edge must agree with them), or -1, -1.
+// nfev_limit / unfinished: see hybr.
+template <int NR, int HE>
+RT_HD inline bool solve_shape(const double *origin, const double *destination, const double *planes, int n_refl_rt,
+                              const double *edge, double *out_points, int *nfev, int nfev_limit = 0x7fffffff,
+                              bool *unfinished = nullptr) {
+    const int n_refl = NR >= 0 ? NR : n_refl_rt;
     System sys;
     double x[RT_HYBR_MAX_N];
-    setup(sys, origin, destination, planes, n_refl, edge, x);
-    const Result res = hybr(sys, x, n_refl == 0);
+    setup<NR>(sys, origin, destination, planes, n_refl, edge, x);
+    const Result res = hybr<NR, HE>(sys, x, n_refl == 0, nfev_limit);
     if (nfev) *nfev = res.nfev;
+    if (unfinished) *unfinished = res.info < 0;
+    RT_UNROLL
     for (int i = 0; i < n_refl; ++i)
         for (int k = 0; k < 3; ++k) out_points[3 * i + k] = x[3 * i + k];
     if (edge) {
@@ -584,7 +711,28 @@ RT_HD inline bool solve_like_reference(const double *origin, const double *desti
     return res.info == 1;
 }
 
+// the same for any shape: the shapes up to two reflections take their unrolled forms, the rest the run-time form
+RT_HD inline bool solve_like_reference(const double *origin, const double *destination, const double *planes, int n_refl,
+                                       const double *edge, double *out_points, int *nfev) {
+    if (edge) {
+        if (n_refl == 0) return solve_shape<0, 1>(origin, destination, planes, 0, edge, out_points, nfev);
+        if (n_refl == 1) return solve_shape<1, 1>(origin, destination, planes, 1, edge, out_points, nfev);
+        if (n_refl == 2) return solve_shape<2, 1>(origin, destination, planes, 2, edge, out_points, nfev);
+    } else {
+        if (n_refl == 1) return solve_shape<1, 0>(origin, destination, planes, 1, edge, out_points, nfev);
+        if (n_refl == 2) return solve_shape<2, 0>(origin, destination, planes, 2, edge, out_points, nfev);
+    }
+    return solve_shape<-1, -1>(origin, destination, planes, n_refl, edge, out_points, nfev);
+}
+
+// the run-time form alone (what the unrolled forms are held against in the CPU test)
+RT_HD inline bool solve_like_reference_generic(const double *origin, const double *destination, const double *planes,
+                                               int n_refl, const double *edge, double *out_points, int *nfev) {
+    return solve_shape<-1, -1>(origin, destination, planes, n_refl, edge, out_points, nfev);
+}
+
 #undef A_
 #undef RT_LD
+#undef RT_N
 
 }  // namespace rt_hybr

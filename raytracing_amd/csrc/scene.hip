@@ -373,6 +373,7 @@ extern "C" void rt_scene_destroy(rt_scene *s) {
     (void)rt_use_device(s->device);
     if (s->caller_event) (void)hipEventDestroy(s->caller_event);
     if (s->side_event) (void)hipEventDestroy(s->side_event);
+    if (s->rejudge_event) (void)hipEventDestroy(s->rejudge_event);
     if (s->side_stream) {
         (void)hipStreamSynchronize(s->side_stream);
         (void)hipStreamDestroy(s->side_stream);

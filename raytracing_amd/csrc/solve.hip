@@ -1689,6 +1689,8 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         scene->last_launches[f] = 0;
     }
     scene->last_segments = 0;
+    scene->last_rejudge_ms = 0;
+    scene->last_rejudge_in = scene->last_rejudge_kept = 0;
     if (n_rx == 0) return 0;
 
     // device views of the caller's arrays

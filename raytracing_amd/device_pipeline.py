@@ -153,6 +153,7 @@ class DevicePipeline:
                     self.scene.synchronize()
             fields_timing = self.field_scene.fields_timing()
         solve_timing = self.scene.last_timing()  # (kept by the library until the next solve)
+        solve_timing["rejudge"] = self.scene.rejudge_timing()  # (zeros unless the scene is in reference-compatible mode)
         return PathBlock(buffers=b, scene=self.field_scene, n_rx=n_rx, n_paths=n, n_attempted=int(attempted),
                          power_db=power_db, frequencies=freqs, records=rec, solve_timing=solve_timing,
                          fields_timing=fields_timing)

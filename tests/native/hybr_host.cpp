@@ -7,3 +7,9 @@ extern "C" int rt_hybr_host_solve(const double *origin, const double *destinatio
                                   const double *edge, double *out_points, int *nfev) {
     return rt_hybr::solve_like_reference(origin, destination, planes, n_refl, edge, out_points, nfev) ? 1 : 0;
 }
+
+// the run-time-sized form alone (the entry point above takes the unrolled forms for the shapes that have one)
+extern "C" int rt_hybr_host_solve_generic(const double *origin, const double *destination, const double *planes, int n_refl,
+                                          const double *edge, double *out_points, int *nfev) {
+    return rt_hybr::solve_like_reference_generic(origin, destination, planes, n_refl, edge, out_points, nfev) ? 1 : 0;
+}

@@ -68,3 +68,61 @@ def oracle_polys_with_buildings(place):
 
 def path_key(rx, kind, order, chain, edge):
     return (int(rx), str(kind), int(order), tuple(int(c) for c in chain), tuple(int(c) for c in edge))
+
+
+# ---- full-size workloads whose every surviving path is pinned against SciPy's hybr (tests/golden/*_rejudge.npz) ---------
+
+FULL_SIZE = ("levant", "lln")
+
+
+def full_size_workload(name):
+    """-> (place, tx, rx, order, with_diffraction): config 2 (levant) and config 3 (lln) of BASELINE.json at full size."""
+    from raytracing_amd import scenarios
+
+    if name == "lln":
+        place, tx, rx = scenarios.lln_grid(100)
+        return place, tx, rx, 2, True
+    if name == "levant":
+        place, tx, rx = scenarios.levant_grid(32)
+        return place, tx, rx, 2, False
+    raise KeyError(name)
+
+
+def full_size_solve(name, modes=("exact", "reference"), frequency=12.5e9):
+    """Solves a full-size workload on the GPU in the given solver modes; per mode the paths sorted by (receiver, group,
+    candidate) with their description, the per-receiver dB and the field status codes."""
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+
+    place, tx, rx, order, with_diffraction = full_size_workload(name)
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons))
+    if with_diffraction:
+        pairs, edges = scene.sharp_edges()
+    else:
+        pairs, edges = np.zeros((0, 2), np.int32), np.zeros((0, 2, 3))
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
+    ev = np.logical_or.reduce(screens)
+    cand = scene.enumerate(vis, ev, pairs, edges, order, with_diffraction=with_diffraction)
+    out = dict(tx=np.asarray(tx, float).reshape(3), rx=rx, order=order, with_diffraction=with_diffraction,
+               n_polygons=len(polygons), ev=ev, edge_pairs=pairs, edges=edges, place=place)
+    for mode in modes:
+        scene.set_reference_solver(mode == "reference")
+        res = scene.solve_paths(cand, tx, rx)  # sorted by (receiver, group, candidate)
+        n = len(res["rx"])
+        keep = res["group"] >= 0
+        kind = np.zeros(n, dtype=np.int32)
+        chain = np.zeros((n, _lib.RT_MAX_ORDER), dtype=np.int32)
+        epolys = np.zeros((n, 2), dtype=np.int32)
+        epts = np.zeros((n, 6))
+        kind[keep], chain[keep], epolys[keep], epts[keep] = cand.describe(res["group"][keep], res["cand"][keep])
+        fields = scene.fields(tx, rx, res["rx"], kind, chain, epolys, epts, res["points"], [frequency])
+        out[mode] = dict(rx=res["rx"], group=res["group"].astype(np.int8), cand=res["cand"], points=res["points"][:, :order].copy(),
+                         kind=kind, chain=chain[:, :order].copy(), edge_polys=epolys, edge_points=epts,
+                         db=fields["power_db"][:, 0], status=fields["status"], n_attempted=res["n_attempted"],
+                         rejudge=scene.rejudge_timing())
+    scene.set_reference_solver(False)
+    cand.close()
+    scene.close()
+    return out
