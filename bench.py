@@ -36,13 +36,15 @@ sys.path.insert(0, ROOT)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (half the 157.3 TFLOP/s fp32 vector rate)
 HBM_PEAK_GBS = 8000.0
 FREQUENCY_HZ = 12.5e9  # materials_properties.py:23 of the reference
+T_PROCESS = 0.0  # when this process entered main()
 
 
 def committed_counters():
-    """Per-kernel counter figures of the committed rocprofv3 --pmc passes of this script (scripts/counters_json.py writes
-    the file): HBM bytes per launch with FETCH_SIZE doubled as gfx950 needs, and where the waves' cycles go."""
+    """Per-kernel counter figures of the committed rocprofv3 --pmc passes of this script (scripts/profile_round3.sh runs
+    them, scripts/counters_json.py writes the file): the double-precision operations a launch executes, its HBM bytes
+    with FETCH_SIZE doubled as gfx950 needs, launches per step, and where the waves' cycles go."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_counters.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r3_counters.json")) as f:
             return json.load(f)
     except (OSError, ValueError):
         return {}
@@ -74,11 +76,11 @@ def launch_workers(args):
 # CPU baseline: the oracle (test infrastructure) timed on this host's cores; never part of the measured GPU path
 # ---------------------------------------------------------------------------------------------------------------
 def cpu_baseline_worker(args):
-    """Oracle path-solves for one receiver on a strided sample of the candidate chains, for about `budget` s."""
+    """Oracle path-solves for one receiver on a sample of the candidates of every group, for about `budget` s."""
     import warnings
 
     warnings.filterwarnings("ignore")
-    polys_data, tx, rx, chains, budget = args
+    polys_data, tx, rx, sample, budget = args
     from oracle import geometry_oracle as go
     from oracle import ray_tracing_oracle as ro
 
@@ -90,27 +92,52 @@ def cpu_baseline_worker(args):
     o = ro.RayTracingOracle(tx, polys, rx.reshape(1, 3), precompute=False)
     t0 = time.perf_counter()
     n = 0
-    for chain in chains:
+    for chain, edge in sample:
         planes = [polys[i].parametric for i in chain]
-        points, sol = go.reflexion_points_from_origin_destination_and_planes(tx, rx, planes)
-        if sol.success:
-            lines = np.vstack([tx.reshape(1, 3), points, rx.reshape(1, 3)])
-            o.check_reflections(lines, list(chain))
+        if edge is None:  # ray_tracing.py:307-314
+            points, sol = go.reflexion_points_from_origin_destination_and_planes(tx, rx, planes)
+            if sol.success:
+                lines = np.vstack([tx.reshape(1, 3), points, rx.reshape(1, 3)])
+                o.check_reflections(lines, list(chain))
+        else:  # ray_tracing.py:341-350, 369-376
+            points, sol = go.reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge(tx, rx, planes, edge)
+            if sol.success:
+                lines = np.vstack([tx.reshape(1, 3), np.asarray(points).reshape(-1, 3), rx.reshape(1, 3)])
+                o.check_reflections_and_diffraction(lines, list(chain), edge)
         n += 1
         if time.perf_counter() - t0 > budget:
             break
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(place, tx, rx, chains2, budget_s=5.0, receivers_per_core=2):
+def cpu_baseline(place, tx, rx, cand, budget_s=5.0, receivers_per_core=2, per_receiver=4000):
+    """The oracle's restatement of the reference's solve (SciPy hybr per candidate, then the checks) on a sample of the
+    candidates of EVERY group, each group in proportion to its share of the workload."""
     import multiprocessing as mp
 
     # the GPU box gives one GPU's job a share of 16 host cores (its os.cpu_count() is the whole machine's)
     host_cpus = os.cpu_count() or 1
     cores = min(16, host_cpus)
     polys_data = [(p.points, p.get_parametric()) for p in place.get_polygons_list()]
-    stride = max(1, len(chains2) // 4000)
-    sample = [tuple(int(v) for v in c) for c in chains2[::stride]]
+    total = int(cand.counts.sum())
+    sample, shares = [], []
+    for g in range(cand.n_groups):
+        count = int(cand.counts[g])
+        if count == 0:
+            continue
+        n_refl, has_edge = cand.group_kind(g)
+        take = max(1, round(per_receiver * count / total))
+        stride = max(1, count // take)
+        chains, edge_ids = cand.group(g)
+        picked = 0
+        for c in range(0, count, stride):
+            chain = tuple(int(v) for v in chains[c]) if n_refl else ()
+            sample.append((chain, cand.edges[edge_ids[c]].copy() if has_edge else None))
+            picked += 1
+        shares.append(f"{'R' * n_refl}{'D' if has_edge else ''} {picked} of {count}")
+    # interleaved, so that a receiver that runs out of time has met the groups in proportion all the same
+    order = np.random.default_rng(0).permutation(len(sample))
+    sample = [sample[i] for i in order]
     rx_ids = np.linspace(0, len(rx) - 1, receivers_per_core * cores).astype(int)
     jobs = [(polys_data, tx, rx[i], sample, budget_s) for i in rx_ids]
     t0 = time.perf_counter()
@@ -120,65 +147,136 @@ def cpu_baseline(place, tx, rx, chains2, budget_s=5.0, receivers_per_core=2):
     solves = sum(r[0] for r in res)
     busy = sum(r[1] for r in res) / cores  # time per core, all cores busy
     return {"value": solves / busy, "unit": "path-solves/s", "cores": cores, "host_cpu_count": host_cpus, "kind": "port",
-            "sample": f"{len(jobs)} receivers x up to {len(sample)} order-2 chains (every {stride}th of {len(chains2)}) of "
-                      f"the same workload = {solves} path-solves; oracle = the reference's algorithm with SciPy hybr and "
-                      f"its checks, one process per core on the {cores} cores this job may use (os.cpu_count() = "
+            "sample": f"{len(jobs)} receivers x up to {len(sample)} candidates of the same workload, every group in proportion "
+                      f"to its share ({'; '.join(shares)}) = {solves} path-solves; oracle = the reference's algorithm with SciPy "
+                      f"hybr and its checks, one process per core on the {cores} cores this job may use (os.cpu_count() = "
                       f"{host_cpus}), {busy:.0f} s of work per core ({wall:.0f} s wall with process start-up)"}
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # rooflines
 # ---------------------------------------------------------------------------------------------------------------
-def kernel_rooflines(n_rx, counts, max_order, n_poly, n_vert, ms, launches, segments_walked, n_paths, counters,
-                     n_valid_paths):
-    """Algorithmic work of one step of one rank over the mean device time of each kernel family.  Work per unit:
-    reflection / diffraction candidates 40 flop per interaction of every (receiver, candidate) pair; obstruction
-    13 N flop per segment walked (a segment against every polygon, as the reference tests it) and, as bytes, 49 per
-    segment plus the scene once per launch; fields 24 (k + 2) + 4 k + 160 bytes per path of k interactions."""
-    refl_flop = 40.0 * n_rx * sum((g + 1) * counts[g] for g in range(max_order))
-    diff_flop = 40.0 * n_rx * sum((m + 1) * counts[max_order + m] for m in range(max_order))
-    occ_flop = 13.0 * n_poly * segments_walked
-    occ_bytes = 49.0 * segments_walked + (64.0 * n_poly + 24.0 * n_vert) * max(launches["obstruct"], 1)
-    field_bytes = float(n_paths)  # the caller passes the bytes themselves (it knows each path's interactions)
+# kernels whose counters make up a family of the step (names without template arguments, as scripts/counters_json.py keys them)
+FAMILY_KERNELS = {
+    "reflect": ("k_reflect_tiled", "k_reflect", "k_rx_count", "k_rx_scatter", "k_rx_boxes"),
+    "diffract": ("k_diffract", "k_diffract_setup", "k_rd_prepare", "k_rd_filter"),
+    "obstruct": ("k_obstruct_grid", "k_obstruct", "k_list_clear_flags"),
+    "rejudge": ("k_rejudge_solve", "k_rejudge_solve_late", "k_rejudge_classify", "k_rejudge_scatter", "k_rejudge_copy_back"),
+    "fields": ("k_fields",),
+}
 
-    def entry(kernel, bound, work, t_ms, extra=None):
-        peak = FP64_VECTOR_PEAK_TFLOPS if bound == "valu_fp64" else HBM_PEAK_GBS
-        scale = 1e12 if bound == "valu_fp64" else 1e9
-        achieved = work / (t_ms * 1e-3) / scale if t_ms > 0 else 0.0
-        e = {"kernel": kernel, "bound": bound, "achieved": achieved, "peak": peak,
-             "unit": "TFLOP/s" if bound == "valu_fp64" else "GB/s", "frac": achieved / peak, "ms_per_step": t_ms,
-             "algorithmic_work_per_step": work}
-        c = counters.get(kernel.split("<")[0].split(" ")[0])
-        if c:
-            e["traffic"] = c.get("hbm_bytes_per_launch")
-            e["traffic_note"] = "HBM bytes per launch from the committed counter passes: 2 x FETCH_SIZE + WRITE_SIZE"
+
+def family_counters(counters, family):
+    """Executed fp64 flop and HBM bytes per step of a family, from the committed counter passes: per launch figures times
+    the launches per step of the same passes, summed over the family's kernels.  None when the passes are missing."""
+    flop = hbm = 0.0
+    seen = False
+    detail = {}
+    for k in FAMILY_KERNELS[family]:
+        c = counters.get(k)
+        if not c or "fp64_flop_per_launch" not in c:
+            continue
+        seen = True
+        per_step = c.get("launches_per_step", 0.0)
+        # (the second pass of the re-judging step runs ONE path per wave, its 64 lanes making the same run: the work
+        # counts once, not 64 times)
+        once = 1.0 / 64.0 if k == "k_rejudge_solve_late" else 1.0
+        flop += c["fp64_flop_per_launch"] * per_step * once
+        hbm += c.get("hbm_bytes_per_launch", 0.0) * per_step
+        detail[k] = {"launches_per_step": per_step, "fp64_flop_per_launch": c["fp64_flop_per_launch"] * once,
+                     "hbm_bytes_per_launch": c.get("hbm_bytes_per_launch"),
+                     "lanes_on_share_of_valu_cycles": c.get("lanes_on_share_of_valu_cycles")}
+    return (flop, hbm, detail) if seen else (None, None, {})
+
+
+def kernel_rooflines(n_rx, counts, max_order, n_poly, n_vert, ms, segments_walked, field_bytes, counters, n_valid_paths):
+    """One entry per kernel family of a step.  For the arithmetic-bound families `achieved` is the double-precision
+    work the lanes EXECUTED (counter passes: fp64 instructions x lanes switched on, per launch x launches per step) over
+    the family's mean device time in a step, measured live with HIP events; `frac` = achieved / vector fp64 peak, at most
+    1 by construction.  The algorithmic count of the reference's brute force (40 flop per interaction of every
+    (receiver, candidate) pair; 13 N flop per segment walked) over the same time is kept beside it as
+    `speed_vs_brute_force`: the kernels reject whole receiver tiles and grid cells, so it exceeds 1.  The field kernel is
+    priced against HBM by its algorithmic bytes (24 (k + 2) + 4 k + 160 per path of k interactions)."""
+    algorithmic = {
+        "reflect": 40.0 * n_rx * sum((g + 1) * counts[g] for g in range(max_order)),
+        "diffract": 40.0 * n_rx * sum((m + 1) * counts[max_order + m] for m in range(max_order)),
+        "obstruct": 13.0 * n_poly * segments_walked,
+        "rejudge": None,
+    }
+    names = {"reflect": "k_reflect_tiled<2> (orders 1 and 2)", "diffract": "k_diffract<0>, k_diffract<1>",
+             "obstruct": "k_obstruct_grid", "rejudge": "k_rejudge_solve<shape>, k_rejudge_solve_late<shape>",
+             "fields": "k_fields"}
+    out = {}
+    for fam in ("reflect", "diffract", "obstruct", "rejudge"):
+        t_ms = ms[fam]
+        flop, hbm, detail = family_counters(counters, fam)
+        e = {"kernel": names[fam], "bound": "valu_fp64", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "ms_per_step": t_ms}
+        if flop is not None and t_ms > 0:
+            e["work_per_step"] = flop
+            e["work_kind"] = "fp64 operations executed by switched-on lanes (committed counter passes)"
+            e["achieved"] = flop / (t_ms * 1e-3) / 1e12
+            e["frac"] = e["achieved"] / FP64_VECTOR_PEAK_TFLOPS
+            e["traffic"] = hbm
+            e["traffic_note"] = "HBM bytes per step from the committed counter passes: (2 x FETCH_SIZE + WRITE_SIZE) x launches per step"
+            e["hbm_achieved_GBs"] = hbm / (t_ms * 1e-3) / 1e9
+            e["hbm_frac"] = e["hbm_achieved_GBs"] / HBM_PEAK_GBS
+            e["counters_by_kernel"] = detail
+            main = counters.get(FAMILY_KERNELS[fam][0 if fam != "rejudge" else 1], {})
             for k in ("wave_cycles_issuing_valu_share", "wave_cycles_issuing_share", "wave_cycles_waiting_share",
                       "wave_cycles_issue_stalled_share", "valu_instructions_per_wave", "fp64_share_of_valu_instructions"):
-                if k in c:
-                    e[k] = c[k]
-            e["counter_source"] = c.get("source")
-        if extra:
-            e.update(extra)
-        return e
+                if k in main:
+                    e[k] = main[k]
+        else:
+            e.update(work_per_step=0.0, work_kind="no counter passes committed for this family", achieved=0.0, frac=0.0, traffic=None)
+        if algorithmic[fam] is not None and t_ms > 0:
+            e["algorithmic_flop_per_step"] = algorithmic[fam]
+            e["speed_vs_brute_force"] = algorithmic[fam] / (t_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS
+        out[fam] = e
+    out["obstruct"]["segments_walked_per_step"] = segments_walked
+    out["obstruct"]["algorithmic_bytes_per_step"] = 49.0 * segments_walked + (64.0 * n_poly + 24.0 * n_vert)
+    out["rejudge"]["note"] = ("the reference's solver call (MINPACK hybr restated) on every path found: a chain of dependent "
+                              "fp64 operations per path, 10 to 1 000 evaluations long; the second pass runs the long runs one "
+                              "per wave, so its time is the longest run's latency, not throughput")
+    t_ms = ms["fields"]
+    flop, hbm, detail = family_counters(counters, "fields")
+    ach = field_bytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+    out["fields"] = {"kernel": names["fields"], "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": t_ms,
+                     "work_per_step": field_bytes, "work_kind": "algorithmic bytes: 24 (k + 2) + 4 k + 160 per path",
+                     "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": hbm, "paths_per_step": n_valid_paths}
+    if flop is not None and t_ms > 0:
+        out["fields"]["fp64_executed_TFLOPs"] = flop / (t_ms * 1e-3) / 1e12
+        out["fields"]["fp64_frac"] = out["fields"]["fp64_executed_TFLOPs"] / FP64_VECTOR_PEAK_TFLOPS
+    return out
 
-    return {
-        "reflect": entry("k_reflect_tiled<2> (orders 1 and 2)", "valu_fp64", refl_flop, ms["reflect"],
-                         {"note": "whole receiver tiles are rejected with an interval test: speed against brute force "
-                                  "(can exceed 1), not vector-unit utilisation"}),
-        "diffract": entry("k_diffract<0>, k_diffract<1>", "valu_fp64", diff_flop, ms["diffract"]),
-        "obstruct": entry("k_obstruct_grid", "valu_fp64", occ_flop, ms["obstruct"],
-                          {"launches_per_step": launches["obstruct"], "segments_walked_per_step": segments_walked,
-                           "hbm_model": {"achieved_GBs": occ_bytes / (ms["obstruct"] * 1e-3) / 1e9 if ms["obstruct"] > 0 else 0.0,
-                                         "peak_GBs": HBM_PEAK_GBS, "algorithmic_bytes_per_step": occ_bytes},
-                           "note": "13 N flop per segment is the reference's segment-against-every-polygon test; the "
-                                   "grid walk looks at ~20 of the 7 615 polygons per segment, so this fraction is speed "
-                                   "against brute force (can exceed 1)"}),
-        "fields": entry("k_fields", "hbm", field_bytes, ms["fields"], {"paths_per_step": n_valid_paths}),
-    }
+
+def once_per_scene_rooflines(counters, vis_timing):
+    """The visibility kernels of the precompute: executed fp64 work of the committed counter passes (one precompute per
+    profiled run) over the device time measured live."""
+    out = {}
+    for name, kernels, key in (("vis_prepare", ("k_vis_prepare", "k_vis_prepare_mid", "k_vis_prepare_big"), "prepare"),
+                               ("vis_paint", ("k_vis_paint",), "paint")):
+        t_ms = vis_timing["rows"][key] + vis_timing["faces"][key]
+        flop = hbm = 0.0
+        seen = False
+        for k in kernels:
+            c = counters.get(k)
+            if c and "fp64_flop_per_launch" in c:
+                seen = True
+                n_launch = c["launches_per_step"] * c.get("steps_profiled", 1.0)
+                flop += c["fp64_flop_per_launch"] * n_launch
+                hbm += c.get("hbm_bytes_per_launch", 0.0) * n_launch
+        ach = flop / (t_ms * 1e-3) / 1e12 if (seen and t_ms > 0) else 0.0
+        out[name] = {"kernel": ", ".join(kernels), "bound": "valu_fp64", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "ms": t_ms, "rows_ms": vis_timing["rows"][key],
+                     "screens_ms": vis_timing["faces"][key], "work": flop,
+                     "work_kind": "fp64 operations executed by switched-on lanes (committed counter passes), whole precompute",
+                     "traffic": hbm if seen else None, "once_per_scene": True,
+                     "note": "rows and screens run side by side, so the two times overlap and the fraction is a lower bound"}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def config2_block(local_rank, dev, steps):
+def config2_block(local_rank, dev, steps, reference_mode):
     """Config 2 of BASELINE.json on one GPU (place_levant, 32 x 32 receivers, reflections to order 2): a step is the
     solve alone, 3.0 M path-solves in three dependent launches — the latency floor of the path."""
     import torch
@@ -193,6 +291,7 @@ def config2_block(local_rank, dev, steps):
     vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
     ev = np.logical_or.reduce(screens)
     cand = scene.enumerate(vis, ev, np.zeros((0, 2), np.int32), np.zeros((0, 2, 3)), 2, with_diffraction=False)
+    scene.set_reference_solver(reference_mode)
     n_rx = len(rx)
     d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
     cap = 256 * n_rx
@@ -216,22 +315,150 @@ def config2_block(local_rank, dev, steps):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     scene.set_timing(True)
-    fam = {"reflect": 0.0, "obstruct": 0.0, "finalize": 0.0}
+    fam = {"reflect": 0.0, "obstruct": 0.0, "finalize": 0.0, "rejudge": 0.0}
     for _ in range(steps):
         step()
         tm = scene.last_timing()
-        for k in fam:
+        for k in ("reflect", "obstruct", "finalize"):
             fam[k] += tm["ms"][k] / steps
+        fam["rejudge"] += scene.rejudge_timing()["ms"] / steps
     out = {"workload": f"place_levant.geojson ({len(polygons)} polygons), 1 TX, 32x32 RX, reflections up to order 2 "
                        "(config 2 of BASELINE.json); a step is the solve alone",
-           "steps": steps, "ms_per_step": 1e3 * dt, "path_solves_per_step": int(attempted),
+           "solver_mode": "reference" if reference_mode else "exact", "steps": steps, "ms_per_step": 1e3 * dt, "path_solves_per_step": int(attempted),
            "path_solves_per_s": attempted / dt, "valid_paths": int(found), "kernel_ms_per_step": fam}
     cand.close()
     scene.close()
     return out
 
 
+def config4_block(local_rank, dev, steps, reference_mode):
+    """Config 4 of BASELINE.json on one GPU: ny.geojson tiled 8 x 8 (5 825 polygons), 256 receivers, reflections up to
+    order 3 (1.4e8 chains of three, formed in the kernels from the level before instead of being stored).  A step is
+    the solve alone."""
+    import torch
+
+    from raytracing_amd import _lib, scenarios
+    from raytracing_amd import geometry as geom
+
+    place, tx, rx = scenarios.ny_tiled(8)
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons), device=local_rank)
+    cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+    t0 = time.perf_counter()
+    vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
+    vis_s = time.perf_counter() - t0
+    ev = np.logical_or.reduce(screens)
+    t0 = time.perf_counter()
+    cand = scene.enumerate(vis, ev, np.zeros((0, 2), np.int32), np.zeros((0, 2, 3)), 3, with_diffraction=False)
+    enum_s = time.perf_counter() - t0
+    scene.set_reference_solver(reference_mode)
+    n_rx = len(rx)
+    d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
+    cap = 64 * n_rx
+    o_rx = torch.empty(cap, dtype=torch.int32, device=dev)
+    o_group = torch.empty_like(o_rx)
+    o_cand = torch.empty_like(o_rx)
+    o_pts = torch.empty((cap, _lib.RT_MAX_ORDER, 3), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        return scene.solve_paths_device(cand, tx, d_rx.data_ptr(), n_rx, o_rx.data_ptr(), o_group.data_ptr(),
+                                        o_cand.data_ptr(), o_pts.data_ptr(), cap)
+
+    scene.set_timing(False)
+    for _ in range(2):
+        found, attempted = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        found, attempted = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    scene.set_timing(True)
+    step()
+    tm = scene.last_timing()["ms"]
+    tm = {k: float(v) for k, v in tm.items()}
+    tm["rejudge"] = scene.rejudge_timing()["ms"]
+    out = {"workload": f"ny.geojson tiled 8x8 ({len(polygons)} polygons), 1 TX, {n_rx} RX, reflections up to order 3 (config 4 "
+                       "of BASELINE.json); a step is the solve alone",
+           "solver_mode": "reference" if reference_mode else "exact", "steps": steps, "ms_per_step": 1e3 * dt,
+           "candidates_by_group": [int(c) for c in cand.counts], "path_solves_per_step": int(attempted),
+           "path_solves_per_s": attempted / dt, "valid_paths": int(found), "kernel_ms_per_step": tm,
+           "visibility_matrix_and_screens_s": round(vis_s, 4), "enumeration_s": round(enum_s, 4)}
+    cand.close()
+    scene.close()
+    return out
+
+
+def config5_block(local_rank, dev, steps, reference_mode, counters):
+    """Config 5 of BASELINE.json on one GPU: place_saint_jean, the five emitters of the reference's measurement campaign,
+    5 000 receivers, order 2 with diffraction, fields at seven frequencies from 3.5 to 60 GHz.  A step is, for every
+    emitter in turn, solve + path description + field step at all frequencies + per-receiver records."""
+    import torch
+
+    from raytracing_amd import _lib, scenarios
+    from raytracing_amd import device_pipeline as dp
+    from raytracing_amd import geometry as geom
+
+    place, emitters, rx, freqs = scenarios.saint_jean_sweep()
+    polygons = place.get_polygons_list()
+    scene = _lib.Scene(geom.scene_arrays_of(polygons), device=local_rank)
+    pairs, edges = scene.sharp_edges()
+    vis = scene.visibility_matrix(False)
+    scene.set_reference_solver(reference_mode)
+    d_rx = torch.tensor(rx, dtype=torch.float64, device=dev)
+    pipes = []
+    for tx in emitters:
+        cube = geom.Cube.by_point_and_side_length(tx, 0.2)
+        ev = np.logical_or.reduce(scene.faces_visibility([(s.points, s.get_parametric(), -1) for s in cube.polygons], False))
+        cand = scene.enumerate(vis, ev, pairs, edges, 2, with_diffraction=True)
+        pipes.append((cand, dp.DevicePipeline(scene, cand, tx, capacity=64 * len(rx))))
+
+    def step():
+        n_paths = attempted = 0
+        kernel_ms = call_ms = 0.0
+        for _, pipe in pipes:
+            block = pipe.run(d_rx, freqs, records=True)
+            n_paths += block.n_paths
+            attempted += block.n_attempted
+            kernel_ms += block.fields_timing["kernel"]
+            call_ms += block.fields_timing["call"]
+        return n_paths, attempted, kernel_ms, call_ms
+
+    scene.set_timing(False)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n_paths, attempted, _, _ = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    scene.set_timing(True)
+    n_paths, attempted, kernel_ms, call_ms = step()
+    pf = n_paths * len(freqs)
+    out = {"workload": f"place_saint_jean ({len(polygons)} polygons), {len(emitters)} TX x {len(rx)} RX x {len(freqs)} frequencies "
+                       "(3.5-60 GHz), order 2 with diffraction (config 5 of BASELINE.json); a step = for every emitter solve + "
+                       "description + fields at all frequencies + per-receiver records",
+           "solver_mode": "reference" if reference_mode else "exact", "steps": steps, "ms_per_step": 1e3 * dt,
+           "path_solves_per_step": int(attempted), "path_solves_per_s": attempted / dt, "valid_paths": int(n_paths),
+           "path_frequencies_per_step": int(pf), "field_kernels_ms_per_step": kernel_ms, "field_call_ms_per_step": call_ms,
+           "path_frequencies_per_s_field_kernels": pf / (kernel_ms * 1e-3) if kernel_ms > 0 else None,
+           "path_frequencies_per_s_whole_step": pf / dt}
+    c = counters.get("k_fields_sweep") or counters.get("k_fields")
+    if c and "fp64_flop_per_path_frequency" in c and kernel_ms > 0:
+        flop = c["fp64_flop_per_path_frequency"] * pf
+        out["field_kernels_fp64_executed_TFLOPs"] = flop / (kernel_ms * 1e-3) / 1e12
+        out["field_kernels_fp64_frac"] = out["field_kernels_fp64_executed_TFLOPs"] / FP64_VECTOR_PEAK_TFLOPS
+    for cand, _ in pipes:
+        cand.close()
+    scene.close()
+    return out
+
+
 def main():
+    global T_PROCESS
+    T_PROCESS = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -239,6 +466,7 @@ def main():
     ap.add_argument("--n-side", type=int, default=100, help="receivers per side of the lattice (100 = the 10k-RX map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary config-2 block")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the secondary config-4 and config-5 blocks")
     ap.add_argument("--solver-mode", choices=("reference", "exact"), default="reference",
                     help="reference: a found path is kept only when the reference's own solver call (SciPy hybr, restated "
                          "on the GPU) reports success and its points pass the reference's checks, i.e. the reference's path "
@@ -434,28 +662,19 @@ def main():
         # bytes the field kernel must move per path of k interactions: points, chain, edge, outputs (24 (k + 2) + 4 k + 160)
         k_inter = ((block.kind & 255) + (block.kind >> 8)).to(torch.float64)
         field_bytes = float((24.0 * (k_inter + 2) + 4.0 * k_inter + 160.0).sum().item())
+        counters = committed_counters()
         by_kernel = kernel_rooflines(end - begin, counts, cand.max_order, len(polygons), int(arrays.verts.shape[0]), fam,
-                                     launches, segments, field_bytes, committed_counters(), block.n_paths)
+                                     segments, field_bytes, counters, block.n_paths)
         # the visibility kernels of the precompute (this rank's share of the rows and screens)
-        n_poly, n_vert = len(polygons), int(arrays.verts.shape[0])
-        my_rows = len(range(rank, n_poly + len(screens), world))
-        vis_flop = (28.0 * n_vert + 20.0 * n_poly) * my_rows
-        for name, key in (("vis_prepare", "prepare"), ("vis_paint", "paint")):
-            t_ms = vis_timing["rows"][key] + vis_timing["faces"][key]
-            ach = vis_flop / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
-            by_kernel[name] = {"kernel": "k_" + name, "bound": "valu_fp64", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "ms": t_ms,
-                               "rows_ms": vis_timing["rows"][key], "screens_ms": vis_timing["faces"][key],
-                               "algorithmic_work": vis_flop, "once_per_scene": True,
-                               "note": "18 V_B + 10 V_A + 20 flop per ordered pair of the rows this rank paints "
-                                       "(mapping, filters; the coverage test is data-dependent and not counted); rows "
-                                       "and screens run side by side, so the two times overlap"}
-        step_kernels = ("reflect", "diffract", "obstruct", "fields")
+        by_kernel.update(once_per_scene_rooflines(counters, vis_timing))
+        step_kernels = ("reflect", "diffract", "obstruct", "rejudge", "fields")
         dominant = max(step_kernels, key=lambda k: by_kernel[k]["ms_per_step"])
         roof = dict(by_kernel[dominant])
+        roof.pop("counters_by_kernel", None)
         roof.setdefault("traffic", None)
-        roof["achieved_per_launch_basis"] = ("algorithmic flop (or bytes) of one step of one rank / mean device time of the "
-                                             "family's launches in a step (HIP events on the library's stream)")
+        roof["family"] = dominant
+        roof["achieved_basis"] = ("work of one step of one rank (see work_kind) / mean device time of the family's launches in a "
+                                  "step, measured in this run with HIP events on the library's stream")
         finite = np.isfinite(rec["power_db"][:, 0])
         flagged = int(rec["n_flagged"].sum())
         out = {
@@ -493,7 +712,14 @@ def main():
                              "worst_field_status": int(rec["worst_status"].max()) if len(rec["worst_status"]) else 0,
                              "note": "scene file -> per-receiver dB on every rank: scene load, device scene, sharp edges, "
                                      "visibility matrix and emitter screens (dealt to the ranks, all-gathered), "
-                                     "enumeration, then one step; max over ranks"},
+                                     "enumeration, then one step; max over ranks",
+                             "taken_before_the_clock": ["interpreter start and imports", "the HIP runtime's first allocation "
+                                                        "and launch", "the library's first use in the process (code object "
+                                                        "load, stream creation) on a scene of 31 polygons", "the process "
+                                                        "group's first all-gather and PyTorch's byte kernels (several ranks)"],
+                             "cold_process_wall_s": round(precompute_s + ms_step * 1e-3 + (t_wall - T_PROCESS), 4),
+                             "cold_process_note": "the same map with the clock started when this process entered main(): "
+                                                  "imports and first-use costs included"},
             "roofline": roof,
             "roofline_by_kernel": by_kernel,
             "kernel_ms_per_step": fam,
@@ -506,10 +732,13 @@ def main():
         if other_mode is not None:
             out["other_solver_mode"] = other_mode
         if world == 1 and not args.no_config2:
-            out["config2"] = config2_block(local_rank, dev, 200)
+            out["config2"] = config2_block(local_rank, dev, 200, args.solver_mode == "reference")
+            out["config2_other_solver_mode"] = config2_block(local_rank, dev, 200, args.solver_mode != "reference")
+        if world == 1 and not args.no_extra_configs:
+            out["config4"] = config4_block(local_rank, dev, 5, args.solver_mode == "reference")
+            out["config5"] = config5_block(local_rank, dev, 5, args.solver_mode == "reference", counters)
         if world == 1 and not args.no_cpu_baseline:
-            chains2, _ = cand.group(1)
-            out["cpu_baseline"] = cpu_baseline(place, tx, rx, chains2)
+            out["cpu_baseline"] = cpu_baseline(place, tx, rx, cand)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)  # (flushed: nothing after this line may cost the line)

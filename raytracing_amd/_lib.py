@@ -163,8 +163,10 @@ class Candidates:
         n = scene.n
         ev8 = np.ascontiguousarray(ev, dtype=np.uint8)
         if hasattr(vis, "data_ptr"):
-            # a matrix that was painted into device memory (Scene.visibility_with_faces(matrix_out=...)) is read there
+            # a matrix that was painted into device memory (Scene.visibility_with_faces(matrix_out=...)) is read there,
+            # on the library's own stream: after whatever the caller's stream still has queued for it
             vis_ptr, on_device = _device_matrix_ptr(vis, n, scene.device), 1
+            scene.wait_for_torch_stream()
         else:
             vis = np.asarray(vis)
             # (a bool matrix is passed as it is: of lln's 58 MB a copy takes longer than the enumeration)
@@ -330,6 +332,14 @@ class Scene:
         ``torch.cuda.current_stream().cuda_stream``; 0 = the null stream), on the device: the host does not wait."""
         _check(load().rt_scene_wait_for_stream(self.handle, c_void_p(int(stream_handle))), "rt_scene_wait_for_stream")
 
+    def wait_for_torch_stream(self):
+        """``wait_for_stream`` on PyTorch's current stream of this scene's GPU: what a caller has queued there for a
+        tensor it now hands to the library (which works on a stream of its own) is finished before the library reads or
+        writes the tensor."""
+        import torch
+
+        self.wait_for_stream(torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream)
+
     def set_deferred_sync(self, on):
         """While on, the device-pointer forms of the path description, the field step and the receiver records only
         queue their work on the scene's stream; ``synchronize`` waits for it."""
@@ -409,6 +419,8 @@ class Scene:
             else:
                 r_out = np.empty((len(rows), self.n), dtype=np.uint8)
                 out_ptr = _ptr(r_out)
+        if on_device:
+            self.wait_for_torch_stream()  # the caller's tensors: after what its stream still has queued for them
         _check(load().rt_visibility_with_faces(self.handle, n_rows, r_ptr, int(bool(strict)), out_ptr, len(faces),
                                                _ptr(off), _ptr(verts), _ptr(normals), _ptr(selfs), int(bool(faces_strict)),
                                                f_ptr, on_device), "rt_visibility_with_faces")

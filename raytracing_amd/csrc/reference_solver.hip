@@ -338,6 +338,7 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
                 case 3: REJ_LAUNCH(1, 1); break;
                 case 4: REJ_LAUNCH(2, 0); break;
                 case 5: REJ_LAUNCH(2, 1); break;
+                case 6: REJ_LAUNCH(3, 0); break;
                 default: REJ_LAUNCH(-1, -1); break;
             }
 #undef REJ_LAUNCH

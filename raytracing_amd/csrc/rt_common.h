@@ -115,7 +115,8 @@ struct rt_scene {
     hipStream_t side_stream = nullptr;  // created on first use: work that runs beside the main stream's (emitter screens,
                                         // the receiver-independent head of a large solve)
     hipEvent_t side_event = nullptr;    // end of the side stream's part of a solve, which the main stream waits for
-    hipEvent_t rejudge_event = nullptr; // what the side stream's part of the re-judging step waits for
+    hipEvent_t rejudge_event = nullptr; // a point of the main stream that the side stream's next piece of work waits for
+                                        // (the start of a solve; the start of the re-judging step)
     SceneView view{};
     std::vector<void *> allocations;
     // host copies used by host-side set-up code

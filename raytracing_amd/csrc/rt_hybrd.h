@@ -503,6 +503,41 @@ RT_HD inline void r1mpyq(int m_rt, int n_rt, double *a, int rs, int cs, const do
     }
 }
 
+// r1mpyq on the matrix q (n rows, column-major with leading dimension RT_LD) and on the row vector b, as the method
+// calls it twice in a row with the same stored rotations: each rotation is read back once and applied to both.
+template <int NC>
+RT_HD inline void r1mpyq_both(int n_rt, double *q, double *b, const double *v, const double *w) {
+    const int n = RT_N(NC, n_rt);
+    RT_UNROLL
+    for (int j = n - 2; j >= 0; --j) {
+        double cos_, sin_;
+        givens_stored(v[j], cos_, sin_);
+        RT_UNROLL
+        for (int i = 0; i < n; ++i) {
+            const double temp = cos_ * A_(q, i, j) - sin_ * A_(q, i, n - 1);
+            A_(q, i, n - 1) = sin_ * A_(q, i, j) + cos_ * A_(q, i, n - 1);
+            A_(q, i, j) = temp;
+        }
+        const double temp = cos_ * b[j] - sin_ * b[n - 1];
+        b[n - 1] = sin_ * b[j] + cos_ * b[n - 1];
+        b[j] = temp;
+    }
+    RT_UNROLL
+    for (int j = 0; j < n - 1; ++j) {
+        double cos_, sin_;
+        givens_stored(w[j], cos_, sin_);
+        RT_UNROLL
+        for (int i = 0; i < n; ++i) {
+            const double temp = cos_ * A_(q, i, j) + sin_ * A_(q, i, n - 1);
+            A_(q, i, n - 1) = -sin_ * A_(q, i, j) + cos_ * A_(q, i, n - 1);
+            A_(q, i, j) = temp;
+        }
+        const double temp = cos_ * b[j] + sin_ * b[n - 1];
+        b[n - 1] = -sin_ * b[j] + cos_ * b[n - 1];
+        b[j] = temp;
+    }
+}
+
 struct Result {
     int info;  // 1 = converged (what SciPy reports as success); -1 = stopped at the caller's evaluation limit, unfinished
     int nfev;
@@ -679,8 +714,7 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac, int nfev_limit =
                 if (ratio >= p0001) qtf[j] = sum;
             }
             r1updt<NC>(n, r, wa1, wa2, wa3, &sing);
-            r1mpyq<NC, NC>(n, n, fjac, 1, RT_LD, wa2, wa3);
-            r1mpyq<NC, 1>(1, n, qtf, 0, 1, wa2, wa3);
+            r1mpyq_both<NC>(n, fjac, qtf, wa2, wa3);
             jeval = false;
         }
     }
@@ -711,7 +745,8 @@ RT_HD inline bool solve_shape(const double *origin, const double *destination, c
     return res.info == 1;
 }
 
-// the same for any shape: the shapes up to two reflections take their unrolled forms, the rest the run-time form
+// the same for any shape: the shapes up to two reflections (and three without an edge) take their unrolled forms, the
+// rest the run-time form
 RT_HD inline bool solve_like_reference(const double *origin, const double *destination, const double *planes, int n_refl,
                                        const double *edge, double *out_points, int *nfev) {
     if (edge) {
@@ -721,6 +756,7 @@ RT_HD inline bool solve_like_reference(const double *origin, const double *desti
     } else {
         if (n_refl == 1) return solve_shape<1, 0>(origin, destination, planes, 1, edge, out_points, nfev);
         if (n_refl == 2) return solve_shape<2, 0>(origin, destination, planes, 2, edge, out_points, nfev);
+        if (n_refl == 3) return solve_shape<3, 0>(origin, destination, planes, 3, edge, out_points, nfev);
     }
     return solve_shape<-1, -1>(origin, destination, planes, n_refl, edge, out_points, nfev);
 }

@@ -1749,6 +1749,10 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     out.count = d_counters + 2;
 
     EventTimer timer(scene);
+    // where the main stream stood when this solve began (the side stream's part waits for it)
+    if (!scene->rejudge_event) SOLVE_HIP(hipEventCreateWithFlags(&scene->rejudge_event, hipEventDisableTiming));
+    hipEvent_t entry_event = scene->rejudge_event;
+    SOLVE_HIP(hipEventRecord(entry_event, st));
 
     const int mo = cand->max_order;
     std::vector<AliveRec *> alive(mo, nullptr);
@@ -1944,6 +1948,10 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
             // beside the reflection launch just queued: the head on the side stream, then the main stream waits for it
             if (!scene->side_stream) SOLVE_HIP(hipStreamCreateWithFlags(&scene->side_stream, hipStreamNonBlocking));
             if (!scene->side_event) SOLVE_HIP(hipEventCreateWithFlags(&scene->side_event, hipEventDisableTiming));
+            // (the head takes blocks of the scene's temporary memory that a call before this one may have handed back
+            // with its kernels still queued on the main stream — the deferred forms of the description and the field
+            // step return without waiting: the side stream starts after what the main stream held when this solve began)
+            SOLVE_HIP(hipStreamWaitEvent(scene->side_stream, entry_event, 0));
             if (counters_were_reset) {
                 // (the reset of all counters queued on the main stream at the start must not land on the head's two)
                 SOLVE_HIP(hipStreamSynchronize(st));

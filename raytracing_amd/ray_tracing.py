@@ -303,6 +303,13 @@ class RayTracingProblem:
             from_arrays = {}
             for name, container, is_diff in (("reflections", self._reflections, False), ("diffractions", self._diffractions, True)):
                 sel = np.flatnonzero(batch["has_edge"] == is_diff)
+                # the encoder takes the paths grouped by receiver in the order of the container's keys (ascending) and by
+                # order within a receiver: a solve of receivers listed out of order (solve(receivers_indexs=[2, 0])) or
+                # twice is not, and goes the dictionaries' way
+                key = batch["rx"][sel] * (2 * _lib.RT_MAX_ORDER + 2) + batch["order"][sel]
+                if len(key) > 1 and (np.diff(key) < 0).any():
+                    from_arrays = None
+                    break
                 lines, n_pts = self._lines_of(batch, sel)
                 from_arrays[name] = _lib.format_paths_json(
                     list(container.keys()), batch["rx"][sel], batch["order"][sel], n_pts + 2, lines, batch["n_refl"][sel],

@@ -1,4 +1,4 @@
-"""Per-kernel figures from the rocprofv3 --pmc passes of bench.py (scripts/profile_round2.sh), written as the JSON that
+"""Per-kernel figures from the rocprofv3 --pmc passes of bench.py (scripts/profile_round3.sh), written as the JSON that
 bench.py quotes in its roofline entries:
 
     python scripts/counters_json.py fetch.csv write.csv sq.csv [f64.csv] out.json
@@ -7,7 +7,13 @@ hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (both counters are in KiB; on
 read requests at 64 bytes, so it is doubled as the hardware guide prescribes; the doubling is calibrated for wide
 streaming reads and is an upper bound for narrower ones); the wave_cycles_* shares say where the cycles of the kernel's
 waves go (waiting for memory or a barrier, stalled at issue, issuing; SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY
-and SQ_ACTIVE_INST_VALU over SQ_WAVE_CYCLES, summed over the kernel's dispatches)."""
+and SQ_ACTIVE_INST_VALU over SQ_WAVE_CYCLES, summed over the kernel's dispatches).
+
+fp64_flop_per_launch = the double-precision operations the kernel's lanes actually executed: (SQ_INSTS_VALU_ADD_F64 +
+SQ_INSTS_VALU_MUL_F64 + SQ_INSTS_VALU_TRANS_F64 + 2 x SQ_INSTS_VALU_FMA_F64) wave instructions x 64 lanes x the share of
+lanes that were switched on while vector instructions ran (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)), per
+dispatch.  launches_per_step = dispatches of the kernel / steps in the profiled run (steps = dispatches of the final
+filter, one per step on this workload).  Kernels are keyed by name without template arguments."""
 import csv
 import json
 import sys
@@ -30,10 +36,12 @@ def main(argv):
     fetch, fcalls = per_kernel(argv[0])
     write, wcalls = per_kernel(argv[1])
     sq, scalls = per_kernel(argv[2])
-    f64 = per_kernel(argv[3])[0] if len(argv) > 4 else {}
+    f64, f64_calls = per_kernel(argv[3]) if len(argv) > 4 else ({}, {})
+    f64_steps = float(max(f64_calls.get("k_finalize", 1), 1))
     out = {}
     for name in sorted(set(fetch) | set(sq)):
-        e = {"source": "rocprofv3 --pmc passes over bench.py --no-cpu-baseline --no-config2 --steps 2 (one pass per counter group)"}
+        e = {"source": "rocprofv3 --pmc passes over bench.py --no-cpu-baseline --no-config2 --no-other-mode --no-extra-configs "
+                       "--steps 2 --warmup 1 (one pass per counter group; scripts/profile_round3.sh)"}
         if name in fetch and fcalls.get(name):
             rd = 1024.0 * fetch[name]["FETCH_SIZE"] / fcalls[name]
             wr = 1024.0 * write.get(name, {}).get("WRITE_SIZE", 0.0) / max(wcalls.get(name, 1), 1)
@@ -60,6 +68,16 @@ def main(argv):
                                                "SQ_INSTS_VALU_TRANS_F64"))
             if c.get("SQ_INSTS_VALU"):
                 e["fp64_share_of_valu_instructions"] = n64 / c["SQ_INSTS_VALU"]
+            ops = n64 + c.get("SQ_INSTS_VALU_FMA_F64", 0.0)  # a fused multiply-add is two operations
+            lanes = 1.0
+            if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
+                lanes = min(1.0, c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]))
+                e["lanes_on_share_of_valu_cycles"] = lanes
+            n_disp = max(f64_calls.get(name, 1), 1)
+            e["fp64_flop_per_launch_all_lanes"] = 64.0 * ops / n_disp
+            e["fp64_flop_per_launch"] = 64.0 * ops * lanes / n_disp
+            e["launches_per_step"] = n_disp / f64_steps
+            e["steps_profiled"] = f64_steps
             e["f64_counters"] = {k: v for k, v in sorted(c.items())}
         out[name] = e
     with open(out_json, "w") as f:

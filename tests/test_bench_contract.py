@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    with open(os.path.join(ROOT, "profiles", "r2_bench_line.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r3_bench_line.json")) as f:
         return json.load(f)
 
 
@@ -40,16 +40,20 @@ def test_value_and_roofline_follow_from_the_lines_own_inputs(line):
     assert line["value"] == pytest.approx(per_step / (line["ms_per_step"] * 1e-3), rel=1e-9)
     for name, r in [("headline", line["roofline"])] + list(line["roofline_by_kernel"].items()):
         assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9), name
+        assert 0.0 <= r["frac"] <= 1.0, name  # a fraction of a peak: executed work, not the brute-force count
         ms = r.get("ms_per_step", r.get("ms"))
-        work = r.get("algorithmic_work_per_step", r.get("algorithmic_work"))
+        work = r.get("work_per_step", r.get("work"))
         scale = 1e12 if r["unit"] == "TFLOP/s" else 1e9
         assert r["achieved"] == pytest.approx(work / (ms * 1e-3) / scale, rel=1e-6), name
     # the headline roofline is the kernel family with the most device time in a step
     fam = line["kernel_ms_per_step"]
-    busiest = max(("reflect", "diffract", "obstruct", "finalize", "fields"), key=lambda k: fam[k])
-    assert line["roofline"]["ms_per_step"] == pytest.approx(fam[busiest])
+    busiest = max(("reflect", "diffract", "obstruct", "rejudge", "fields"), key=lambda k: fam[k])
+    assert line["roofline"]["ms_per_step"] == pytest.approx(fam[busiest]) and line["roofline"]["family"] == busiest
     # kernels of a step (events around every launch) add up to the step within the host's share
-    assert sum(fam[k] for k in ("reflect", "diffract", "obstruct", "finalize", "fields_call")) < 1.1 * line["ms_per_step"]
+    assert sum(fam[k] for k in ("reflect", "diffract", "obstruct", "finalize", "rejudge", "fields_call")) < 1.1 * line["ms_per_step"]
+    # the headline is measured in the mode that gives the reference's path set, the other mode is beside it
+    assert line["config"]["solver_mode"] == "reference" and line["other_solver_mode"]["solver_mode"] == "exact"
+    assert line["config"]["paths_before_and_after_rejudge_rank0"] == [173760, 172630]
     assert line["coverage_map_wall_s"] > line["coverage_map"]["precompute_s"]
 
 

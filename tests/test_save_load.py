@@ -114,3 +114,38 @@ def test_json_written_from_the_arrays_is_the_json_of_the_dictionaries(tmp_path):
     assert open(tmp_path / "from_arrays.json").read() == open(tmp_path / "from_dictionaries.json").read()
     loaded = RayTracingProblem.from_json(str(tmp_path / "from_arrays.json"))
     assert loaded == problem and loaded.path_set() == problem.path_set()
+
+
+@pytest.mark.gpu
+def test_json_of_receivers_solved_out_of_order(tmp_path):
+    """solve(receivers_indexs=[2, 0]) hands the paths over receiver 2 first: the array route of to_json needs them by
+    ascending receiver, so the file then comes from the dictionaries, and says what a solve in order says."""
+    from raytracing_amd import geometry as geom
+    from raytracing_amd.ray_tracing import RayTracingProblem
+
+    def solved(indices):
+        place = geom.load_place("data/small.geojson")
+        tx, rx = small_tx_rx(4)
+        place.add_set_of_points(rx)
+        problem = RayTracingProblem(tx.reshape(1, 3), place)
+        problem.solve(max_order=2, receivers_indexs=indices)
+        return problem
+
+    backwards = solved([2, 0])
+    backwards.to_json(str(tmp_path / "backwards.json"))
+    loaded = RayTracingProblem.from_json(str(tmp_path / "backwards.json"))
+    assert loaded.path_set() == backwards.path_set()
+    forwards = solved([0, 2])
+    assert forwards.path_set() == backwards.path_set() and len(forwards.path_set()) > 10
+    for r in (0, 2):
+        for k in forwards.reflections[r]:
+            for (a, ca), (b, cb) in zip(forwards.reflections[r][k], loaded.reflections[r][k]):
+                np.testing.assert_array_equal(a, b)
+                assert list(ca) == list(cb)
+    twice = solved([1, 1])  # a receiver listed twice has its paths twice, as in the reference (results are appended)
+    twice.to_json(str(tmp_path / "twice.json"))
+    again = RayTracingProblem.from_json(str(tmp_path / "twice.json"))
+    once = solved([1])
+    n_once = sum(len(v) for by in once.reflections.values() for v in by.values())
+    n_twice = sum(len(v) for by in again.reflections.values() for v in by.values())
+    assert n_twice == 2 * n_once and n_once > 0

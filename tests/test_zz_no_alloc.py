@@ -49,3 +49,50 @@ def test_no_alloc_entry_point_gives_the_flags_of_the_allocating_one():
     with pytest.raises(_lib.RtError, match="at most"):
         scene.obstructed_noalloc(d_segs.data_ptr(), (1 << 22) + 1, None, got.data_ptr())
     scene.close()
+
+
+def test_no_alloc_entry_point_on_a_side_stream_and_replayed_from_a_graph():
+    """The two callers the entry point is for: a stream of the caller's own (no allocation during the call: PyTorch's
+    and the device's free memory stay where they were), and a captured HIP graph replayed several times with eager work
+    and synchronisations in between, every replay giving the eager flags."""
+    import torch
+
+    from raytracing_amd import _lib
+    from raytracing_amd import geometry as geom
+
+    place = geom.load_place("data/place_saint_jean/place_saint_jean.geojson")
+    scene = _lib.Scene(geom.scene_arrays_of(place.get_polygons_list()))
+    dev = torch.device("cuda", scene.device)
+    n = 50_000
+    segs = _segments(place, n, 11)
+    d_segs = torch.tensor(segs, dtype=torch.float64, device=dev)
+    want = torch.zeros(n, dtype=torch.uint8, device=dev)
+    got = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+    scene.obstructed_device(d_segs.data_ptr(), n, None, want.data_ptr())
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)  # default priority
+    with torch.cuda.stream(side):
+        got.fill_(9)  # (the runtime sets a stream's queue up at its first launch, 2 MiB: not the entry point's doing)
+    side.synchronize()
+    allocated, free = torch.cuda.memory_allocated(dev), torch.cuda.mem_get_info(dev)[0]
+    scene.obstructed_noalloc(d_segs.data_ptr(), n, None, got.data_ptr(), stream=side.cuda_stream)
+    side.synchronize()
+    assert torch.cuda.memory_allocated(dev) == allocated and torch.cuda.mem_get_info(dev)[0] == free
+    assert torch.equal(got, want) and 0 < int(want.sum()) < n
+
+    graph = torch.cuda.CUDAGraph()
+    got.fill_(9)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):  # (capture refuses any allocation made while it records)
+        scene.obstructed_noalloc(d_segs.data_ptr(), n, None, got.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+    for replay in range(3):
+        got.fill_(9)
+        # eager work of the program's own between the replays: the allocating entry point on other segments
+        other = torch.tensor(_segments(place, 3_000 + replay, 20 + replay), dtype=torch.float64, device=dev)
+        flags = torch.zeros(len(other), dtype=torch.uint8, device=dev)
+        scene.obstructed_device(other.data_ptr(), len(other), None, flags.data_ptr())
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"replay {replay}"
+    scene.close()
