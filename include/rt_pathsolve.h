@@ -162,6 +162,15 @@ int rt_solve_reflections(int device, const double *origin, const double *dests, 
 int rt_solve_reflections_diffraction(int device, const double *origin, const double *dests, int64_t n_dest,
                                      const double *planes, int32_t k, const double *edge, double *out_points,
                                      uint8_t *out_ok);
+/* The same three solver functions answered as the reference's own solver answers them: SciPy's root with its default
+ * method hybr (MINPACK hybrd; hybrj with the reference's hand-written derivative for the pure diffraction, geometry.py:
+ * 710-713, 744), from the reference's first guess (geometry.py:624-630, 742, 821-824), restated on the GPU operation
+ * for operation.  k planes (0 for a pure diffraction), edge NULL for pure reflections.  out_points as above: the
+ * solver's sol.x reshaped as the reference returns it (the diffraction point mapped back to the world);
+ * out_success[n_dest] = sol.success; out_nfev[n_dest] (may be NULL) = the evaluations the method itself made, which is
+ * SciPy's sol.nfev less the two calls its wrapper makes to check shapes.  Host pointers; runs on `device`. */
+int rt_solve_like_reference(int device, const double *origin, const double *dests, int64_t n_dest, const double *planes,
+                            int32_t k, const double *edge, double *out_points, uint8_t *out_success, int32_t *out_nfev);
 
 /* ---- candidate enumeration: the depth-first loops of RayTracingProblem.solve (ray_tracing.py:299-388) -------------
  * vis[N*N] (visibility matrix), ev[N] (emitter visibility), edge_pairs[n_edges*2] / edges[n_edges*6] (sharp edges in

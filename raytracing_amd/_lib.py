@@ -60,6 +60,8 @@ _SIGNATURES = {
     "rt_solve_reflections": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "rt_solve_reflections_diffraction": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
                                                  c_void_p, c_void_p]),
+    "rt_solve_like_reference": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "rt_enumerate": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_int]),
     "rt_candidates_destroy": (None, [c_void_p]),
     "rt_candidates_group_count": (c_int32, [c_void_p]),
@@ -624,6 +626,24 @@ def solve_reflections_and_diffraction(origin, destinations, planes, edge, device
                                                 _ptr(dests), len(dests), _ptr(planes) if k else None, k, _ptr(edge),
                                                 _ptr(out), _ptr(ok)), "rt_solve_reflections_diffraction")
     return out, ok.astype(bool)
+
+
+def solve_like_reference(origin, destinations, planes, edge=None, device=None):
+    """The reference's own solver call (SciPy hybr, restated on the GPU) on the system of ``planes`` (k, 4) and ``edge``
+    (2, 3) or None for every destination: returns (x [n, k (+1), 3], success bool [n], nfev int32 [n])."""
+    lib = require_gpu()
+    planes = _f64(planes).reshape(-1, 4)
+    dests = _f64(destinations).reshape(-1, 3)
+    origin = _f64(origin).reshape(3)
+    e = None if edge is None else _f64(edge).reshape(2, 3)
+    k = len(planes)
+    out = np.zeros((len(dests), k + (0 if e is None else 1), 3), dtype=np.float64)
+    ok = np.zeros(len(dests), dtype=np.uint8)
+    nfev = np.zeros(len(dests), dtype=np.int32)
+    _check(lib.rt_solve_like_reference(default_device() if device is None else device, _ptr(origin), _ptr(dests), len(dests),
+                                       _ptr(planes) if k else None, k, _ptr(e), _ptr(out), _ptr(ok), _ptr(nfev)),
+           "rt_solve_like_reference")
+    return out, ok.astype(bool), nfev
 
 
 def format_array_rows(values):

@@ -5,6 +5,7 @@
 // success, a root reached but reported as failure with the hand-written derivative of geometry.py:710-713); this mode
 // loses the same ones.  The paths are few (the survivors of the obstruction tests), so one thread per path is enough.
 #include <algorithm>
+#include <cstdlib>
 
 #include "rt_candidates.h"
 #include "rt_common.h"
@@ -305,6 +306,11 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
                        n, n_groups, lists, counts, recs, flags);
     const d3 TX = ld3(tx);
     int max_nseg = 0;
+    static const int first_pass_nfev = [] {
+        const char *e = getenv("RT_REJ_FIRST_PASS_NFEV");  // (for measurements of the hand-over point)
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : REJ_FIRST_PASS_NFEV;
+    }();
     // The groups that end with a diffraction on the scene's stream, the pure reflections beside them on its side stream
     // (same priority): a group's second pass lasts as long as its longest run and fills a fraction of the chip, and
     // the two kinds have about the same to do.  Each stream: first passes, then second passes.
@@ -326,7 +332,7 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
     if (pass == 0)                                                                                                               \
         hipLaunchKernelGGL((k_rejudge_solve<NR, HE>), grid1, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,       \
                            G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, lists + (size_t)g * np, counts + g, g,     \
-                           REJ_FIRST_PASS_NFEV, late + (size_t)g * np, late_counts + g, recs, flags);                            \
+                           first_pass_nfev, late + (size_t)g * np, late_counts + g, recs, flags);                            \
     else                                                                                                                         \
         hipLaunchKernelGGL((k_rejudge_solve_late<NR, HE>), grid2, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,  \
                            G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, late + (size_t)g * np, late_counts + g, g, \
@@ -374,6 +380,86 @@ extern "C" int rt_solve_last_rejudge(rt_scene *scene, double *ms, int64_t *n_in,
     if (ms) *ms = scene->last_rejudge_ms;
     if (n_in) *n_in = scene->last_rejudge_in;
     if (n_kept) *n_kept = scene->last_rejudge_kept;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the stand-alone solver entry points as the reference's own solver answers them (geometry.py:660-687, 718-748, 800-833)
+// ---------------------------------------------------------------------------------------------------------------
+template <int NR, int HE>
+__global__ __launch_bounds__(64) void k_solve_reference(const double *__restrict__ origin, const double *__restrict__ dests,
+                                                         int64_t n, const double *__restrict__ planes_in, int k,
+                                                         const double *__restrict__ edge_in, double *__restrict__ out,
+                                                         uint8_t *__restrict__ ok, int32_t *__restrict__ nfev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int n_refl = NR >= 0 ? NR : k;
+    double planes[4 * RT_MAX_ORDER], edge[6];
+#pragma unroll
+    for (int q = 0; q < 4 * RT_MAX_ORDER; ++q)
+        if (q < 4 * n_refl) planes[q] = planes_in[q];
+    if (edge_in)
+        for (int q = 0; q < 6; ++q) edge[q] = edge_in[q];
+    const double a[3] = {origin[0], origin[1], origin[2]};
+    const double b[3] = {dests[3 * i], dests[3 * i + 1], dests[3 * i + 2]};
+    double pts[3 * RT_MAX_ORDER];
+    int evals = 0;
+    const bool good = rt_hybr::solve_shape<NR, HE>(a, b, planes, n_refl, edge_in ? edge : nullptr, pts, &evals);
+    const int n_pts = n_refl + (edge_in ? 1 : 0);
+#pragma unroll
+    for (int q = 0; q < 3 * RT_MAX_ORDER; ++q)
+        if (q < 3 * n_pts) out[(size_t)i * 3 * n_pts + q] = pts[q];
+    ok[i] = good ? 1 : 0;
+    if (nfev) nfev[i] = evals;
+}
+
+extern "C" int rt_solve_like_reference(int device, const double *origin, const double *dests, int64_t n_dest,
+                                       const double *planes, int32_t k, const double *edge, double *out_points,
+                                       uint8_t *out_success, int32_t *out_nfev) {
+    if (!origin || (n_dest > 0 && (!dests || !out_points || !out_success))) RT_FAIL("rt_solve_like_reference: null argument");
+    if (k < 0 || k > RT_MAX_ORDER || (k > 0 && !planes)) RT_FAIL("rt_solve_like_reference: bad plane count");
+    const int n_pts = k + (edge ? 1 : 0);
+    if (n_pts == 0) RT_FAIL("rt_solve_like_reference: nothing to solve");
+    if (n_dest <= 0) return 0;
+    RT_HIP(rt_use_device(device));
+    double *d_in = nullptr, *d_out = nullptr;
+    uint8_t *d_ok = nullptr;
+    int32_t *d_nfev = nullptr;
+    const size_t n_in = 3 + 3 * (size_t)n_dest + 4 * RT_MAX_ORDER + 6;
+    hipError_t e = hipMalloc(&d_in, sizeof(double) * n_in);
+    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(double) * 3 * n_pts * n_dest);
+    if (e == hipSuccess) e = hipMalloc(&d_ok, n_dest);
+    if (e == hipSuccess) e = hipMalloc(&d_nfev, sizeof(int32_t) * n_dest);
+    double *d_origin = d_in, *d_dests = d_in + 3, *d_planes = d_dests + 3 * n_dest, *d_edge = d_planes + 4 * RT_MAX_ORDER;
+    if (e == hipSuccess) e = hipMemcpy(d_origin, origin, sizeof(double) * 3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_dests, dests, sizeof(double) * 3 * n_dest, hipMemcpyHostToDevice);
+    if (e == hipSuccess && k) e = hipMemcpy(d_planes, planes, sizeof(double) * 4 * k, hipMemcpyHostToDevice);
+    if (e == hipSuccess && edge) e = hipMemcpy(d_edge, edge, sizeof(double) * 6, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const dim3 grid((unsigned)((n_dest + 63) / 64)), block(64);
+#define SOLVE_LAUNCH(NR, HE)                                                                                                  \
+    hipLaunchKernelGGL((k_solve_reference<NR, HE>), grid, block, 0, 0, d_origin, d_dests, n_dest, d_planes, k,                \
+                       edge ? d_edge : (const double *)nullptr, d_out, d_ok, d_nfev)
+        switch (k * 2 + (edge ? 1 : 0)) {
+            case 1: SOLVE_LAUNCH(0, 1); break;
+            case 2: SOLVE_LAUNCH(1, 0); break;
+            case 3: SOLVE_LAUNCH(1, 1); break;
+            case 4: SOLVE_LAUNCH(2, 0); break;
+            case 5: SOLVE_LAUNCH(2, 1); break;
+            case 6: SOLVE_LAUNCH(3, 0); break;
+            default: SOLVE_LAUNCH(-1, -1); break;
+        }
+#undef SOLVE_LAUNCH
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_points, d_out, sizeof(double) * 3 * n_pts * n_dest, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_success, d_ok, n_dest, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_nfev) e = hipMemcpy(out_nfev, d_nfev, sizeof(int32_t) * n_dest, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    (void)hipFree(d_ok);
+    (void)hipFree(d_nfev);
+    if (e != hipSuccess) RT_FAIL(std::string("rt_solve_like_reference: ") + hipGetErrorString(e));
     return 0;
 }
 

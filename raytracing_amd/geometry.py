@@ -986,51 +986,71 @@ def sharp_edges_visibility_dict(sharp_edges):
 
 class SolveResult:
     """What the three solver entry points return beside the points: the fields of SciPy's result object that the
-    reference's callers read (``success``, ``x``)."""
+    reference's callers read (``success``, ``x``; ``nfev`` when the reference's own solver was asked for)."""
 
-    def __init__(self, x, success):
+    def __init__(self, x, success, nfev=None):
         self.x = x
         self.success = bool(success)
         self.status = 1 if success else 0
         self.message = "The solution converged." if success else "No specular solution exists."
+        if nfev is not None:
+            self.nfev = int(nfev) + 2  # SciPy's count: the method's evaluations and the two of its wrapper's shape check
+            self.message = "The solution converged." if success else "The solver did not report convergence."
+
+
+def _reference_solver_asked(kwargs):
+    """``reference_solver=True`` (or ``ray_tracing.REFERENCE_SOLVER``) makes the three solver functions answer as the
+    reference's own solver does — SciPy's hybr from the reference's first guess, with its misses — instead of with the
+    exact root."""
+    asked = kwargs.pop("reference_solver", None)
+    if asked is None:
+        from . import ray_tracing
+
+        asked = ray_tracing.REFERENCE_SOLVER
+    return bool(asked)
+
+
+def _solve(origin, destination, planes, edge, reference):
+    from . import _lib
+
+    origin = np.asarray(origin, dtype=float).reshape(3)
+    destination = np.asarray(destination, dtype=float).reshape(1, 3)
+    if reference:
+        x, ok, nfev = _lib.solve_like_reference(origin, destination, planes, edge)
+        # sol.x is the solver's vector of unknowns: the reflection points, then the diffraction unknown in the edge's
+        # frame; the points are what the reference's functions return beside it
+        return x[0], SolveResult(x[0].reshape(-1), ok[0], nfev[0])
+    if edge is None:
+        x, ok = _lib.solve_reflections(origin, destination, planes)
+    else:
+        x, ok = _lib.solve_reflections_and_diffraction(origin, destination, planes, edge)
+    return x[0], SolveResult(x[0].reshape(-1), ok[0])
 
 
 def reflexion_points_from_origin_destination_and_planes(origin, destination, planes_parametric, **kwargs):
     """Reflection point on each plane (reference geometry.py:660-687).  ``success`` is False when no specular path
-    exists over the infinite planes (an image segment misses its plane)."""
-    from . import _lib
-
+    exists over the infinite planes (an image segment misses its plane); with ``reference_solver=True`` it is what
+    SciPy's hybr reports from the reference's first guess, and the points are that solver's."""
     planes = np.asarray(planes_parametric, dtype=float).reshape(-1, 4)
-    x, ok = _lib.solve_reflections(np.asarray(origin, dtype=float).reshape(3),
-                                   np.asarray(destination, dtype=float).reshape(1, 3), planes)
-    return x[0], SolveResult(x[0].reshape(-1), ok[0])
+    return _solve(origin, destination, planes, None, _reference_solver_asked(kwargs))
 
 
 def diffraction_point_from_origin_destination_and_edge(origin, destination, edge, **kwargs):
     """Keller-cone point on the edge's line (reference geometry.py:718-748)."""
-    from . import _lib
-
-    x, ok = _lib.solve_reflections_and_diffraction(np.asarray(origin, dtype=float).reshape(3),
-                                                   np.asarray(destination, dtype=float).reshape(1, 3),
-                                                   np.empty((0, 4)), np.asarray(edge, dtype=float).reshape(2, 3))
-    return x[0], SolveResult(x[0].reshape(-1), ok[0])
+    return _solve(origin, destination, np.empty((0, 4)), np.asarray(edge, dtype=float).reshape(2, 3),
+                  _reference_solver_asked(kwargs))
 
 
 def reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge(origin, destination,
                                                                                    planes_parametric, edge, **kwargs):
     """Reflections then one diffraction (reference geometry.py:800-833), including its rule that the reflection
     points are aimed at the edge's first endpoint."""
-    from . import _lib
-
     if len(planes_parametric) == 0:
         return diffraction_point_from_origin_destination_and_edge(origin, destination, edge, **kwargs)
     if edge is None:
         return reflexion_points_from_origin_destination_and_planes(origin, destination, planes_parametric, **kwargs)
     planes = np.asarray(planes_parametric, dtype=float).reshape(-1, 4)
-    x, ok = _lib.solve_reflections_and_diffraction(np.asarray(origin, dtype=float).reshape(3),
-                                                   np.asarray(destination, dtype=float).reshape(1, 3),
-                                                   planes, np.asarray(edge, dtype=float).reshape(2, 3))
-    return x[0], SolveResult(x[0].reshape(-1), ok[0])
+    return _solve(origin, destination, planes, np.asarray(edge, dtype=float).reshape(2, 3), _reference_solver_asked(kwargs))
 
 
 def point_on_edge_(point, edge, tol=1e-8):

@@ -86,3 +86,38 @@ def test_reference_compatible_mode_keeps_hybrs_paths_and_power(name):
     assert got == hybr, f"only GPU: {sorted(got - hybr)[:5]}, only hybr: {sorted(hybr - got)[:5]}"
     if not fx["field_asserts_hybr"]:
         _compare_db(db, fx["db_hybr"], name + " against the oracle with SciPy hybr")
+
+
+def test_the_three_solver_functions_answer_as_the_references_solver_does():
+    """geometry.reflexion_points_from_origin_destination_and_planes & co. with reference_solver=True reproduce, on the
+    GPU and through the C ABI (rt_solve_like_reference), every vector recorded from the reference's own three solver
+    functions (tests/golden/solvers.json: sol.x, sol.success, sol.nfev) bit for bit."""
+    from raytracing_amd import geometry as geom
+
+    with open(os.path.join(GOLDEN, "solvers.json")) as f:
+        cases = json.load(f)
+    planes = np.load(os.path.join(GOLDEN, "helpers.npz"))["cube_planes"]
+    n = 0
+    for kind in ("reflection", "diffraction", "mixed"):
+        for case in cases[kind]:
+            pl = [planes[f] for f in case.get("faces", [])]
+            a, b = np.array(case["a"]), np.array(case["b"])
+            if kind == "reflection":
+                x, sol = geom.reflexion_points_from_origin_destination_and_planes(a, b, pl, reference_solver=True)
+            elif kind == "diffraction":
+                x, sol = geom.diffraction_point_from_origin_destination_and_edge(a, b, np.array(case["edge"]), reference_solver=True)
+            else:
+                x, sol = geom.reflexion_points_and_diffraction_point_from_origin_destination_planes_and_edge(
+                    a, b, pl, np.array(case["edge"]), reference_solver=True)
+            assert sol.success == case["success"]
+            np.testing.assert_array_equal(np.asarray(x).reshape(-1, 3), np.array(case["x"]).reshape(-1, 3))  # bit for bit
+            if "nfev" in case:
+                assert sol.nfev == case["nfev"]
+            n += 1
+    assert n == 154
+    # and without the flag the same functions give the exact root, which the solver's answer is close to when it succeeds
+    case = cases["reflection"][0]
+    pl = [planes[f] for f in case["faces"]]
+    x_exact, sol_exact = geom.reflexion_points_from_origin_destination_and_planes(np.array(case["a"]), np.array(case["b"]), pl)
+    if case["success"] and sol_exact.success:
+        assert np.abs(np.asarray(x_exact) - np.array(case["x"]).reshape(-1, 3)).max() < 1e-5
