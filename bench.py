@@ -559,9 +559,11 @@ def main():
         stamps[name] = round(time.perf_counter() - since, 4)
         return time.perf_counter()
 
-    place, tx = scenarios.lln_place()
-    polygons = place.get_polygons_list()
-    arrays = geom.scene_arrays_of(polygons)
+    # (the scene's arrays come from the scene cache when this file has been loaded before with this loader — build()
+    # loads every scene file once —, and through the place's objects otherwise: the same arrays bit for bit)
+    loaded, tx = scenarios.lln_scene()
+    arrays = loaded.arrays
+    n_polygons = arrays.n
     t = stamp("scene_file_s", t_wall)
     # the receivers of the map are placed (host work: a lattice minus the buildings' footprints) on a second thread while
     # the scene goes to the GPU and the GPU paints: the library calls release the interpreter lock.  The thread makes no
@@ -569,7 +571,7 @@ def main():
     import threading
 
     made = {}
-    worker = threading.Thread(target=lambda: made.update(rx=scenarios.lattice_receivers(place, args.n_side, 1.5)))
+    worker = threading.Thread(target=lambda: made.update(rx=scenarios.lattice_receivers(loaded, args.n_side, 1.5)))
     worker.start()
     scene = _lib.Scene(arrays, device=local_rank)
     pairs, edges = scene.sharp_edges()
@@ -663,7 +665,7 @@ def main():
         k_inter = ((block.kind & 255) + (block.kind >> 8)).to(torch.float64)
         field_bytes = float((24.0 * (k_inter + 2) + 4.0 * k_inter + 160.0).sum().item())
         counters = committed_counters()
-        by_kernel = kernel_rooflines(end - begin, counts, cand.max_order, len(polygons), int(arrays.verts.shape[0]), fam,
+        by_kernel = kernel_rooflines(end - begin, counts, cand.max_order, n_polygons, int(arrays.verts.shape[0]), fam,
                                      segments, field_bytes, counters, block.n_paths)
         # the visibility kernels of the precompute (this rank's share of the rows and screens)
         by_kernel.update(once_per_scene_rooflines(counters, vis_timing))
@@ -690,7 +692,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"lln.geojson ({len(polygons)} polygons), 1 TX, {args.n_side}x{args.n_side} RX coverage "
+            "config": {"workload": f"lln.geojson ({n_polygons} polygons), 1 TX, {args.n_side}x{args.n_side} RX coverage "
                                    "map, reflections + diffractions up to order 2 (config 3 of BASELINE.json); a step = "
                                    "solve + path description + field step + all-gather of one record per receiver",
                        "receivers": n_total, "receivers_per_gpu": end - begin,
@@ -738,7 +740,7 @@ def main():
             out["config4"] = config4_block(local_rank, dev, 5, args.solver_mode == "reference")
             out["config5"] = config5_block(local_rank, dev, 5, args.solver_mode == "reference", counters)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(place, tx, rx, cand)
+            out["cpu_baseline"] = cpu_baseline(loaded.place, tx, rx, cand)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)  # (flushed: nothing after this line may cost the line)

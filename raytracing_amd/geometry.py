@@ -904,6 +904,107 @@ class SceneArrays:
         return self._device_scene
 
 
+class LoadedScene:
+    """A rooftop file as the kernels need it — ``arrays`` (SceneArrays), the buildings' ``footprints`` (list of (n, 2)
+    rings) and the scene's box — without the thousands of Python objects of a place.  ``place`` builds those when asked
+    for (``load_place``).  Stands in for a place where only footprints and the box are read (``get_domain``)."""
+
+    def __init__(self, filename, seed, arrays, footprints, domain):
+        self.filename, self.seed = filename, seed
+        self.arrays, self.footprints, self.domain = arrays, footprints, domain
+        self._place = None
+
+    def get_domain(self):
+        return self.domain[0].copy(), self.domain[1].copy()
+
+    @property
+    def place(self):
+        if self._place is None:
+            self._place = load_place(self.filename, seed=self.seed)
+        return self._place
+
+
+def _scene_cache_dir():
+    """Where loaded scenes are kept: ``data/.scene_cache`` beside the package when it can be written (the files then
+    travel with the tree, like built libraries), else the user's cache directory."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for d in (os.path.join(root, "data", ".scene_cache"), os.path.join(os.path.expanduser("~"), ".cache", "raytracing_amd")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            if os.access(d, os.W_OK):
+                return d
+        except OSError:
+            pass
+    return None
+
+
+def _loader_fingerprint():
+    """Changes whenever the code that turns a file into arrays does (this module and the material table)."""
+    global _LOADER_FINGERPRINT
+    if _LOADER_FINGERPRINT is None:
+        import hashlib
+
+        h = hashlib.sha1()
+        here = os.path.dirname(os.path.abspath(__file__))
+        for name in ("geometry.py", "materials_properties.py", "array_utils.py"):
+            with open(os.path.join(here, name), "rb") as f:
+                h.update(f.read())
+        h.update(np.__version__.encode())
+        _LOADER_FINGERPRINT = h.hexdigest()
+    return _LOADER_FINGERPRINT
+
+
+_LOADER_FINGERPRINT = None
+
+
+def load_scene(filename, seed=0, use_cache=True):
+    """``load_place`` for callers that need the arrays, not the objects: the SceneArrays of the file's polygon list, the
+    footprints and the box, read from a cache file when this very file (by content), seed and loader code have been
+    loaded before, and made through ``load_place`` (and cached) otherwise.  The cached arrays are the arrays
+    ``SceneArrays(load_place(filename, seed).get_polygons_list())`` gives, bit for bit: they are those arrays, stored."""
+    import hashlib
+
+    path = None
+    if use_cache:
+        cache_dir = _scene_cache_dir()
+        if cache_dir is not None:
+            with open(filename, "rb") as f:
+                digest = hashlib.sha1(f.read() + f"|{seed}|{_loader_fingerprint()}".encode()).hexdigest()
+            path = os.path.join(cache_dir, f"{os.path.basename(filename)}-{digest[:20]}.npz")
+            if os.path.exists(path):
+                try:
+                    with np.load(path) as z:
+                        arrays = SceneArrays.__new__(SceneArrays)
+                        arrays.vert_off, arrays.verts, arrays.planes = z["vert_off"], z["verts"], z["planes"]
+                        arrays.material, arrays.building = z["material"], z["building"]
+                        arrays.n = len(arrays.material)
+                        arrays._device_scene = None
+                        off, xy, domain = z["footprint_off"], z["footprint_xy"], z["domain"]
+                    footprints = [xy[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+                    return LoadedScene(filename, seed, arrays, footprints, (domain[0], domain[1]))
+                except (OSError, ValueError, KeyError):
+                    pass  # an unreadable cache file is made again
+    place = load_place(filename, seed=seed)
+    arrays = scene_arrays_of(place.get_polygons_list())
+    footprints = [p.get_top_face().points[:, :2].copy() for p in place.polyhedra]
+    lo, hi = place.get_domain()
+    scene = LoadedScene(filename, seed, arrays, footprints, (np.asarray(lo, float), np.asarray(hi, float)))
+    scene._place = place
+    if path is not None:
+        off = np.zeros(len(footprints) + 1, dtype=np.int64)
+        np.cumsum([len(f) for f in footprints], out=off[1:])
+        tmp = f"{path}.{os.getpid()}.tmp.npz"
+        try:
+            np.savez(tmp, vert_off=arrays.vert_off, verts=arrays.verts, planes=arrays.planes, material=arrays.material,
+                     building=arrays.building, footprint_off=off,
+                     footprint_xy=np.concatenate(footprints) if footprints else np.zeros((0, 2)),
+                     domain=np.stack([scene.domain[0], scene.domain[1]]))
+            os.replace(tmp, path)  # (several ranks may load the same scene at once: each writes its own file, then renames)
+        except OSError:
+            pass
+    return scene
+
+
 def scene_arrays_of(polygons):
     """SceneArrays for a polygon list, cached on the list's first polygon so repeated calls reuse the upload."""
     polygons = list(polygons)

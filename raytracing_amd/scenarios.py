@@ -14,6 +14,9 @@ DATA_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 
 
 def _footprints(place):
+    """Rings of the buildings' footprints, of a place or of a ``geometry.LoadedScene`` (which holds them ready)."""
+    if hasattr(place, "footprints"):
+        return place.footprints
     return [p.get_top_face().points[:, :2] for p in place.polyhedra]
 
 
@@ -141,6 +144,14 @@ def lln_place():
     place = geom.load_place(os.path.join(DATA_DIR, "lln.geojson"))
     lo, hi = place.get_domain()
     return place, emitter_outside(place, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
+
+
+def lln_scene():
+    """Config 3 for callers that need arrays only: (geometry.LoadedScene of data/lln.geojson, emitter), the same scene
+    and emitter as ``lln_place`` without the place's objects (they are made if ``.place`` is asked for)."""
+    scene = geom.load_scene(os.path.join(DATA_DIR, "lln.geojson"))
+    lo, hi = scene.get_domain()
+    return scene, emitter_outside(scene, (lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 30.0)
 
 
 def lln_grid(n_side=100):
