@@ -37,6 +37,15 @@
 // shown visible, edge_has_witness calls from canvas edges, cut gathers), summed over a launch; read by the profiling scripts.
 __device__ unsigned long long g_vis_stats[8];
 __device__ unsigned long long g_vis_phase[16];
+#ifdef RT_VIS_STAMPS
+// (profiling builds) start, duration (10 ns ticks), candidates and visible polygons of every work item of the last launch
+#define VIS_FACE_LOG 16384
+__device__ unsigned long long g_vis_face_log[4 * VIS_FACE_LOG];
+extern "C" int rt_debug_visibility_face_log(unsigned long long *out, int n) {
+    if (n > VIS_FACE_LOG) n = VIS_FACE_LOG;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vis_face_log), sizeof(unsigned long long) * 4 * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int rt_debug_visibility_phases(unsigned long long *out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_vis_phase), sizeof(g_vis_phase)) != hipSuccess) return -1;
     unsigned long long z[16] = {0};
@@ -44,7 +53,8 @@ extern "C" int rt_debug_visibility_phases(unsigned long long *out16) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_vis_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 // Compiled in only for profiling builds (-DRT_VIS_STATS, ~170 M updates on a 7 615-polygon scene); otherwise
-// rt_debug_visibility_stats reads zeros.
+// rt_debug_visibility_stats reads zeros, except [6] candidates held against the covered-cell bitmap and [7] those it
+// settled, which every build counts (two updates per 256 candidates).
 #ifdef RT_VIS_STATS
 #define VIS_STAT(i, v) atomicAdd(&g_vis_stats[i], (unsigned long long)(v))
 #else
@@ -463,6 +473,8 @@ struct PaintScratch {
     int64_t split_cap;
     int32_t *work;    // per wave [2 * vtot]: (entry, vertex) of canvas edges that enter the current polygon
     int32_t *tlist;   // per workgroup [n]: candidates of the tile being painted
+    uint32_t *grid;   // per workgroup [VIS_GRID_WORDS]: the covered-cell bitmap of the face being painted
+    int32_t *chunk;   // per workgroup [1024]: the candidates of the current stretch that are left to paint
 };
 
 // The polygons one coverage decision works on: entry 0 = the polygon B being decided, entries 1..count-1 = the canvas
@@ -1557,6 +1569,80 @@ __device__ __forceinline__ int shortcuts_alone(const Store *cs, const uint16_t *
     return VIS_UNSETTLED;
 }
 
+// ---- The covered-cell bitmap.  Nine candidates in ten are hidden behind ONE nearer polygon, and finding that out took
+// most of the painter's time although the answer is usually obvious: the candidate is a far wall a few cells of view
+// wide, the nearer polygon a wall that fills a tenth of the view.  So the (azimuth, polar) box of a face's candidates is
+// cut into VIS_GRID x VIS_GRID cells with one bit each: set when the cell lies wholly inside some CONVEX polygon of the
+// canvas, shrunk by VIS_GRID_MARGIN.  A candidate whose box (widened by VIS_GRID_EPS) lies in set cells lies inside the
+// union of canvas polygons with a margin four hundred times the witness offset: every witness the full decision could
+// place is covered, so "hidden" is the answer the full decision gives.  A bit that is not set proves nothing and the
+// candidate goes the usual way.  Bits are only ever added while a face is painted (the canvas only grows), so a test
+// against an older state of the bitmap errs on the side of the usual way.  The bitmap lives in global memory (LDS is
+// taken by the canvas), written with atomics and read past the first-level cache.
+#define VIS_GRID 256
+#define VIS_GRID_WORDS (VIS_GRID * VIS_GRID / 32)
+#define VIS_GRID_MARGIN 1e-7
+#define VIS_GRID_EPS 1e-9
+#define VIS_GRID_MIN_CANDIDATES 256 /* faces with fewer candidates are painted without the bitmap */
+#define VIS_GRID_MAX_CELLS 64       /* a candidate over more cells goes the usual way */
+#define VIS_GRID_MAX_NV 8           /* canvas polygons with more vertices set no bits */
+struct GridDomain {
+    double x0, y0, cw, ch, inv_cw, inv_ch;
+};
+
+__device__ inline bool grid_hides(const uint32_t *grid, const GridDomain &g, double xmin, double xmax, double ymin, double ymax) {
+    int ix0 = (int)floor((xmin - VIS_GRID_EPS - g.x0) * g.inv_cw), ix1 = (int)floor((xmax + VIS_GRID_EPS - g.x0) * g.inv_cw);
+    int iy0 = (int)floor((ymin - VIS_GRID_EPS - g.y0) * g.inv_ch), iy1 = (int)floor((ymax + VIS_GRID_EPS - g.y0) * g.inv_ch);
+    // (the domain is the box of all candidates: what sticks out of it is the widening alone)
+    ix0 = ix0 < 0 ? 0 : ix0;
+    iy0 = iy0 < 0 ? 0 : iy0;
+    ix1 = ix1 >= VIS_GRID ? VIS_GRID - 1 : ix1;
+    iy1 = iy1 >= VIS_GRID ? VIS_GRID - 1 : iy1;
+    if (ix1 < ix0 || iy1 < iy0 || (ix1 - ix0 + 1) * (iy1 - iy0 + 1) > VIS_GRID_MAX_CELLS) return false;
+    for (int iy = iy0; iy <= iy1; ++iy)
+        for (int w = ix0 >> 5; w <= (ix1 >> 5); ++w) {
+            const int lo = w == (ix0 >> 5) ? (ix0 & 31) : 0, hi = w == (ix1 >> 5) ? (ix1 & 31) : 31;
+            const uint32_t need = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            const uint32_t have = __hip_atomic_load(grid + iy * (VIS_GRID / 32) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((have & need) != need) return false;
+        }
+    return true;
+}
+
+// the canvas polygon in `slot` has just been found visible: the cells wholly inside it get their bit (all threads)
+template <typename Store>
+__device__ inline void grid_mark(const Store *cs, int slot, uint32_t *grid, const GridDomain &g) {
+    const int nv = cs->nvs[slot];
+    if (nv > VIS_GRID_MAX_NV) return;
+    const double *x = cs->xy + cs->offs[slot], *y = x + nv;
+    const double sgn = (double)cs->sgns[slot];
+    if (!ring_turns_one_way(x, y, nv, sgn)) return;
+    const double *bb = cs->boxes + 4 * slot;
+    int ix0 = (int)ceil((bb[0] - g.x0) * g.inv_cw), ix1 = (int)floor((bb[1] - g.x0) * g.inv_cw);  // cells [ix0, ix1) lie in the box
+    int iy0 = (int)ceil((bb[2] - g.y0) * g.inv_ch), iy1 = (int)floor((bb[3] - g.y0) * g.inv_ch);
+    ix0 = ix0 < 0 ? 0 : ix0;
+    iy0 = iy0 < 0 ? 0 : iy0;
+    ix1 = ix1 > VIS_GRID ? VIS_GRID : ix1;
+    iy1 = iy1 > VIS_GRID ? VIS_GRID : iy1;
+    const int ncx = ix1 - ix0, ncy = iy1 - iy0;
+    if (ncx <= 0 || ncy <= 0) return;
+    for (int c = threadIdx.x; c < ncx * ncy; c += blockDim.x) {
+        const int ix = ix0 + c % ncx, iy = iy0 + c / ncx;
+        const double xs[2] = {g.x0 + ix * g.cw, g.x0 + (ix + 1) * g.cw}, ys[2] = {g.y0 + iy * g.ch, g.y0 + (iy + 1) * g.ch};
+        bool inside = true;
+        for (int k = 0; k < nv && inside; ++k) {
+            const int u = k == 0 ? nv - 1 : k - 1;
+            const double ex = x[k] - x[u], ey = y[k] - y[u];
+            const double far2 = VIS_GRID_MARGIN * VIS_GRID_MARGIN * (ex * ex + ey * ey);
+            for (int q = 0; q < 4; ++q) {
+                const double cr = sgn * (ex * (ys[q >> 1] - y[u]) - ey * (xs[q & 1] - x[u]));
+                if (!(cr > 0.0 && cr * cr >= far2)) inside = false;
+            }
+        }
+        if (inside) atomicOr(grid + iy * (VIS_GRID / 32) + (ix >> 5), 1u << (ix & 31));
+    }
+}
+
 // One workgroup (NW waves: four when many faces are painted at once, sixteen for a handful) paints one face at a time.  Per candidate polygon, in painter's order: wave 0 lists the canvas
 // polygons whose box meets it and stages them in LDS; all waves then decide coverage together.
 template <typename Store, int NW>
@@ -1581,7 +1667,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
     __shared__ double lds_px[NW][PIECE_LDS], lds_py[NW][PIECE_LDS];
     __shared__ int lds_pstate[NW][PIECE_LDS];
     __shared__ int s_face, s_nlist, s_fits, s_flag;
+    // (every byte of LDS counts here: three workgroups share a compute unit, and 1.2 KB more per workgroup made it two)
+    __shared__ int s_mc, s_grid_on;
+    __shared__ GridDomain s_gdom;
+    double (*s_red)[PIECE_LDS] = lds_px;  // free between two decisions: scratch of the reduction over the candidates' boxes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *grid = ps.grid + (int64_t)blockIdx.x * VIS_GRID_WORDS;
+    // the candidates of the stretch being painted that the bitmap did not settle (global memory: read ahead like the order)
+    int32_t *s_chunk = ps.chunk + (int64_t)blockIdx.x * (64 * NW);
     LocalStore *store = &stores.staged;
     Store *cs = &stores.canvas;
     int32_t *list = ps.list + (int64_t)blockIdx.x * sc.n;
@@ -1671,6 +1764,48 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
         m = __builtin_amdgcn_readfirstlane(m);
         int n_canvas = 0;
         int n_cs = 0, used = 0;
+        // ---- the covered-cell bitmap of this face (whole faces with enough candidates to pay for it): its domain is
+        // the box of the candidates' boxes
+        const bool want_grid = !span.bounded() && m >= VIS_GRID_MIN_CANDIDATES;
+        if (want_grid) {
+            double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+            for (int q = threadIdx.x; q < m; q += blockDim.x) {
+                const PolyMeta &mq = meta_f[ord[q]];
+                bx0 = fmin(bx0, mq.xmin);
+                bx1 = fmax(bx1, mq.xmax);
+                by0 = fmin(by0, mq.ymin);
+                by1 = fmax(by1, mq.ymax);
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                bx0 = fmin(bx0, __shfl_xor(bx0, off));
+                bx1 = fmax(bx1, __shfl_xor(bx1, off));
+                by0 = fmin(by0, __shfl_xor(by0, off));
+                by1 = fmax(by1, __shfl_xor(by1, off));
+            }
+            if (lane == 0) {
+                s_red[wave][0] = bx0;
+                s_red[wave][1] = bx1;
+                s_red[wave][2] = by0;
+                s_red[wave][3] = by1;
+            }
+            for (int q = threadIdx.x; q < VIS_GRID_WORDS; q += blockDim.x) grid[q] = 0u;
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < NW; ++w) {
+                    s_red[0][0] = fmin(s_red[0][0], s_red[w][0]);
+                    s_red[0][1] = fmax(s_red[0][1], s_red[w][1]);
+                    s_red[0][2] = fmin(s_red[0][2], s_red[w][2]);
+                    s_red[0][3] = fmax(s_red[0][3], s_red[w][3]);
+                }
+                const double wx = s_red[0][1] - s_red[0][0], wy = s_red[0][3] - s_red[0][2];
+                const bool ok = wx > 1e-6 && wy > 1e-6 && wx < 1e3 && wy < 1e3;
+                s_grid_on = ok ? 1 : 0;
+                if (ok) s_gdom = GridDomain{s_red[0][0], s_red[0][2], wx / VIS_GRID, wy / VIS_GRID, VIS_GRID / wx, VIS_GRID / wy};
+            }
+            __syncthreads();
+        }
+        const bool grid_on = want_grid && __builtin_amdgcn_readfirstlane(s_grid_on) != 0;
 #ifdef RT_VIS_STAMPS
         const unsigned long long t_item = wall_clock64();
 #endif
@@ -1689,188 +1824,241 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
         // of the wave's candidate two groups on (lanes 0-13 its words, lanes 14/15 its vertex range) and the vertices
         // of its candidate of the next group (lane = coordinate; longer rings are read when they are staged).
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        int k = 0;
-        {
-            int ord_cur = lane < m ? ord[lane] : 0, ord_next = 64 + lane < m ? ord[64 + lane] : 0;
-            auto place = [&](int idx, int from) -> int {  // candidate at place idx (uniform), seen from group `from`
-                return (idx >> 6) == (from >> 6) ? __builtin_amdgcn_readlane(ord_cur, idx & 63)
-                                                 : __builtin_amdgcn_readlane(ord_next, idx & 63);
-            };
-            auto record = [&](int Bx) -> int {
-                return lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
-            };
-            int rec0 = 0, rec1 = 0;
-            double xy0 = 0.0;
-            if (wave_u < m) {
-                rec0 = record(place(wave_u, 0));
-                const int v0x = __builtin_amdgcn_readlane(rec0, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec0, 15) - v0x);
-                if (lane < n2) xy0 = sph_f[(size_t)v0x * 2 + lane];
-            }
-            if (NW + wave_u < m) rec1 = record(place(NW + wave_u, 0));
-            uint16_t *my_list = s_wlist[wave_u], *my_lpre = s_wlpre[wave_u];
-            while (k < m) {
-                if (k != 0 && (k & 63) == 0) {
-                    ord_cur = ord_next;
-                    ord_next = k + 64 + lane < m ? ord[k + 64 + lane] : 0;
-                }
-                const int mine = k + wave_u;
-                const bool have = mine < m;
-                const int B = have ? place(mine, k) : 0;
-                PolyMeta mb;
-                {
-                    auto word = [&](int i) { return (unsigned long long)(unsigned)__builtin_amdgcn_readlane(rec0, i); };
-                    mb.xmin = __longlong_as_double((long long)(word(4) | (word(5) << 32)));
-                    mb.xmax = __longlong_as_double((long long)(word(6) | (word(7) << 32)));
-                    mb.ymin = __longlong_as_double((long long)(word(8) | (word(9) << 32)));
-                    mb.ymax = __longlong_as_double((long long)(word(10) | (word(11) << 32)));
-                    mb.sgn = __builtin_amdgcn_readlane(rec0, 13);
-                }
-                const int b_v0 = __builtin_amdgcn_readlane(rec0, 14);
-                const int nv2 = have ? 2 * (__builtin_amdgcn_readlane(rec0, 15) - b_v0) : 0;
-                const double b_xy = xy0;
-                // the reads that run ahead
-                int rec2 = 0;
-                if (mine + 2 * NW < m) rec2 = record(place(mine + 2 * NW, k));
-                double xy1 = 0.0;
-                if (mine + NW < m) {
-                    const int v0x = __builtin_amdgcn_readlane(rec1, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec1, 15) - v0x);
-                    if (lane < n2) xy1 = sph_f[(size_t)v0x * 2 + lane];
-                }
-                if (lane == 0) {
-                    s_gnv[wave_u] = nv2;
-                    s_gB[wave_u] = B;
-                }
-                __syncthreads();
-                int before = 0, total = 0;  // coordinates the group's earlier members / all its members stage
-                for (int w = 0; w < NW; ++w) {
-                    const int c = s_gnv[w];
-                    if (w < wave_u) before += c;
-                    total += c;
-                }
-                if (n_cs + NW > Store::max_poly || used + total > Store::max_coord) {
-                    break;  // the same in every wave: the rest of the face goes the slow way
-                }
-                const int slot_b = n_cs + wave_u, at_b = used + before;
-                int verdict = 0;  // 0 hidden, 1 shows, or unsettled
-                if (have) {
-                    // what of B can show in this tile lies in B's box cut to the sector: only canvas polygons reaching
-                    // there matter
-                    const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
-                    int n_list = 0;
-                    for (int base = 0; base < n_cs; base += 64) {
-                        const int ci = base + lane;
-                        bool take = false;
-                        if (ci < n_cs) {
-                            const double *cb = cs->boxes + 4 * ci;
-                            take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
-                        }
-                        const unsigned long long mk = __ballot(take);
-                        const int at = n_list + __popcll(mk & ((1ull << lane) - 1));
-                        if (take && at < VIS_WAVE_LIST) my_list[at] = (uint16_t)ci;
-                        n_list += __popcll(mk);
+        // The candidates are taken in stretches of one per thread.  Each thread first holds its candidate's box against
+        // the bitmap (as it stands: a test against an older canvas can only send a candidate the usual way); the
+        // candidates that are left are put together, in order, and painted in groups as described below.
+        int k = 0;                    // place in the face's order where the candidates not yet looked at begin
+        int left_k = 0, left_m = 0;   // candidates of the last stretch the resident path did not get to: s_chunk[left_k, left_m)
+        bool resident = true;
+        while (k < m && resident) {
+            const int chunk_n = m - k < 64 * NW ? m - k : 64 * NW;
+            {
+                int B = -1;
+                bool keep = false;
+                if ((int)threadIdx.x < chunk_n) {
+                    B = ord[k + threadIdx.x];
+                    keep = true;
+                    if (grid_on) {
+                        const PolyMeta &mq = meta_f[B];
+                        keep = !grid_hides(grid, s_gdom, mq.xmin, mq.xmax, mq.ymin, mq.ymax);
                     }
-                    const double *src = sph_f + (size_t)b_v0 * 2;
-                    if (lane < nv2) cs->xy[at_b + lane] = b_xy;
-                    for (int q = 64 + lane; q < nv2; q += 64) cs->xy[at_b + q] = src[q];
+                }
+                const unsigned long long mk = __ballot(keep);
+                if (lane == 0) s_wcnt[wave] = __popcll(mk);
+                __syncthreads();
+                int at = __popcll(mk & ((1ull << lane) - 1));
+                for (int w = 0; w < wave; ++w) at += s_wcnt[w];
+                if (keep) s_chunk[at] = B;
+                if (threadIdx.x == 0) {
+                    int tot = 0;
+                    for (int w = 0; w < NW; ++w) tot += s_wcnt[w];
+                    s_mc = tot;
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            const int m_c = __builtin_amdgcn_readfirstlane(s_mc);
+            if (threadIdx.x == 0 && grid_on) {  // (two updates per stretch of 256 candidates: kept in every build)
+                atomicAdd(&g_vis_stats[6], (unsigned long long)chunk_n);
+                atomicAdd(&g_vis_stats[7], (unsigned long long)(chunk_n - m_c));
+            }
+            const int32_t *ord_c = s_chunk;
+            int kc = 0;
+            {
+                int ord_cur = lane < m_c ? ord_c[lane] : 0, ord_next = 64 + lane < m_c ? ord_c[64 + lane] : 0;
+                auto place = [&](int idx, int from) -> int {  // candidate at place idx (uniform), seen from group `from`
+                    return (idx >> 6) == (from >> 6) ? __builtin_amdgcn_readlane(ord_cur, idx & 63)
+                                                     : __builtin_amdgcn_readlane(ord_next, idx & 63);
+                };
+                auto record = [&](int Bx) -> int {
+                    return lane < 14 ? ((const int32_t *)(meta_f + Bx))[lane] : (lane < 16 ? sc.vert_off[Bx + lane - 14] : 0);
+                };
+                int rec0 = 0, rec1 = 0;
+                double xy0 = 0.0;
+                if (wave_u < m_c) {
+                    rec0 = record(place(wave_u, 0));
+                    const int v0x = __builtin_amdgcn_readlane(rec0, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec0, 15) - v0x);
+                    if (lane < n2) xy0 = sph_f[(size_t)v0x * 2 + lane];
+                }
+                if (NW + wave_u < m_c) rec1 = record(place(NW + wave_u, 0));
+                uint16_t *my_list = s_wlist[wave_u], *my_lpre = s_wlpre[wave_u];
+                while (kc < m_c) {
+                    if (kc != 0 && (kc & 63) == 0) {
+                        ord_cur = ord_next;
+                        ord_next = kc + 64 + lane < m_c ? ord_c[kc + 64 + lane] : 0;
+                    }
+                    const int mine = kc + wave_u;
+                    const bool have = mine < m_c;
+                    const int B = have ? place(mine, kc) : 0;
+                    PolyMeta mb;
+                    {
+                        auto word = [&](int i) { return (unsigned long long)(unsigned)__builtin_amdgcn_readlane(rec0, i); };
+                        mb.xmin = __longlong_as_double((long long)(word(4) | (word(5) << 32)));
+                        mb.xmax = __longlong_as_double((long long)(word(6) | (word(7) << 32)));
+                        mb.ymin = __longlong_as_double((long long)(word(8) | (word(9) << 32)));
+                        mb.ymax = __longlong_as_double((long long)(word(10) | (word(11) << 32)));
+                        mb.sgn = __builtin_amdgcn_readlane(rec0, 13);
+                    }
+                    const int b_v0 = __builtin_amdgcn_readlane(rec0, 14);
+                    const int nv2 = have ? 2 * (__builtin_amdgcn_readlane(rec0, 15) - b_v0) : 0;
+                    const double b_xy = xy0;
+                    // the reads that run ahead
+                    int rec2 = 0;
+                    if (mine + 2 * NW < m_c) rec2 = record(place(mine + 2 * NW, kc));
+                    double xy1 = 0.0;
+                    if (mine + NW < m_c) {
+                        const int v0x = __builtin_amdgcn_readlane(rec1, 14), n2 = 2 * (__builtin_amdgcn_readlane(rec1, 15) - v0x);
+                        if (lane < n2) xy1 = sph_f[(size_t)v0x * 2 + lane];
+                    }
                     if (lane == 0) {
-                        cs->nvs[slot_b] = nv2 / 2;
-                        cs->offs[slot_b] = at_b;
-                        cs->sgns[slot_b] = mb.sgn;
-                        cs->boxes[4 * slot_b] = mb.xmin;
-                        cs->boxes[4 * slot_b + 1] = mb.xmax;
-                        cs->boxes[4 * slot_b + 2] = mb.ymin;
-                        cs->boxes[4 * slot_b + 3] = mb.ymax;
-                        VIS_STAT(0, 1);
-                        VIS_STAT(1, n_list);
+                        s_gnv[wave_u] = nv2;
+                        s_gB[wave_u] = B;
                     }
-                    if (n_list > VIS_WAVE_LIST) {
-                        verdict = VIS_UNSETTLED;
-                    } else {
-                        canvas_prefix(cs, my_list, n_list, nv2 / 2, my_lpre);
-                        __builtin_amdgcn_wave_barrier();
-                        verdict = shortcuts_alone(cs, my_list, my_lpre, slot_b, n_list, span);
+                    __syncthreads();
+                    int before = 0, total = 0;  // coordinates the group's earlier members / all its members stage
+                    for (int w = 0; w < NW; ++w) {
+                        const int c = s_gnv[w];
+                        if (w < wave_u) before += c;
+                        total += c;
                     }
-                }
-                if (lane == 0) s_verdict[wave_u] = verdict;
-                __syncthreads();
-                // ---- the group's verdicts in order
-                int shown = 0;
-                for (int j = 0; j < NW && k + j < m; ++j) {
-                    int v = s_verdict[j];
-                    const int nv2_j = s_gnv[j];
-                    bool in_place = false;
-                    if (v == VIS_UNSETTLED || (v == 1 && shown > 0)) {
-                        // the full decision, by all waves together, against the canvas as it is now: its wave moves it
-                        // to the canvas's next slot and lists again (any length; the shortcuts again only if the
-                        // canvas has grown since they were tried)
-                        if (wave_u == j) {
-                            move_staged(cs, slot_b, n_cs, used);
-                            int n_list = 0;
-                            const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
-                            for (int base = 0; base < n_cs; base += 64) {
-                                const int ci = base + lane;
-                                bool take = false;
-                                if (ci < n_cs) {
-                                    const double *cb = cs->boxes + 4 * ci;
-                                    take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
-                                }
-                                const unsigned long long mk = __ballot(take);
-                                if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = (uint16_t)ci;
-                                n_list += __popcll(mk);
+                    if (n_cs + NW > Store::max_poly || used + total > Store::max_coord) {
+                        resident = false;
+                        break;  // the same in every wave: the rest of the face goes the slow way
+                    }
+                    const int slot_b = n_cs + wave_u, at_b = used + before;
+                    int verdict = 0;  // 0 hidden, 1 shows, or unsettled
+                    if (have) {
+                        // what of B can show in this tile lies in B's box cut to the sector: only canvas polygons reaching
+                        // there matter
+                        const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+                        int n_list = 0;
+                        for (int base = 0; base < n_cs; base += 64) {
+                            const int ci = base + lane;
+                            bool take = false;
+                            if (ci < n_cs) {
+                                const double *cb = cs->boxes + 4 * ci;
+                                take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
                             }
-                            canvas_prefix(cs, cs->list, n_list, nv2 / 2, cs->lpre);
+                            const unsigned long long mk = __ballot(take);
+                            const int at = n_list + __popcll(mk & ((1ull << lane) - 1));
+                            if (take && at < VIS_WAVE_LIST) my_list[at] = (uint16_t)ci;
+                            n_list += __popcll(mk);
+                        }
+                        const double *src = sph_f + (size_t)b_v0 * 2;
+                        if (lane < nv2) cs->xy[at_b + lane] = b_xy;
+                        for (int q = 64 + lane; q < nv2; q += 64) cs->xy[at_b + q] = src[q];
+                        if (lane == 0) {
+                            cs->nvs[slot_b] = nv2 / 2;
+                            cs->offs[slot_b] = at_b;
+                            cs->sgns[slot_b] = mb.sgn;
+                            cs->boxes[4 * slot_b] = mb.xmin;
+                            cs->boxes[4 * slot_b + 1] = mb.xmax;
+                            cs->boxes[4 * slot_b + 2] = mb.ymin;
+                            cs->boxes[4 * slot_b + 3] = mb.ymax;
+                            VIS_STAT(0, 1);
+                            VIS_STAT(1, n_list);
+                        }
+                        if (n_list > VIS_WAVE_LIST) {
+                            verdict = VIS_UNSETTLED;
+                        } else {
+                            canvas_prefix(cs, my_list, n_list, nv2 / 2, my_lpre);
                             __builtin_amdgcn_wave_barrier();
-                            int again = VIS_UNSETTLED;
-                            if (shown > 0 || v != VIS_UNSETTLED || n_list > VIS_WAVE_LIST)
-                                again = shortcuts_alone(cs, cs->list, cs->lpre, n_cs, n_list, span);
-                            if (lane == 0) {
-                                // (slots of their own: a wave that is late may still be reading the first verdict,
-                                // and every wave has to take the same way through the barriers)
-                                s_again[j] = again;
-                                s_nlist = n_list;
-                                s_flag = 0;
+                            verdict = shortcuts_alone(cs, my_list, my_lpre, slot_b, n_list, span);
+                        }
+                    }
+                    if (lane == 0) s_verdict[wave_u] = verdict;
+                    __syncthreads();
+                    // ---- the group's verdicts in order
+                    int shown = 0;
+                    for (int j = 0; j < NW && kc + j < m_c; ++j) {
+                        int v = s_verdict[j];
+                        const int nv2_j = s_gnv[j];
+                        bool in_place = false;
+                        if (v == VIS_UNSETTLED || (v == 1 && shown > 0)) {
+                            // the full decision, by all waves together, against the canvas as it is now: its wave moves it
+                            // to the canvas's next slot and lists again (any length; the shortcuts again only if the
+                            // canvas has grown since they were tried)
+                            if (wave_u == j) {
+                                move_staged(cs, slot_b, n_cs, used);
+                                int n_list = 0;
+                                const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+                                for (int base = 0; base < n_cs; base += 64) {
+                                    const int ci = base + lane;
+                                    bool take = false;
+                                    if (ci < n_cs) {
+                                        const double *cb = cs->boxes + 4 * ci;
+                                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                                    }
+                                    const unsigned long long mk = __ballot(take);
+                                    if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = (uint16_t)ci;
+                                    n_list += __popcll(mk);
+                                }
+                                canvas_prefix(cs, cs->list, n_list, nv2 / 2, cs->lpre);
+                                __builtin_amdgcn_wave_barrier();
+                                int again = VIS_UNSETTLED;
+                                if (shown > 0 || v != VIS_UNSETTLED || n_list > VIS_WAVE_LIST)
+                                    again = shortcuts_alone(cs, cs->list, cs->lpre, n_cs, n_list, span);
+                                if (lane == 0) {
+                                    // (slots of their own: a wave that is late may still be reading the first verdict,
+                                    // and every wave has to take the same way through the barriers)
+                                    s_again[j] = again;
+                                    s_nlist = n_list;
+                                    s_flag = 0;
+                                }
+                            }
+                            __syncthreads();
+                            v = s_again[j];
+                            if (v == VIS_UNSETTLED) {
+                                const CanvasSet<Store> cv{cs, cs->list, cs->lpre, n_cs, s_nlist + 1};
+                                v = polygon_uncovered(cv, splits, lds_count, work, &s_flag, span, true) ? 1 : 0;
+                                __syncthreads();  // the flag and the list are the next unsettled candidate's after this
+                            }
+                            in_place = true;
+                        }
+                        if (v == 1) {
+                            if (wave_u == j && !in_place) move_staged(cs, slot_b, n_cs, used);
+                            __syncthreads();  // the moved ring is part of the canvas for what comes after
+                            if (threadIdx.x == 0) {
+                                const int Bj = s_gB[j];
+                                VIS_STAT(5, 1);
+                                canvas[n_canvas] = Bj;  // (kept in global memory too, for a face that outgrows the store)
+                                double *cb = cbox + 4 * (size_t)n_canvas;
+                                const double *bb = cs->boxes + 4 * n_cs;
+                                cb[0] = bb[0]; cb[1] = bb[1]; cb[2] = bb[2]; cb[3] = bb[3];
+                                if (faces_viewer(sc, fb, f, Bj)) out_f[Bj] = 1;
+                                __threadfence_block();
+                            }
+                            ++n_cs;
+                            used += nv2_j;
+                            ++n_canvas;
+                            ++shown;
+                            if (grid_on) {
+                                grid_mark(cs, n_cs - 1, grid, s_gdom);
+                                __threadfence();  // (the next stretch's test comes after a barrier)
                             }
                         }
-                        __syncthreads();
-                        v = s_again[j];
-                        if (v == VIS_UNSETTLED) {
-                            const CanvasSet<Store> cv{cs, cs->list, cs->lpre, n_cs, s_nlist + 1};
-                            v = polygon_uncovered(cv, splits, lds_count, work, &s_flag, span, true) ? 1 : 0;
-                            __syncthreads();  // the flag and the list are the next unsettled candidate's after this
-                        }
-                        in_place = true;
                     }
-                    if (v == 1) {
-                        if (wave_u == j && !in_place) move_staged(cs, slot_b, n_cs, used);
-                        __syncthreads();  // the moved ring is part of the canvas for what comes after
-                        if (threadIdx.x == 0) {
-                            const int Bj = s_gB[j];
-                            VIS_STAT(5, 1);
-                            canvas[n_canvas] = Bj;  // (kept in global memory too, for a face that outgrows the store)
-                            double *cb = cbox + 4 * (size_t)n_canvas;
-                            const double *bb = cs->boxes + 4 * n_cs;
-                            cb[0] = bb[0]; cb[1] = bb[1]; cb[2] = bb[2]; cb[3] = bb[3];
-                            if (faces_viewer(sc, fb, f, Bj)) out_f[Bj] = 1;
-                            __threadfence_block();
-                        }
-                        ++n_cs;
-                        used += nv2_j;
-                        ++n_canvas;
-                        ++shown;
-                    }
+                    rec0 = rec1;
+                    rec1 = rec2;
+                    xy0 = xy1;
+                    kc += NW;
+                    __syncthreads();  // the staging slots and the verdicts are rewritten by the next group
                 }
-                rec0 = rec1;
-                rec1 = rec2;
-                xy0 = xy1;
-                k += NW;
-                __syncthreads();  // the staging slots and the verdicts are rewritten by the next group
             }
+            k += chunk_n;
+            if (kc < m_c) {
+                left_k = kc;
+                left_m = m_c;
+            }
+            __syncthreads();  // the list of the stretch is rewritten by the next one
         }
         __threadfence_block();
         // ---- what is left once the canvas has outgrown the resident store: one candidate at a time, all waves
         // together, the canvas read from global memory (staged in LDS per candidate when it fits)
-        for (; k < m; ++k) {
-            const int B = ord[k];  // uniform over the workgroup
+        const int n_left = left_m - left_k;
+        for (int q_rest = 0; q_rest < n_left + (m - k); ++q_rest) {
+            // first what the resident path left of its last stretch, then the rest of the face's order
+            const int B = q_rest < n_left ? s_chunk[left_k + q_rest] : ord[k + q_rest - n_left];  // uniform over the workgroup
             const PolyMeta mb = meta_f[B];
             const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
             if (wave == 0) {
@@ -1981,6 +2169,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
             atomicMin(&g_vis_phase[15], t_item);
             atomicAdd(&g_vis_stats[3], (unsigned long long)m);
             atomicAdd(&g_vis_stats[4], (unsigned long long)n_canvas);
+            if (f < VIS_FACE_LOG) {
+                g_vis_face_log[4 * f] = t_item;
+                g_vis_face_log[4 * f + 1] = t_end - t_item;
+                g_vis_face_log[4 * f + 2] = (unsigned long long)m;
+                g_vis_face_log[4 * f + 3] = (unsigned long long)n_canvas;
+            }
         }
 #endif
     }
@@ -2007,7 +2201,7 @@ struct DevBuf {
 // Device buffers of one batch of faces: they live until the batch's kernels have run.
 struct RowsJob {
     DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work,
-        b_queue, b_tlist, b_bounds, b_ntiles, b_itemoff, b_big;
+        b_queue, b_tlist, b_bounds, b_ntiles, b_itemoff, b_big, b_grid, b_chunk;
     std::vector<int32_t> h_big;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, mapped, sorted, painted
     ~RowsJob() {
@@ -2068,6 +2262,8 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         b_counter.alloc(sizeof(unsigned long long)) || b_order.alloc(sizeof(int32_t) * (size_t)m_stride * n_faces) ||
         b_counts.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_queue.alloc(sizeof(int32_t) * (size_t)n_faces) ||
         b_work.alloc(sizeof(int32_t) * 2 * (size_t)sc.vtot * n_waves) || job.b_tlist.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) ||
+        job.b_grid.alloc(sizeof(uint32_t) * VIS_GRID_WORDS * (size_t)n_blocks) ||
+        job.b_chunk.alloc(sizeof(int32_t) * 1024 * (size_t)n_blocks) ||
         job.b_bounds.alloc(sizeof(double) * (VIS_MAX_TILES + 1) * (size_t)n_faces) ||
         job.b_ntiles.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_itemoff.alloc(sizeof(int32_t) * ((size_t)n_faces + 1)))
         RT_FAIL("visibility: out of device memory");
@@ -2169,7 +2365,8 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     }
     if (job.ev[2]) RT_HIP(hipEventRecord(job.ev[2], st));
     PaintScratch ps{(int32_t *)b_list.p, (int32_t *)b_canvas.p, (double *)b_cbox.p, (double *)b_splits.p, split_cap,
-                    (int32_t *)b_work.p, (int32_t *)job.b_tlist.p};
+                    (int32_t *)b_work.p, (int32_t *)job.b_tlist.p, (uint32_t *)job.b_grid.p,
+                    (int32_t *)job.b_chunk.p};
     // at most one face per CU: the large canvas store (one workgroup per CU) costs no parallelism
     if (n_faces <= 256)
         hipLaunchKernelGGL((k_vis_paint<LargeCanvasStore, 16>), dim3(n_blocks), dim3(1024), 0, st, sc, fb,

@@ -1,0 +1,51 @@
+"""How many candidates the painter's covered-cell bitmap settles (not a test): python scripts/grid_probe.py lln"""
+import ctypes
+import sys
+import time
+
+sys.path.insert(0, ".")
+from raytracing_amd import _lib, geometry as geom  # noqa: E402
+
+name = sys.argv[1]
+loaded = geom.load_scene(f"data/{name}.geojson")
+scene = _lib.Scene(loaded.arrays)
+st = (ctypes.c_ulonglong * 8)()
+_lib.load().rt_debug_visibility_stats(st)
+for rep in range(2):
+    t = time.perf_counter()
+    vis = scene.visibility_matrix(False)
+    dt = time.perf_counter() - t
+    _lib.load().rt_debug_visibility_stats(st)
+    print(f"matrix {1e3 * dt:.1f} ms, kernels {scene.visibility_timing()['rows']}, visible pairs {int(vis.sum())}; "
+          f"bitmap: {st[6]} candidates tested, {st[7]} settled ({100.0 * st[7] / max(1, st[6]):.1f} %)", flush=True)
+if hasattr(_lib.load(), "rt_debug_visibility_phases"):
+    # (a build with -DRT_VIS_STAMPS: where the faces' time goes, in 10 ns ticks of the wall clock, summed over faces)
+    ph = (ctypes.c_ulonglong * 16)()
+    _lib.load().rt_debug_visibility_phases(ph)
+    vis = scene.visibility_matrix(False)
+    _lib.load().rt_debug_visibility_phases(ph)
+    names = ["samples", "inside-one", "own edges", "collect", "canvas edges"]
+    full = sum(ph[2 * i] for i in range(5))
+    print("full decisions: " + ", ".join(f"{nm} {ph[2 * i] / 1e5:.1f} ms x{ph[2 * i + 1]}" for i, nm in enumerate(names)), flush=True)
+    print(f"faces: {ph[12] / 1e5:.1f} ms summed over the workgroups (longest {ph[13] / 1e5:.2f} ms), of which full decisions "
+          f"{full / 1e5:.1f} ms; span of the launch {(ph[14] - ph[15]) / 1e5:.1f} ms", flush=True)
+if hasattr(_lib.load(), "rt_debug_visibility_face_log"):
+    import numpy as np
+
+    n = scene.n
+    log = np.zeros((n, 4), dtype=np.uint64)
+    _lib.load().rt_debug_visibility_face_log(ctypes.c_void_p(log.ctypes.data), n)
+    start = (log[:, 0] - log[:, 0].min()).astype(float) / 1e5
+    dur = log[:, 1].astype(float) / 1e5
+    cand, shown = log[:, 2].astype(int), log[:, 3].astype(int)
+    end = start + dur
+    print(f"faces: span {end.max():.1f} ms; durations: mean {dur.mean():.2f}, p50 {np.median(dur):.2f}, p99 {np.percentile(dur, 99):.1f}, max {dur.max():.1f} ms")
+    for f in np.argsort(-dur)[:12]:
+        print(f"  longest: face {f}: start {start[f]:.1f} ms, lasts {dur[f]:.1f} ms, candidates {cand[f]}, visible {shown[f]}")
+    late = np.argsort(-end)[:6]
+    for f in late:
+        print(f"  face {f}: start {start[f]:.1f} ms, lasts {dur[f]:.1f} ms, candidates {cand[f]}, visible {shown[f]}")
+    for t in (50, 100, 125, 150, 175):
+        print(f"  at {t} ms: {(int(((start <= t) & (end > t)).sum()))} faces in flight, {int((start > t).sum())} not started")
+    c = np.corrcoef(cand, dur)[0, 1]
+    print(f"  correlation of a face's time with its candidates {c:.2f}, with candidates x visible {np.corrcoef(cand * shown, dur)[0, 1]:.2f}, with visible {np.corrcoef(shown, dur)[0, 1]:.2f}")
