@@ -1579,12 +1579,16 @@ __device__ __forceinline__ int shortcuts_alone(const Store *cs, const uint16_t *
 // candidate goes the usual way.  Bits are only ever added while a face is painted (the canvas only grows), so a test
 // against an older state of the bitmap errs on the side of the usual way.  The bitmap lives in global memory (LDS is
 // taken by the canvas), written with atomics and read past the first-level cache.
-#define VIS_GRID 256
+#ifndef VIS_GRID
+#define VIS_GRID 128 /* lln's matrix: 64 cells a side paint in 132 ms, 128 in 117, 256 in 130, 512 in 188 (setting the bits costs) */
+#endif
 #define VIS_GRID_WORDS (VIS_GRID * VIS_GRID / 32)
 #define VIS_GRID_MARGIN 1e-7
 #define VIS_GRID_EPS 1e-9
 #define VIS_GRID_MIN_CANDIDATES 256 /* faces with fewer candidates are painted without the bitmap */
+#ifndef VIS_GRID_MAX_CELLS
 #define VIS_GRID_MAX_CELLS 64       /* a candidate over more cells goes the usual way */
+#endif
 #define VIS_GRID_MAX_NV 8           /* canvas polygons with more vertices set no bits */
 struct GridDomain {
     double x0, y0, cw, ch, inv_cw, inv_ch;
@@ -1610,8 +1614,11 @@ __device__ inline bool grid_hides(const uint32_t *grid, const GridDomain &g, dou
 }
 
 // the canvas polygon in `slot` has just been found visible: the cells wholly inside it get their bit (all threads)
+// (also called for a candidate that the usual way has just found HIDDEN: all of it lies behind the canvas, so the cells
+// inside it do too, although no single canvas polygon holds them — the seam between two walls, for one)
+// Threads first, first + stride, ... of the caller share the cells: a whole workgroup (0, blockDim.x) or one wave (lane, 64).
 template <typename Store>
-__device__ inline void grid_mark(const Store *cs, int slot, uint32_t *grid, const GridDomain &g) {
+__device__ inline void grid_mark(const Store *cs, int slot, uint32_t *grid, const GridDomain &g, int first, int stride) {
     const int nv = cs->nvs[slot];
     if (nv > VIS_GRID_MAX_NV) return;
     const double *x = cs->xy + cs->offs[slot], *y = x + nv;
@@ -1626,7 +1633,7 @@ __device__ inline void grid_mark(const Store *cs, int slot, uint32_t *grid, cons
     iy1 = iy1 > VIS_GRID ? VIS_GRID : iy1;
     const int ncx = ix1 - ix0, ncy = iy1 - iy0;
     if (ncx <= 0 || ncy <= 0) return;
-    for (int c = threadIdx.x; c < ncx * ncy; c += blockDim.x) {
+    for (int c = first; c < ncx * ncy; c += stride) {
         const int ix = ix0 + c % ncx, iy = iy0 + c / ncx;
         const double xs[2] = {g.x0 + ix * g.cw, g.x0 + (ix + 1) * g.cw}, ys[2] = {g.y0 + iy * g.ch, g.y0 + (iy + 1) * g.ch};
         bool inside = true;
@@ -1964,6 +1971,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             canvas_prefix(cs, my_list, n_list, nv2 / 2, my_lpre);
                             __builtin_amdgcn_wave_barrier();
                             verdict = shortcuts_alone(cs, my_list, my_lpre, slot_b, n_list, span);
+                            // hidden behind the canvas as it stood, and the bitmap had not said so: the cells inside it
+                            // are covered too (by this wave, now: once the verdicts are gone through, a member that
+                            // shows is moved over the staged rings of the members before it)
+                            if (verdict == 0 && grid_on) grid_mark(cs, slot_b, grid, s_gdom, lane, 64);
                         }
                     }
                     if (lane == 0) s_verdict[wave_u] = verdict;
@@ -2033,9 +2044,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             ++n_canvas;
                             ++shown;
                             if (grid_on) {
-                                grid_mark(cs, n_cs - 1, grid, s_gdom);
-                                __threadfence();  // (the next stretch's test comes after a barrier)
+                                // (no fence: a test that does not see a bit yet only sends its candidate the usual way)
+                                grid_mark(cs, n_cs - 1, grid, s_gdom, (int)threadIdx.x, (int)blockDim.x);
                             }
+                        } else if (grid_on && in_place && nv2_j > 0) {
+                            // hidden by the full decision, and the bitmap had not said so: the cells inside it are
+                            // covered too (its ring is in the slot it was moved to, which the next member that shows
+                            // will take: hence the barrier)
+                            grid_mark(cs, n_cs, grid, s_gdom, (int)threadIdx.x, (int)blockDim.x);
+                            __syncthreads();
                         }
                     }
                     rec0 = rec1;
