@@ -130,44 +130,76 @@ __device__ inline double radiation_pattern(double theta, const rt_antenna_params
 }
 
 // Source field at `q` (electromagnetism.py:156-176), world frame.
-__device__ inline c3 source_field(const AntennaFrame &tx, d3 q, double K, const rt_antenna_params &ap, int &status) {
+struct SourceGeom {
+    d3 v;  // unit polarisation vector in the antenna's frame
+    double r, pattern;
+    int status;
+};
+__device__ inline SourceGeom source_geometry(const AntennaFrame &tx, d3 q, const rt_antenna_params &ap) {
+    SourceGeom g;
+    g.status = ST_OK;
     const d3 pa = w2a(tx, q - tx.pos);
-    double r, theta, phi;
-    if (!to_spherical(pa, r, theta, phi)) {
-        status = ST_ORIGIN;
-        return c3{{0, 0}, {0, 0}, {0, 0}};
-    }
+    double r = 1, theta = 0, phi;
+    if (!to_spherical(pa, r, theta, phi)) g.status = ST_ORIGIN;
     const d3 r_vv = vv_normalize(pa);
     const d3 pol_a = w2a(tx, tx.ax);
-    const d3 v = vv_normalize(cross(cross(r_vv, pol_a), r_vv));
+    g.v = vv_normalize(cross(cross(r_vv, pol_a), r_vv));
+    g.r = r;
+    g.pattern = radiation_pattern(theta, ap);
+    return g;
+}
+__device__ inline c3 source_apply(const SourceGeom &g, d3 ax, d3 ay, d3 az, double K, int &status) {
+    if (g.status != ST_OK) {
+        status = g.status;
+        return c3{{0, 0}, {0, 0}, {0, 0}};
+    }
     const double Z0 = 120.0 * M_PI;
     // -j K Z0 / (4 pi) exp(-j K r) / r F(theta)
-    const double mag = K * Z0 / (4.0 * M_PI) / r * radiation_pattern(theta, ap);
-    const cd ph = cexpj(-K * r);
+    const double mag = K * Z0 / (4.0 * M_PI) / g.r * g.pattern;
+    const cd ph = cexpj(-K * g.r);
     const cd amp = cmul(cd{0.0, -mag}, ph);
-    const c3 ea = cvec_scale(amp, v);
+    const c3 ea = cvec_scale(amp, g.v);
     // back to world: E_A @ mat
     c3 ew;
-    ew.x = cadd(cadd(cscale(tx.ax.x, ea.x), cscale(tx.ay.x, ea.y)), cscale(tx.az.x, ea.z));
-    ew.y = cadd(cadd(cscale(tx.ax.y, ea.x), cscale(tx.ay.y, ea.y)), cscale(tx.az.y, ea.z));
-    ew.z = cadd(cadd(cscale(tx.ax.z, ea.x), cscale(tx.ay.z, ea.y)), cscale(tx.az.z, ea.z));
+    ew.x = cadd(cadd(cscale(ax.x, ea.x), cscale(ay.x, ea.y)), cscale(az.x, ea.z));
+    ew.y = cadd(cadd(cscale(ax.y, ea.x), cscale(ay.y, ea.y)), cscale(az.y, ea.z));
+    ew.z = cadd(cadd(cscale(ax.z, ea.x), cscale(ay.z, ea.y)), cscale(az.z, ea.z));
     return ew;
 }
 
+// The field functions come in two halves: what depends on the path alone (directions, angles, the vectors of the dyadics)
+// and what depends on the carrier frequency as well (coefficients, phases).  A sweep over several frequencies computes
+// the first half once per path; the arithmetic of each half is the same whether the two run in one thread or not.
+
 // One reflection (electromagnetism.py:276-304, 247-273, 236-244, 308-311, 340): E <- (E·R) e^{-jK Sr} Si/(Si+Sr)
-__device__ inline c3 reflect_field(const SceneView &sc, c3 E, d3 p0, d3 p1, d3 p2, int poly, const FreqTable &ft, int f,
-                                   int &status) {
+struct ReflGeom {
+    d3 e_per, ei_par, er_par;
+    double sin_i, cosi, spread, Sr;  // spread = Si / (Si + Sr)
+    int material, status;
+};
+__device__ inline ReflGeom reflect_geometry(const SceneView &sc, d3 p0, d3 p1, d3 p2, int poly) {
+    ReflGeom g;
     const d3 v0 = p1 - p0, v1 = p2 - p1;
     const double Si = norm3(v0), Sr = norm3(v1);
     const d3 si = divs(v0, Si), sr = divs(v1, Sr);
     const d3 n = ld3(sc.planes + 4 * (size_t)poly);
     const double theta_i = acos(dot(n, mk3(-si.x, -si.y, -si.z)));
-    if (!(0 < theta_i && theta_i < M_PI / 2)) {
-        if (status == ST_OK) status = ST_INCIDENCE;
-    }
-    const int m = sc.material[poly];
+    g.status = (0 < theta_i && theta_i < M_PI / 2) ? ST_OK : ST_INCIDENCE;
+    g.material = sc.material[poly];
+    g.sin_i = sin(theta_i);
+    g.cosi = cos(theta_i);
+    g.e_per = vv_normalize(cross(si, sr));
+    g.ei_par = vv_normalize(cross(g.e_per, si));
+    g.er_par = vv_normalize(cross(g.e_per, sr));
+    g.spread = Si / (Si + Sr);
+    g.Sr = Sr;
+    return g;
+}
+__device__ inline c3 reflect_apply(c3 E, const ReflGeom &g, const FreqTable &ft, int f, int &status) {
+    if (status == ST_OK) status = g.status;
+    const int m = g.material;
     const cd eps{ft.eps_re[f][m], ft.eps_im[f][m]};
-    const double sin_i = sin(theta_i), cosi = cos(theta_i);
+    const double sin_i = g.sin_i, cosi = g.cosi;
     const cd root = csqrt_(cd{eps.re - sin_i * sin_i, eps.im});
     const cd ec = cscale(cosi, eps);
     const cd rp = cdivc(cd{ec.re - root.re, ec.im - root.im}, cd{ec.re + root.re, ec.im + root.im});
@@ -182,27 +214,33 @@ __device__ inline c3 reflect_field(const SceneView &sc, c3 E, d3 p0, d3 p1, d3 p
         r_par *= chi;
         r_per *= chi;
     }
-    const d3 e_per = vv_normalize(cross(si, sr));
-    const d3 ei_par = vv_normalize(cross(e_per, si));
-    const d3 er_par = vv_normalize(cross(e_per, sr));
     // E @ R with R = e_per e_per^T r_per + ei_par er_par^T r_par
-    const cd a = cscale(r_per, cdot_real(E, e_per));
-    const cd b = cscale(r_par, cdot_real(E, ei_par));
-    const cd ph = cscale(Si / (Si + Sr), cexpj(-ft.K[f] * Sr));
+    const cd a = cscale(r_per, cdot_real(E, g.e_per));
+    const cd b = cscale(r_par, cdot_real(E, g.ei_par));
+    const cd ph = cscale(g.spread, cexpj(-ft.K[f] * g.Sr));
     c3 out;
-    out.x = cmul(cadd(cscale(e_per.x, a), cscale(er_par.x, b)), ph);
-    out.y = cmul(cadd(cscale(e_per.y, a), cscale(er_par.y, b)), ph);
-    out.z = cmul(cadd(cscale(e_per.z, a), cscale(er_par.z, b)), ph);
+    out.x = cmul(cadd(cscale(g.e_per.x, a), cscale(g.er_par.x, b)), ph);
+    out.y = cmul(cadd(cscale(g.e_per.y, a), cscale(g.er_par.y, b)), ph);
+    out.z = cmul(cadd(cscale(g.e_per.z, a), cscale(g.er_par.z, b)), ph);
     return out;
 }
 
-// UTD transition function (electromagnetism.py:355-363)
+// UTD transition function (electromagnetism.py:355-363): 2j sqrt(x) e^{jx} sqrt(pi/2) ((1 - j)/2 - C(t) + j S(t)) with
+// t = sqrt(x) / sqrt(pi/2).  With the integrals written through their auxiliary functions (rt_fresnel.h) the bracket is
+// (g - j f) e^{-jx}: the exponentials cancel and F = 2 sqrt(x) sqrt(pi/2) (f + j g), without sine, cosine or the
+// cancellation of C and S against 1/2.  Below RT_FRESNEL_X0 the integrals themselves are used, as written.
 __device__ inline cd transition_F(double x) {
     const double factor = sqrt(M_PI / 2);
     const double sqrtx = sqrt(x);
+    const double t = sqrtx / factor;
+    if (t >= RT_FRESNEL_X0) {
+        double f, g;
+        rt_fresnel_fg(t, &f, &g);
+        const double w = 2.0 * sqrtx * factor;
+        return cd{w * f, w * g};
+    }
     double S, C;
-    rt_fresnel(sqrtx / factor, &S, &C);
-    // 2j sqrt(x) e^{jx} factor ((1 - j)/2 - C + jS)
+    rt_fresnel_small(t, &S, &C);
     const cd inner{factor * (0.5 - C), factor * (-0.5 + S)};
     const cd ex = cexpj(x);
     return cmul(cmul(cd{0.0, 2.0 * sqrtx}, ex), inner);
@@ -220,8 +258,14 @@ __device__ inline double py_mod_2pi(double a) {
 __device__ inline double sgn(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); }
 
 // One wedge diffraction (electromagnetism.py:395-507)
-__device__ inline c3 diffract_field(const SceneView &sc, c3 E, d3 p0, d3 p1, d3 p2, int poly0, int poly1, d3 c0, d3 c1,
-                                    double K, int &status) {
+struct DiffGeom {
+    d3 b_i, phi_i_vv, b_d, phi_d_vv;
+    double n, sin_b, L, A[4], cot[4], spread, Sd;  // spread = sqrt(Si / (Sd (Sd + Si)))
+    int status;
+};
+__device__ inline DiffGeom diffract_geometry(const SceneView &sc, d3 p0, d3 p1, d3 p2, int poly0, int poly1, d3 c0, d3 c1) {
+    DiffGeom g;
+    int status = ST_OK;
     const d3 v0 = p1 - p0, v1 = p2 - p1;
     const double Si = norm3(v0), Sd = norm3(v1);
     const d3 si = divs(v0, Si), sd = divs(v1, Sd);
@@ -255,35 +299,45 @@ __device__ inline c3 diffract_field(const SceneView &sc, c3 E, d3 p0, d3 p1, d3 
     if (!(0 <= phi_i && phi_i <= n * M_PI && 0 <= phi_d && phi_d <= n * M_PI)) {
         if (status == ST_OK) status = ST_INSIDE_WEDGE;
     }
-    // common_factor = -exp(-j pi/4) / (2 n sqrt(2 pi K) sin(beta_0))
-    const double cf_mag = 1.0 / (2 * n * sqrt(2 * M_PI * K) * sin(beta_0));
-    const cd cf = cscale(-cf_mag, cexpj(-M_PI / 4));
     const double sb = sin(beta_0);
-    const double L = sb * sb * Si * Sd / (Si + Sd);
+    g.n = n;
+    g.sin_b = sb;
+    g.L = sb * sb * Si * Sd / (Si + Sd);
     const double dm = phi_d - phi_i, dp = phi_d + phi_i;
-    const double cot1 = 1.0 / tan((M_PI + dm) * 1 / (2 * n));
-    const double cot2 = 1.0 / tan((M_PI - dm) * 1 / (2 * n));
-    const double cot3 = 1.0 / tan((M_PI + dp) * 1 / (2 * n));
-    const double cot4 = 1.0 / tan((M_PI - dp) * 1 / (2 * n));
-    const cd F1 = transition_F(K * L * utd_A(dm, n, true));
-    const cd F2 = transition_F(K * L * utd_A(dm, n, false));
-    const cd F3 = transition_F(K * L * utd_A(dp, n, true));
-    const cd F4 = transition_F(K * L * utd_A(dp, n, false));
-    const cd D1 = cmul(cscale(cot1, cf), F1), D2 = cmul(cscale(cot2, cf), F2);
-    const cd D3 = cmul(cscale(cot3, cf), F3), D4 = cmul(cscale(cot4, cf), F4);
-    const cd Dsum = cadd(cadd(D1, D2), cadd(D3, D4));  // D_per = D_par (r_per = r_par = 1, :483-487)
-    const d3 phi_i_vv = vv_normalize(cross(mk3(-e.x, -e.y, -e.z), si));
-    const d3 phi_d_vv = vv_normalize(cross(e, sd));
-    const d3 b_i = vv_normalize(cross(phi_i_vv, si));
-    const d3 b_d = vv_normalize(cross(phi_d_vv, sd));
+    g.cot[0] = 1.0 / tan((M_PI + dm) * 1 / (2 * n));
+    g.cot[1] = 1.0 / tan((M_PI - dm) * 1 / (2 * n));
+    g.cot[2] = 1.0 / tan((M_PI + dp) * 1 / (2 * n));
+    g.cot[3] = 1.0 / tan((M_PI - dp) * 1 / (2 * n));
+    g.A[0] = utd_A(dm, n, true);
+    g.A[1] = utd_A(dm, n, false);
+    g.A[2] = utd_A(dp, n, true);
+    g.A[3] = utd_A(dp, n, false);
+    g.phi_i_vv = vv_normalize(cross(mk3(-e.x, -e.y, -e.z), si));
+    g.phi_d_vv = vv_normalize(cross(e, sd));
+    g.b_i = vv_normalize(cross(g.phi_i_vv, si));
+    g.b_d = vv_normalize(cross(g.phi_d_vv, sd));
+    g.spread = sqrt(Si / (Sd * (Sd + Si)));
+    g.Sd = Sd;
+    g.status = status;
+    return g;
+}
+__device__ inline c3 diffract_apply(c3 E, const DiffGeom &g, double K, int &status) {
+    if (status == ST_OK) status = g.status;
+    // common_factor = -exp(-j pi/4) / (2 n sqrt(2 pi K) sin(beta_0))
+    const double cf_mag = 1.0 / (2 * g.n * sqrt(2 * M_PI * K) * g.sin_b);
+    const cd cf = cscale(-cf_mag, cexpj(-M_PI / 4));
+    cd Dsum{0, 0};  // D_per = D_par (r_per = r_par = 1, :483-487); (D1 + D2) + (D3 + D4)
+    cd D[4];
+    for (int q = 0; q < 4; ++q) D[q] = cmul(cscale(g.cot[q], cf), transition_F(K * g.L * g.A[q]));
+    Dsum = cadd(cadd(D[0], D[1]), cadd(D[2], D[3]));
     // E @ D, D = b_i b_d^T (-D_per) - phi_i phi_d^T D_par
-    const cd a = cmul(cdot_real(E, b_i), cd{-Dsum.re, -Dsum.im});
-    const cd b = cmul(cdot_real(E, phi_i_vv), cd{-Dsum.re, -Dsum.im});
-    const cd ph = cscale(sqrt(Si / (Sd * (Sd + Si))), cexpj(-K * Sd));
+    const cd a = cmul(cdot_real(E, g.b_i), cd{-Dsum.re, -Dsum.im});
+    const cd b = cmul(cdot_real(E, g.phi_i_vv), cd{-Dsum.re, -Dsum.im});
+    const cd ph = cscale(g.spread, cexpj(-K * g.Sd));
     c3 out;
-    out.x = cmul(cadd(cscale(b_d.x, a), cscale(phi_d_vv.x, b)), ph);
-    out.y = cmul(cadd(cscale(b_d.y, a), cscale(phi_d_vv.y, b)), ph);
-    out.z = cmul(cadd(cscale(b_d.z, a), cscale(phi_d_vv.z, b)), ph);
+    out.x = cmul(cadd(cscale(g.b_d.x, a), cscale(g.phi_d_vv.x, b)), ph);
+    out.y = cmul(cadd(cscale(g.b_d.y, a), cscale(g.phi_d_vv.y, b)), ph);
+    out.z = cmul(cadd(cscale(g.b_d.z, a), cscale(g.phi_d_vv.z, b)), ph);
     if (!(cnorm3(E) >= cnorm3(out))) {
         if (status == ST_OK) status = ST_DIFFRACTED_GAIN;
     }
@@ -423,15 +477,18 @@ __global__ __launch_bounds__(256) void k_field_classes(PathArrays pa, int32_t *_
 // after the other are in ascending order too --, then the grouping of geometry.py:886-895 by one lane.  (One wave per
 // line of sight left two waves on a SIMD with nothing to hide the record reads behind: 100 us for lln's 2 000 lines.)
 #define LOS_HIT_CAP 128
-__global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, d3 tx, const double *__restrict__ rx,
-                                                    const int32_t *__restrict__ los_list, const unsigned long long *los_count,
-                                                    TreeHits *__restrict__ out) {
-    __shared__ int32_t s_hits[4][LOS_HIT_CAP];
-    __shared__ int s_n[4];
+// The look-up itself, by a workgroup of WAVES waves (every thread of the workgroup calls it; `first`, `step`: which
+// entries of the list this workgroup takes).
+template <int WAVES>
+__device__ __forceinline__ void los_tree_hits(const SceneView &sc, const PathArrays &pa, d3 tx, const double *__restrict__ rx,
+                                              const int32_t *__restrict__ los_list, const unsigned long long *los_count,
+                                              TreeHits *__restrict__ out, int64_t first, int64_t step) {
+    __shared__ int32_t s_hits[WAVES][LOS_HIT_CAP];
+    __shared__ int s_n[WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n_los = (int64_t)*los_count;
-    const int per_wave = ((sc.n + 3) / 4 + 63) & ~63;  // polygons per wave, whole trips of 64
-    for (int64_t j = blockIdx.x; j < n_los; j += gridDim.x) {
+    const int per_wave = ((sc.n + WAVES - 1) / WAVES + 63) & ~63;  // polygons per wave, whole trips of 64
+    for (int64_t j = first; j < n_los; j += step) {
         const int64_t i = los_list[j];
         const d3 A = pa.origin ? ld3(pa.origin + 3 * (size_t)i) : tx;
         const d3 B = ld3(rx + 3 * (size_t)pa.rx[i]);
@@ -452,7 +509,15 @@ __global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, 
         if (lane == 0) s_n[wave] = n_mine;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int n_hits = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+            int n_hits = 0;
+            bool too_many = false;
+            for (int w = 0; w < WAVES; ++w) {
+                n_hits += s_n[w];
+                too_many = too_many || s_n[w] > LOS_HIT_CAP;
+            }
+            // (a wave that finds more than LOS_HIT_CAP on its own has kept its first LOS_HIT_CAP; the path is then marked as
+            // not to be trusted below, and what is grouped does not matter)
+            too_many = too_many || n_hits > LOS_HIT_CAP;
             // the q-th crossed polygon in ascending order (q below LOS_HIT_CAP, which bounds what is looked at)
             auto hit_at = [&](int q) -> int {
                 int w = 0;
@@ -462,13 +527,13 @@ __global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, 
             TreeHits h;
             h.n = 0;
             h.concave = 0;
-            int first = -1, second = -1, count = 0;
+            int first_p = -1, second_p = -1, count = 0;
             auto flush = [&]() {
                 if (count == 2) {
                     // geometry.py:89-106 for both polygons
                     const d3 dir = vv_normalize(B - A);
                     d3 pts[2];
-                    const int idx[2] = {first, second};
+                    const int idx[2] = {first_p, second_p};
                     for (int q = 0; q < 2; ++q) {
                         const d3 n = ld3(sc.planes + 4 * (size_t)idx[q]);
                         const d3 pp = ld3(sc.verts + 3 * ((size_t)sc.vert_off[idx[q]] + 1));
@@ -484,18 +549,14 @@ __global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, 
                     h.concave = 1;
                 }
             };
-            // (a wave that finds more than LOS_HIT_CAP on its own has kept its first LOS_HIT_CAP; the path is then marked as
-            // not to be trusted below, and what is grouped does not matter)
-            const bool too_many = n_hits > LOS_HIT_CAP || s_n[0] > LOS_HIT_CAP || s_n[1] > LOS_HIT_CAP || s_n[2] > LOS_HIT_CAP ||
-                                  s_n[3] > LOS_HIT_CAP;
             const int m = too_many ? 0 : n_hits;
             for (int q = 0; q < m; ++q) {
                 const int p = hit_at(q);
                 if (count == 0) {
-                    first = p;
+                    first_p = p;
                     count = 1;
-                } else if (sc.building[first] == sc.building[p]) {
-                    if (count == 1) second = p;
+                } else if (sc.building[first_p] == sc.building[p]) {
+                    if (count == 1) second_p = p;
                     ++count;
                 } else {
                     flush();  // geometry.py:890-892: the group is closed and the polygon that closed it is dropped
@@ -509,6 +570,11 @@ __global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, 
         __syncthreads();  // the lists are free for the next line of sight
     }
 }
+__global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, d3 tx, const double *__restrict__ rx,
+                                                    const int32_t *__restrict__ los_list, const unsigned long long *los_count,
+                                                    TreeHits *__restrict__ out) {
+    los_tree_hits<4>(sc, pa, tx, rx, los_list, los_count, out, blockIdx.x, gridDim.x);
+}
 
 struct FieldOut {
     double *field;    // [n_paths * n_freq * 6]
@@ -519,115 +585,240 @@ struct FieldOut {
     double *power_sum;// [n_rx * n_freq]
 };
 
+// What a path's geometry half leaves for its frequency half when the two run in different kernels: slot q of path i is
+// geom[q * stride + i].  A value passes through `io` in the same order on both sides.
+#define GEOM_COMMON 26
+#define GEOM_PER_REFLECTION 14
+#define GEOM_DIFFRACTION 26
+#define GEOM_SLOTS (GEOM_COMMON + GEOM_PER_REFLECTION * RT_MAX_ORDER + GEOM_DIFFRACTION)
+enum FieldMode {
+    FIELDS_WHOLE = 0,     // a thread per (path, frequency) does both halves
+    FIELDS_GEOMETRY = 1,  // a thread per path writes its geometry
+    FIELDS_FREQUENCY = 2  // a thread per (path, frequency) reads it
+};
+template <int MODE>
+struct GeomIO {
+    double *at;  // slot 0 of this path
+    int64_t stride;
+    bool on;  // FIELDS_GEOMETRY: this thread has computed what passes now and writes it
+    __device__ inline void io(double &v) {
+        if (MODE == FIELDS_GEOMETRY && on) *at = v;
+        if (MODE == FIELDS_FREQUENCY) v = *at;
+        at += stride;
+    }
+    __device__ inline void io(d3 &v) {
+        io(v.x);
+        io(v.y);
+        io(v.z);
+    }
+    __device__ inline void io(int &a, int &b) {  // two small non-negative integers in one slot
+        double v = (double)(a * 256 + b);
+        io(v);
+        if (MODE == FIELDS_FREQUENCY) {
+            a = (int)v >> 8;
+            b = (int)v & 255;
+        }
+    }
+    __device__ inline void skip(int slots) { at += (int64_t)slots * stride; }
+};
+
 // CLASS: 0 lines of sight, 1 reflections only, 2 paths ending with a diffraction (k_field_classes); a thread takes entry
-// blockIdx.x * blockDim.x + threadIdx.x of its class's list.
-template <int CLASS>
-__global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, FreqTable ft, rt_antenna_params ap, d3 tx,
-                                                 const double *__restrict__ rx,
-                                                 const unsigned long long *__restrict__ best_idx,
-                                                 const int32_t *__restrict__ list, const unsigned long long *list_count,
-                                                 const TreeHits *__restrict__ los_trees, FieldOut out) {
-    // one thread per (path, frequency): blockIdx.y is the frequency.  The frequency-independent set-up (antenna frames,
-    // angles) is cheap beside the coefficients and is simply redone per frequency; what it writes, frequency 0 writes.
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// blockIdx.x * blockDim.x + threadIdx.x of its class's list, and in the modes with a thread per (path, frequency)
+// blockIdx.y is the frequency.  In FIELDS_WHOLE what the path alone decides (antenna frames, angles, the geometry of
+// every interaction) is redone for every frequency; a sweep over several frequencies goes through FIELDS_GEOMETRY once
+// per path and FIELDS_FREQUENCY per frequency instead.  Segments through tree crowns (n_late) need FIELDS_WHOLE.
+template <int CLASS, int MODE>
+__device__ __forceinline__ void fields_of_path(const SceneView &sc, const PathArrays &pa, const FreqTable &ft,
+                                               const rt_antenna_params &ap, d3 tx, const double *__restrict__ rx,
+                                               const unsigned long long *__restrict__ best_idx, const int32_t *__restrict__ list,
+                                               const unsigned long long *list_count, const TreeHits *__restrict__ los_trees,
+                                               const FieldOut &out, double *geom, int64_t geom_stride, int64_t j,
+                                               int f_or_part) {
     if (j >= (int64_t)*list_count) return;
     const int64_t i = list[j];
-    const int f = blockIdx.y;
-    const int r = pa.rx[i];
+    const int f = MODE == FIELDS_GEOMETRY ? 0 : f_or_part;
     const int kind = pa.kind[i];
-    d3 P[RT_MAX_ORDER + 2];
-    const int np = path_points(pa, i, tx, rx, P);
-    const d3 R = P[np - 1];
-    // antennas aligned on the receiver's shortest path (electromagnetism.py:768-771)
-    d3 aim_t, aim_r;
-    if (pa.aim_tx && pa.aim_rx) {
-        aim_t = ld3(pa.aim_tx + 3 * (size_t)r);
-        aim_r = ld3(pa.aim_rx + 3 * (size_t)r);
-    } else {
-        d3 Q[RT_MAX_ORDER + 2];
-        const int nq = path_points(pa, (int64_t)best_idx[r], tx, rx, Q);
-        aim_t = Q[1];
-        aim_r = Q[nq - 2];
-    }
-    const AntennaFrame txa = align_antenna(tx, aim_t);
-    const AntennaFrame rxa = align_antenna(R, aim_r);
-
-    int status = ST_OK;
-    double len = 0;
-    for (int k = 0; k + 1 < np; ++k) len += norm3(P[k + 1] - P[k]);
-    double rr, tx_el = 0, tx_az = 0, rx_el = 0, rx_az = 0;
-    if (!to_spherical(w2a(txa, P[1] - tx), rr, tx_el, tx_az)) status = ST_ORIGIN;
-    if (!to_spherical(w2a(rxa, P[np - 2] - R), rr, rx_el, rx_az)) status = ST_ORIGIN;
-    if (f == 0) {
-        const double deg = 180.0 / M_PI;
-        out.time[i] = len / 299792458.0;
-        out.angles[4 * i + 0] = tx_el * deg;
-        out.angles[4 * i + 1] = tx_az * deg;
-        out.angles[4 * i + 2] = rx_el * deg;
-        out.angles[4 * i + 3] = rx_az * deg;
-    }
-
     const int n_refl = CLASS == 0 ? 0 : (kind & 255);
     const bool has_edge = CLASS == 2;
-    const int32_t *chain = pa.chain + (size_t)i * RT_MAX_ORDER;
+    // FIELDS_GEOMETRY: blockIdx.y is the part of the path's geometry this thread computes (the parts are independent
+    // of each other, and a path's geometry is a chain of dependent operations that lasts as long as its longest part):
+    // 0 antennas, angles and source, 1 + k the k-th reflection, RT_MAX_ORDER + 1 the diffraction
+    const int part = MODE == FIELDS_GEOMETRY ? f_or_part : -1;
+    if (MODE == FIELDS_GEOMETRY && ((part >= 1 && part <= RT_MAX_ORDER && part - 1 >= n_refl) || (part == RT_MAX_ORDER + 1 && !has_edge)))
+        return;
+    auto mine = [&](int what) { return MODE == FIELDS_WHOLE || (MODE == FIELDS_GEOMETRY && part == what); };
+    GeomIO<MODE> g{geom + i, geom_stride, false};
 
-    {
-        const double K = ft.K[f];
-        int st = status;
-        c3 E;
+    d3 P[RT_MAX_ORDER + 2];
+    int np = 0;
+    d3 tx_ax, tx_ay, tx_az, rx_ax, rx_ay, rx_az;
+    double rx_pattern = 0;
+    int status = ST_OK;
+    SourceGeom src;
+    src.status = ST_OK;
+    if (MODE != FIELDS_FREQUENCY) np = path_points(pa, i, tx, rx, P);
+    g.on = mine(0);
+    if (mine(0)) {
+        const int r = pa.rx[i];
+        const d3 R = P[np - 1];
+        // antennas aligned on the receiver's shortest path (electromagnetism.py:768-771)
+        d3 aim_t, aim_r;
+        if (pa.aim_tx && pa.aim_rx) {
+            aim_t = ld3(pa.aim_tx + 3 * (size_t)r);
+            aim_r = ld3(pa.aim_rx + 3 * (size_t)r);
+        } else {
+            d3 Q[RT_MAX_ORDER + 2];
+            const int nq = path_points(pa, (int64_t)best_idx[r], tx, rx, Q);
+            aim_t = Q[1];
+            aim_r = Q[nq - 2];
+        }
+        const AntennaFrame txa = align_antenna(tx, aim_t);
+        const AntennaFrame rxa = align_antenna(R, aim_r);
+        double len = 0;
+        for (int k = 0; k + 1 < np; ++k) len += norm3(P[k + 1] - P[k]);
+        double rr, tx_el = 0, tx_az_deg = 0, rx_el = 0, rx_az_deg = 0;
+        if (!to_spherical(w2a(txa, P[1] - tx), rr, tx_el, tx_az_deg)) status = ST_ORIGIN;
+        if (!to_spherical(w2a(rxa, P[np - 2] - R), rr, rx_el, rx_az_deg)) status = ST_ORIGIN;
+        if (f == 0) {
+            const double deg = 180.0 / M_PI;
+            out.time[i] = len / 299792458.0;
+            out.angles[4 * i + 0] = tx_el * deg;
+            out.angles[4 * i + 1] = tx_az_deg * deg;
+            out.angles[4 * i + 2] = rx_el * deg;
+            out.angles[4 * i + 3] = rx_az_deg * deg;
+        }
+        if (!pa.e_in) src = source_geometry(txa, P[1], ap);
+        tx_ax = txa.ax; tx_ay = txa.ay; tx_az = txa.az;
+        rx_ax = rxa.ax; rx_ay = rxa.ay; rx_az = rxa.az;
+        rx_pattern = radiation_pattern(rx_el, ap);
+    }
+    g.io(src.v); g.io(src.r); g.io(src.pattern);
+    g.io(status, src.status);
+    g.io(tx_ax); g.io(tx_ay); g.io(tx_az);
+    g.io(rx_ax); g.io(rx_ay); g.io(rx_az);
+    g.io(rx_pattern);
+    static_assert(GEOM_COMMON == 3 + 2 + 1 + 9 + 9 + 1 + 1, "one slot spare");
+
+    const double K = ft.K[f];
+    int st = status;
+    c3 E{{0, 0}, {0, 0}, {0, 0}};
+    double e0 = 0;
+    if (MODE != FIELDS_GEOMETRY) {
         if (pa.e_in) {
             const double *q = pa.e_in + 6 * (size_t)i;
             E = c3{{q[0], q[1]}, {q[2], q[3]}, {q[4], q[5]}};
         } else {
-            E = source_field(txa, P[1], K, ap, st);
+            E = source_apply(src, tx_ax, tx_ay, tx_az, K, st);
         }
-        const double e0 = cnorm3(E);
-        const int late_begin = sc.n - pa.n_late;
-        auto through_trees = [&](d3 A, d3 B, int p_begin) {
-            if (p_begin >= sc.n) return;
-            const double fac = tree_factor(sc, A, B, ft.freq[f], st, p_begin);
-            E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
-        };
-        if (CLASS == 0 && !pa.e_in) {  // electromagnetism.py:669: every polygon of the scene, found by k_los_trees
-            const TreeHits h = los_trees[j];
-            if (h.concave && st == ST_OK) st = ST_CONCAVE;
-            const double fac = tree_factor_of(h, ft.freq[f]);
-            E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
-        }
-        for (int k = 0; k < n_refl; ++k) {
-            through_trees(P[k], P[k + 1], late_begin);  // :338
-            E = reflect_field(sc, E, P[k], P[k + 1], P[k + 2], chain[k], ft, f, st);
+        e0 = cnorm3(E);
+    }
+    const int late_begin = sc.n - pa.n_late;
+    auto through_trees = [&](int from, int to, int p_begin) {  // the segment between two of the path's points
+        if (MODE != FIELDS_WHOLE || p_begin >= sc.n) return;
+        const double fac = tree_factor(sc, P[from], P[to], ft.freq[f], st, p_begin);
+        E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
+    };
+    if (CLASS == 0 && !pa.e_in && MODE != FIELDS_GEOMETRY) {  // electromagnetism.py:669: every polygon of the scene, found by k_los_trees
+        const TreeHits h = los_trees[j];
+        if (h.concave && st == ST_OK) st = ST_CONCAVE;
+        const double fac = tree_factor_of(h, ft.freq[f]);
+        E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
+    }
+    for (int k = 0; k < n_refl; ++k) {
+        through_trees(k, k + 1, late_begin);  // :338
+        ReflGeom rg{};
+        g.on = mine(1 + k);
+        if (mine(1 + k)) rg = reflect_geometry(sc, P[k], P[k + 1], P[k + 2], pa.chain[(size_t)i * RT_MAX_ORDER + k]);
+        g.io(rg.e_per); g.io(rg.ei_par); g.io(rg.er_par);
+        g.io(rg.sin_i); g.io(rg.cosi); g.io(rg.spread); g.io(rg.Sr);
+        g.io(rg.material, rg.status);
+        if (MODE != FIELDS_GEOMETRY) {
+            E = reflect_apply(E, rg, ft, f, st);
             if (!(e0 >= cnorm3(E)) && st == ST_OK) st = ST_REFLECTED_GAIN;  // electromagnetism.py:342 (E_i is the first field)
         }
-        if (n_refl > 0) through_trees(P[n_refl], P[n_refl + 1], late_begin);  // :346-348
-        if (has_edge) {
-            if (n_refl == 0 && !pa.e_in) through_trees(P[0], P[1], late_begin);  // :724-725
+    }
+    if (n_refl > 0) through_trees(n_refl, n_refl + 1, late_begin);  // :346-348
+    if (has_edge) {
+        if (n_refl == 0 && !pa.e_in) through_trees(0, 1, late_begin);  // :724-725
+        DiffGeom dg{};
+        g.on = mine(RT_MAX_ORDER + 1);
+        if (mine(RT_MAX_ORDER + 1)) {
             const d3 c0 = ld3(pa.edge_pts + 6 * (size_t)i), c1 = ld3(pa.edge_pts + 6 * (size_t)i + 3);
-            E = diffract_field(sc, E, P[np - 3], P[np - 2], P[np - 1], pa.edge_polys[2 * i], pa.edge_polys[2 * i + 1], c0,
-                               c1, K, st);
-            through_trees(P[np - 2], P[np - 1], late_begin);  // :506
+            dg = diffract_geometry(sc, P[np - 3], P[np - 2], P[np - 1], pa.edge_polys[2 * i], pa.edge_polys[2 * i + 1], c0, c1);
         }
-        // received power (electromagnetism.py:779-787)
-        const double Ae = (ft.lambda[f] * ft.lambda[f] / (4 * M_PI)) * ap.rx_gain * radiation_pattern(rx_el, ap);
-        c3 Ea;
-        Ea.x = cdot_real(E, rxa.ax);
-        Ea.y = cdot_real(E, rxa.ay);
-        Ea.z = cdot_real(E, rxa.az);
-        const double en = cnorm3(Ea);
-        const d3 pol_a = w2a(rxa, rxa.ax);
-        cd pe{0, 0};
-        if (en != 0) pe = cscale(1.0 / en, cdot_real(Ea, pol_a));
-        const double pol_eff = pe.re * pe.re + pe.im * pe.im;
-        const double re2 = Ea.x.re * Ea.x.re + Ea.y.re * Ea.y.re + Ea.z.re * Ea.z.re;
-        const double Z0 = 120.0 * M_PI;
-        double power = 1 / (2 * Z0) * Ae * re2;
-        power = power * pol_eff * ap.tx_gain;
-        double *fo = out.field + ((size_t)i * ft.n_freq + f) * 6;
-        fo[0] = E.x.re; fo[1] = E.x.im; fo[2] = E.y.re; fo[3] = E.y.im; fo[4] = E.z.re; fo[5] = E.z.im;
-        out.power[(size_t)i * ft.n_freq + f] = power;
-        // the status of a path is that of the lowest frequency at which something went wrong (the order in which a
-        // loop over the frequencies would have met it): keep the smallest (frequency, status) key
-        if (st != ST_OK) atomicMin(&out.status[i], (f << 8) | st);
+        g.io(dg.b_i); g.io(dg.phi_i_vv); g.io(dg.b_d); g.io(dg.phi_d_vv);
+        g.io(dg.n); g.io(dg.sin_b); g.io(dg.L);
+        for (int q = 0; q < 4; ++q) g.io(dg.A[q]);
+        for (int q = 0; q < 4; ++q) g.io(dg.cot[q]);
+        g.io(dg.spread); g.io(dg.Sd);
+        int none = 0;
+        g.io(none, dg.status);
+        if (MODE != FIELDS_GEOMETRY) E = diffract_apply(E, dg, K, st);
+        through_trees(np - 2, np - 1, late_begin);  // :506
+    }
+    if (MODE == FIELDS_GEOMETRY) return;
+    // received power (electromagnetism.py:779-787)
+    const double Ae = (ft.lambda[f] * ft.lambda[f] / (4 * M_PI)) * ap.rx_gain * rx_pattern;
+    c3 Ea;
+    Ea.x = cdot_real(E, rx_ax);
+    Ea.y = cdot_real(E, rx_ay);
+    Ea.z = cdot_real(E, rx_az);
+    const double en = cnorm3(Ea);
+    const d3 pol_a = mk3(dot(rx_ax, rx_ax), dot(rx_ax, rx_ay), dot(rx_ax, rx_az));  // the x axis in the antenna's own frame
+    cd pe{0, 0};
+    if (en != 0) pe = cscale(1.0 / en, cdot_real(Ea, pol_a));
+    const double pol_eff = pe.re * pe.re + pe.im * pe.im;
+    const double re2 = Ea.x.re * Ea.x.re + Ea.y.re * Ea.y.re + Ea.z.re * Ea.z.re;
+    const double Z0 = 120.0 * M_PI;
+    double power = 1 / (2 * Z0) * Ae * re2;
+    power = power * pol_eff * ap.tx_gain;
+    double *fo = out.field + ((size_t)i * ft.n_freq + f) * 6;
+    fo[0] = E.x.re; fo[1] = E.x.im; fo[2] = E.y.re; fo[3] = E.y.im; fo[4] = E.z.re; fo[5] = E.z.im;
+    out.power[(size_t)i * ft.n_freq + f] = power;
+    // the status of a path is that of the lowest frequency at which something went wrong (the order in which a
+    // loop over the frequencies would have met it): keep the smallest (frequency, status) key
+    if (st != ST_OK) atomicMin(&out.status[i], (f << 8) | st);
+}
+
+// The three classes in one launch, side by side: blockIdx.z is the class (lists[c * n] with counts[c]); the grid is sized
+// for the whole batch per class and the blocks past the end of a list leave at once.
+//   FIELDS_WHOLE      grid (entries / 128, frequencies, 3)
+//   FIELDS_GEOMETRY   grid (entries / 128 or more, parts of a path's geometry, 3); for the lines of sight the tree look-up
+//                     is done instead, a workgroup per line
+//   FIELDS_FREQUENCY  grid (entries / (128 / frequencies), 1, 3): the frequencies of a path are neighbouring lanes, so a
+//                     wave reads the geometry of its nine or so paths once instead of once per frequency and writes each
+//                     path's fields as one run of bytes; the lines of sight go through FIELDS_WHOLE here
+#define FIELDS_GEOMETRY_PARTS (RT_MAX_ORDER + 2)
+template <int MODE>
+__global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, FreqTable ft, rt_antenna_params ap, d3 tx,
+                                                 const double *__restrict__ rx,
+                                                 const unsigned long long *__restrict__ best_idx,
+                                                 const int32_t *__restrict__ lists, const unsigned long long *counts,
+                                                 TreeHits *__restrict__ los_trees, FieldOut out, double *geom,
+                                                 int64_t geom_stride) {
+    const int cls = blockIdx.z;
+    const int32_t *list = lists + (size_t)cls * pa.n;
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int f_or_part = blockIdx.y;
+    if (MODE == FIELDS_FREQUENCY) {
+        const int per_block = (int)blockDim.x / ft.n_freq, local = (int)threadIdx.x / ft.n_freq;
+        if (local >= per_block) return;
+        f_or_part = (int)threadIdx.x - local * ft.n_freq;
+        j = (int64_t)blockIdx.x * per_block + local;
+    }
+    if (cls == 0) {
+        if (MODE == FIELDS_GEOMETRY) {
+            if (!pa.e_in)
+                los_tree_hits<2>(sc, pa, tx, rx, list, counts, los_trees, (int64_t)blockIdx.y * gridDim.x + blockIdx.x,
+                                 (int64_t)gridDim.x * gridDim.y);
+        } else {
+            fields_of_path<0, FIELDS_WHOLE>(sc, pa, ft, ap, tx, rx, best_idx, list, counts, los_trees, out, geom, geom_stride, j,
+                                            f_or_part);
+        }
+    } else if (cls == 1) {
+        fields_of_path<1, MODE>(sc, pa, ft, ap, tx, rx, best_idx, list, counts + 1, los_trees, out, geom, geom_stride, j, f_or_part);
+    } else {
+        fields_of_path<2, MODE>(sc, pa, ft, ap, tx, rx, best_idx, list, counts + 2, los_trees, out, geom, geom_stride, j, f_or_part);
     }
 }
 
@@ -1042,6 +1233,12 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
     unsigned long long *cls_counts = scene->d_counters + 13;  // [13], [14], [15]
     F_PTR(fo.power_sum); F_PTR(best_len); F_PTR(best_idx); F_PTR(rx_counts); F_PTR(rx_off); F_PTR(rx_order);
     F_PTR(cls_lists); F_PTR(los_trees); F_PTR(rx_keys);
+    // several frequencies and no segment through tree crowns: the paths' geometry goes through memory (k_fields)
+    double *geom = nullptr;
+    if (n_freq > 1 && pa.n_late == 0 && n_paths > 0) {
+        geom = (double *)dalloc(sizeof(double) * GEOM_SLOTS * np_);
+        F_PTR(geom);
+    }
     // everything that has to start from a fixed value, in one launch (six fills used to go one by one)
     {
         const int64_t most = std::max<int64_t>((int64_t)(n_rx * nf), std::max<int64_t>(2 * n_rx, (int64_t)np_));
@@ -1058,16 +1255,23 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
         if (ev[1]) F_HIP(hipEventRecord(ev[1], st));
         // the class kernels read their list's length on the device: the grids are sized for the whole batch and the
         // blocks past the end of a list leave at once
-        const dim3 fgrid((unsigned)((n_paths + 127) / 128), (unsigned)n_freq);
-        if (!pa.e_in)
-            hipLaunchKernelGGL(k_los_trees, dim3((unsigned)std::min<int64_t>((int64_t)n_paths, 4096)), dim3(256), 0, st,
-                               scene->view, pa, TX, d_rx, cls_lists, cls_counts, los_trees);
-        hipLaunchKernelGGL(k_fields<0>, fgrid, dim3(128), 0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx, cls_lists,
-                           cls_counts, los_trees, fo);
-        hipLaunchKernelGGL(k_fields<1>, fgrid, dim3(128), 0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx,
-                           cls_lists + np_, cls_counts + 1, los_trees, fo);
-        hipLaunchKernelGGL(k_fields<2>, fgrid, dim3(128), 0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx,
-                           cls_lists + 2 * np_, cls_counts + 2, los_trees, fo);
+        const unsigned fblocks = (unsigned)((n_paths + 127) / 128);
+        if (geom) {
+            // a sweep: the geometry of every path once (and the tree look-up of the lines of sight beside it), then a
+            // thread per (path, frequency) for what the frequency decides
+            // (at least 1 024 x parts workgroups, so that the lines of sight of a small batch get a workgroup each)
+            hipLaunchKernelGGL(k_fields<FIELDS_GEOMETRY>, dim3(std::max(fblocks, 1024u), FIELDS_GEOMETRY_PARTS, 3), dim3(128), 0, st, scene->view,
+                               pa, ft, *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, geom, (int64_t)np_);
+            const int64_t per_block = 128 / n_freq;
+            hipLaunchKernelGGL(k_fields<FIELDS_FREQUENCY>, dim3((unsigned)((n_paths + per_block - 1) / per_block), 1, 3), dim3(128), 0, st, scene->view, pa,
+                               ft, *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, geom, (int64_t)np_);
+        } else {
+            if (!pa.e_in)
+                hipLaunchKernelGGL(k_los_trees, dim3((unsigned)std::min<int64_t>((int64_t)n_paths, 4096)), dim3(256), 0, st,
+                                   scene->view, pa, TX, d_rx, cls_lists, cls_counts, los_trees);
+            hipLaunchKernelGGL(k_fields<FIELDS_WHOLE>, dim3(fblocks, (unsigned)n_freq, 3), dim3(128), 0, st, scene->view, pa, ft,
+                               *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, (double *)nullptr, (int64_t)0);
+        }
         if (ev[2]) F_HIP(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k_status_final, dim3(grid), dim3(256), 0, st, fo.status, (int64_t)n_paths);
         hipLaunchKernelGGL(k_rx_path_count, dim3(grid), dim3(256), 0, st, pa, rx_counts);
