@@ -364,21 +364,6 @@ __device__ inline double path_key_length(const PathArrays &pa, int64_t i, d3 tx,
     return len;
 }
 
-// pass 1: shortest length per receiver
-__global__ void k_best_length(PathArrays pa, d3 tx, const double *__restrict__ rx, unsigned long long *best_len) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pa.n) return;
-    atomicMin(&best_len[pa.rx[i]], (unsigned long long)__double_as_longlong(path_key_length(pa, i, tx, rx)));
-}
-// pass 2: among equally short ones (exact ties only) the first in the order the paths were given
-__global__ void k_best_index(PathArrays pa, d3 tx, const double *__restrict__ rx, const unsigned long long *best_len,
-                             unsigned long long *best_idx) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pa.n) return;
-    if ((unsigned long long)__double_as_longlong(path_key_length(pa, i, tx, rx)) == best_len[pa.rx[i]])
-        atomicMin(&best_idx[pa.rx[i]], (unsigned long long)i);
-}
-
 // Loss the reference applies to a segment that crosses geometry: whatever it crosses is treated as tree crowns
 // (electromagnetism.py:179-199, geometry.py:868-921).  Polygons p_begin.. are looked at: all of them for a line of
 // sight (it was only checked against the polygons the emitter sees), and for the other segments the polygons added
@@ -448,11 +433,15 @@ __device__ inline double tree_factor_of(const TreeHits &h, double freq) {
     return factor;
 }
 
-// The paths of a batch by what the field kernel has to do for them: [0] lines of sight, [1] reflections only, [2] paths
-// ending with a diffraction.  One kernel per class works on its own list: full waves of like work, and the common
-// classes compile to small kernels (the all-in-one kernel needed 256 registers and scratch memory).  A block reserves
-// the room of its entries with one atomic per class.
-__global__ __launch_bounds__(256) void k_field_classes(PathArrays pa, int32_t *__restrict__ lists, unsigned long long *counts) {
+// First pass over the paths of a batch, a thread per path:
+//  - the paths by what the field kernel has to do for them: lists[0] lines of sight, [1] reflections only, [2] paths
+//    ending with a diffraction (full waves of like work; a block reserves the room of its entries with one atomic per
+//    class);
+//  - the shortest length per receiver (the antennas are aimed along that path, electromagnetism.py:610-644);
+//  - the number of paths per receiver.
+__global__ __launch_bounds__(256) void k_fields_pass1(PathArrays pa, d3 tx, const double *__restrict__ rx,
+                                                       unsigned long long *best_len, int32_t *__restrict__ lists,
+                                                       unsigned long long *counts, int32_t *rx_counts) {
     __shared__ int s_n[3];
     __shared__ unsigned long long s_base[3];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -463,6 +452,9 @@ __global__ __launch_bounds__(256) void k_field_classes(PathArrays pa, int32_t *_
         const int kind = pa.kind[i];
         cls = (kind >> 8) ? 2 : ((kind & 255) ? 1 : 0);
         slot = atomicAdd(&s_n[cls], 1);
+        const int r = pa.rx[i];
+        atomicMin(&best_len[r], (unsigned long long)__double_as_longlong(path_key_length(pa, i, tx, rx)));
+        atomicAdd(&rx_counts[r], 1);
     }
     __syncthreads();
     if (threadIdx.x < 3 && s_n[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)s_n[threadIdx.x]);
@@ -570,12 +562,86 @@ __device__ __forceinline__ void los_tree_hits(const SceneView &sc, const PathArr
         __syncthreads();  // the lists are free for the next line of sight
     }
 }
-__global__ __launch_bounds__(256) void k_los_trees(SceneView sc, PathArrays pa, d3 tx, const double *__restrict__ rx,
-                                                    const int32_t *__restrict__ los_list, const unsigned long long *los_count,
-                                                    TreeHits *__restrict__ out) {
-    los_tree_hits<4>(sc, pa, tx, rx, los_list, los_count, out, blockIdx.x, gridDim.x);
+// Second pass, workgroups of 1 024 threads with three kinds of work side by side:
+//  - blocks [0, path_blocks): among a receiver's equally short paths (exact ties only) the first in the order the paths
+//    were given;
+//  - block path_blocks: where each receiver's paths start in receiver order (running sum of the counts);
+//  - the blocks after it: the tree look-up of the lines of sight (whose list the first pass has made), a line at a time.
+__global__ __launch_bounds__(1024) void k_fields_pass2(SceneView sc, PathArrays pa, d3 tx, const double *__restrict__ rx,
+                                                        const unsigned long long *__restrict__ best_len,
+                                                        unsigned long long *best_idx, const int32_t *__restrict__ rx_counts,
+                                                        int64_t n_rx, int64_t *__restrict__ rx_off,
+                                                        const int32_t *__restrict__ los_list, const unsigned long long *los_count,
+                                                        TreeHits *__restrict__ los_trees, int path_blocks) {
+    if ((int)blockIdx.x < path_blocks) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= pa.n) return;
+        if ((unsigned long long)__double_as_longlong(path_key_length(pa, i, tx, rx)) == best_len[pa.rx[i]])
+            atomicMin(&best_idx[pa.rx[i]], (unsigned long long)i);
+    } else if ((int)blockIdx.x == path_blocks) {
+        __shared__ long long part[1024];
+        __shared__ long long carry;
+        if (threadIdx.x == 0) carry = 0;
+        __syncthreads();
+        for (int64_t base = 0; base < n_rx; base += 1024) {
+            const int64_t r = base + threadIdx.x;
+            const long long v = r < n_rx ? rx_counts[r] : 0;
+            part[threadIdx.x] = v;
+            __syncthreads();
+            for (int o = 1; o < 1024; o <<= 1) {
+                const long long add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+                __syncthreads();
+                part[threadIdx.x] += add;
+                __syncthreads();
+            }
+            if (r < n_rx) rx_off[r] = carry + part[threadIdx.x] - v;
+            __syncthreads();
+            if (threadIdx.x == 0) carry += part[1023];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) rx_off[n_rx] = carry;
+    } else if (!pa.e_in) {
+        los_tree_hits<16>(sc, pa, tx, rx, los_list, los_count, los_trees, (int64_t)blockIdx.x - path_blocks - 1,
+                          (int64_t)gridDim.x - path_blocks - 1);
+    }
 }
 
+// Per-receiver power: the powers of a receiver's paths added in the order of the reference's table (line of sight,
+// reflections by order and chain, diffractions by order, chain and edge; electromagnetism.py:776-778), whatever order
+// the paths arrive in: the same map gives the same dB to the last bit on every run and every split over GPUs.
+// What the reference's row order looks at, per path, in the order it looks at it: kind (0 line of sight, 1.. reflections,
+// 256.. diffractions by the reflections before them), the reflecting polygons, the edge's two polygons, and the path's
+// own index last.  Entries a kind does not have are zero, so that the order is the lexicographic order of the eight.
+struct __attribute__((aligned(16))) PathKey {
+    unsigned long long w[4];  // the eight in pairs, the earlier one in the upper half: (kind, chain 0), (chain 1, chain 2),
+                              // (chain 3, edge 0), (edge 1, index); none of them is negative
+    __device__ inline int32_t index() const { return (int32_t)(w[3] & 0xffffffffull); }
+};
+static_assert(RT_MAX_ORDER == 4, "PathKey holds kind, four chain entries, two edge polygons and the index");
+// The keys of path i put among its receiver's (in the order the threads happen to arrive).
+__device__ inline void rx_path_fill(const PathArrays &pa, int64_t i, const int64_t *__restrict__ off, int32_t *cursor,
+                                    PathKey *__restrict__ keys) {
+    if (i >= pa.n) return;
+    const int r = pa.rx[i];
+    const int64_t slot = off[r] + atomicAdd(&cursor[r], 1);
+    const int kind = pa.kind[i], n_refl = kind & 255;
+    unsigned v[8];
+    v[0] = (unsigned)kind;
+    for (int k = 0; k < RT_MAX_ORDER; ++k) v[1 + k] = k < n_refl ? (unsigned)pa.chain[(size_t)i * RT_MAX_ORDER + k] : 0u;
+    for (int k = 0; k < 2; ++k) v[5 + k] = (kind >> 8) ? (unsigned)pa.edge_polys[2 * (size_t)i + k] : 0u;
+    v[7] = (unsigned)i;
+    PathKey key;
+    for (int k = 0; k < 4; ++k) key.w[k] = ((unsigned long long)v[2 * k] << 32) | v[2 * k + 1];
+    keys[slot] = key;
+}
+// lexicographic order of the eight, without branches (the index, last, makes it a strict order)
+__device__ inline bool key_before(const PathKey &a, const PathKey &b) {
+    bool before = a.w[3] < b.w[3];
+    before = (a.w[2] < b.w[2]) | ((a.w[2] == b.w[2]) & before);
+    before = (a.w[1] < b.w[1]) | ((a.w[1] == b.w[1]) & before);
+    before = (a.w[0] < b.w[0]) | ((a.w[0] == b.w[0]) & before);
+    return before;
+}
 struct FieldOut {
     double *field;    // [n_paths * n_freq * 6]
     double *power;    // [n_paths * n_freq]
@@ -622,7 +688,7 @@ struct GeomIO {
     __device__ inline void skip(int slots) { at += (int64_t)slots * stride; }
 };
 
-// CLASS: 0 lines of sight, 1 reflections only, 2 paths ending with a diffraction (k_field_classes); a thread takes entry
+// CLASS: 0 lines of sight, 1 reflections only, 2 paths ending with a diffraction (k_fields_pass1); a thread takes entry
 // blockIdx.x * blockDim.x + threadIdx.x of its class's list, and in the modes with a thread per (path, frequency)
 // blockIdx.y is the frequency.  In FIELDS_WHOLE what the path alone decides (antenna frames, angles, the geometry of
 // every interaction) is redone for every frequency; a sweep over several frequencies goes through FIELDS_GEOMETRY once
@@ -718,7 +784,7 @@ __device__ __forceinline__ void fields_of_path(const SceneView &sc, const PathAr
         const double fac = tree_factor(sc, P[from], P[to], ft.freq[f], st, p_begin);
         E = c3{cscale(fac, E.x), cscale(fac, E.y), cscale(fac, E.z)};
     };
-    if (CLASS == 0 && !pa.e_in && MODE != FIELDS_GEOMETRY) {  // electromagnetism.py:669: every polygon of the scene, found by k_los_trees
+    if (CLASS == 0 && !pa.e_in && MODE != FIELDS_GEOMETRY) {  // electromagnetism.py:669: every polygon of the scene, found by los_tree_hits
         const TreeHits h = los_trees[j];
         if (h.concave && st == ST_OK) st = ST_CONCAVE;
         const double fac = tree_factor_of(h, ft.freq[f]);
@@ -783,11 +849,12 @@ __device__ __forceinline__ void fields_of_path(const SceneView &sc, const PathAr
 // The three classes in one launch, side by side: blockIdx.z is the class (lists[c * n] with counts[c]); the grid is sized
 // for the whole batch per class and the blocks past the end of a list leave at once.
 //   FIELDS_WHOLE      grid (entries / 128, frequencies, 3)
-//   FIELDS_GEOMETRY   grid (entries / 128 or more, parts of a path's geometry, 3); for the lines of sight the tree look-up
-//                     is done instead, a workgroup per line
+//   FIELDS_GEOMETRY   grid (entries / 128, parts of a path's geometry, 3); nothing to do for the lines of sight
 //   FIELDS_FREQUENCY  grid (entries / (128 / frequencies), 1, 3): the frequencies of a path are neighbouring lanes, so a
 //                     wave reads the geometry of its nine or so paths once instead of once per frequency and writes each
 //                     path's fields as one run of bytes; the lines of sight go through FIELDS_WHOLE here
+// With a fourth slice in z (FIELDS_WHOLE, FIELDS_FREQUENCY) the keys of the paths are put in receiver order beside the
+// fields (rx_path_fill), a thread per path.
 #define FIELDS_GEOMETRY_PARTS (RT_MAX_ORDER + 2)
 template <int MODE>
 __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, FreqTable ft, rt_antenna_params ap, d3 tx,
@@ -795,8 +862,13 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
                                                  const unsigned long long *__restrict__ best_idx,
                                                  const int32_t *__restrict__ lists, const unsigned long long *counts,
                                                  TreeHits *__restrict__ los_trees, FieldOut out, double *geom,
-                                                 int64_t geom_stride) {
+                                                 int64_t geom_stride, const int64_t *__restrict__ rx_off, int32_t *rx_cursor,
+                                                 PathKey *__restrict__ rx_keys) {
     const int cls = blockIdx.z;
+    if (cls == 3) {  // (not in the FIELDS_GEOMETRY launch) beside the fields: the paths' keys in receiver order
+        if (blockIdx.y == 0) rx_path_fill(pa, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, rx_off, rx_cursor, rx_keys);
+        return;
+    }
     const int32_t *list = lists + (size_t)cls * pa.n;
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int f_or_part = blockIdx.y;
@@ -807,11 +879,7 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
         j = (int64_t)blockIdx.x * per_block + local;
     }
     if (cls == 0) {
-        if (MODE == FIELDS_GEOMETRY) {
-            if (!pa.e_in)
-                los_tree_hits<2>(sc, pa, tx, rx, list, counts, los_trees, (int64_t)blockIdx.y * gridDim.x + blockIdx.x,
-                                 (int64_t)gridDim.x * gridDim.y);
-        } else {
+        if (MODE != FIELDS_GEOMETRY) {
             fields_of_path<0, FIELDS_WHOLE>(sc, pa, ft, ap, tx, rx, best_idx, list, counts, los_trees, out, geom, geom_stride, j,
                                             f_or_part);
         }
@@ -822,104 +890,77 @@ __global__ __launch_bounds__(128) void k_fields(SceneView sc, PathArrays pa, Fre
     }
 }
 
-// Per-receiver power: the powers of a receiver's paths added in the order of the reference's table (line of sight,
-// reflections by order and chain, diffractions by order, chain and edge; electromagnetism.py:776-778), whatever order
-// the paths arrive in: the same map gives the same dB to the last bit on every run and every split over GPUs.
-__global__ void k_rx_path_count(PathArrays pa, int32_t *__restrict__ counts) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < pa.n) atomicAdd(&counts[pa.rx[i]], 1);
-}
-__global__ __launch_bounds__(1024) void k_rx_offsets(const int32_t *__restrict__ counts, int64_t n_rx, int64_t *__restrict__ off) {
-    __shared__ long long part[1024];
-    __shared__ long long carry;
-    if (threadIdx.x == 0) carry = 0;
+#define STATUS_UNSET 0x7f7f7f7f /* what hipMemset(0x7f) leaves: larger than any (frequency, status) key */
+// Place of every path among its receiver's paths in the reference's row order: a thread per path counts the keys before
+// its own (a receiver has a handful to a few hundred paths).  Threads go by the place in the filled list, so a workgroup
+// holds runs of paths of the same receivers and the keys it has to look at are one stretch of the list, from the first
+// key of its first thread's receiver to the last key of its last thread's: staged through LDS a tile at a time, every
+// thread reading the part of the tile that belongs to its receiver.  (Each thread reading its receiver's keys from
+// memory, one after the other, waited for memory at every key: 88 us for 72 000 paths.)
+// The blocks after rank_blocks turn each path's smallest (frequency, status) key into its status.
+#define RANK_TILE 256
+__global__ __launch_bounds__(RANK_TILE) void k_rx_path_rank(PathArrays pa, const int64_t *__restrict__ off,
+                                                             const PathKey *__restrict__ keys, int32_t *__restrict__ ordered,
+                                                             int32_t *__restrict__ status, int rank_blocks) {
+    if ((int)blockIdx.x >= rank_blocks) {
+        const int64_t i = (int64_t)(blockIdx.x - rank_blocks) * blockDim.x + threadIdx.x;
+        if (i >= pa.n) return;
+        const int32_t key = status[i];
+        status[i] = key == STATUS_UNSET ? ST_OK : (key & 255);
+        return;
+    }
+    __shared__ PathKey s_keys[RANK_TILE];
+    __shared__ int64_t s_span[2];
+    const int64_t t = (int64_t)blockIdx.x * RANK_TILE + threadIdx.x;
+    const bool live = t < pa.n;
+    PathKey mine{};
+    int64_t b = 0, e = 0;
+    if (live) {
+        mine = keys[t];
+        const int r = pa.rx[mine.index()];
+        b = off[r];
+        e = off[r + 1];
+    }
+    const int64_t last = (pa.n - 1 < (int64_t)blockIdx.x * RANK_TILE + RANK_TILE - 1) ? pa.n - 1 : (int64_t)blockIdx.x * RANK_TILE + RANK_TILE - 1;
+    if (threadIdx.x == 0) s_span[0] = b;
+    if (t == last) s_span[1] = e;
     __syncthreads();
-    for (int64_t base = 0; base < n_rx; base += 1024) {
-        const int64_t r = base + threadIdx.x;
-        const long long v = r < n_rx ? counts[r] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const long long add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (r < n_rx) off[r] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += part[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) off[n_rx] = carry;
-}
-// What the reference's row order looks at, per path, in the order it looks at it: kind (0 line of sight, 1.. reflections,
-// 256.. diffractions by the reflections before them), the reflecting polygons, the edge's two polygons, and the path's
-// own index last.  Entries a kind does not have are zero, so that the order is the lexicographic order of the eight.
-struct PathKey {
-    int32_t v[8];
-};
-static_assert(RT_MAX_ORDER == 4, "PathKey holds kind, four chain entries, two edge polygons and the index");
-__global__ void k_rx_path_fill(PathArrays pa, const int64_t *__restrict__ off, int32_t *__restrict__ cursor,
-                               int32_t *__restrict__ order, PathKey *__restrict__ keys) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pa.n) return;
-    const int r = pa.rx[i];
-    const int64_t slot = off[r] + atomicAdd(&cursor[r], 1);
-    order[slot] = (int32_t)i;
-    PathKey key;
-    const int kind = pa.kind[i], n_refl = kind & 255;
-    key.v[0] = kind;
-    for (int k = 0; k < RT_MAX_ORDER; ++k) key.v[1 + k] = k < n_refl ? pa.chain[(size_t)i * RT_MAX_ORDER + k] : 0;
-    for (int k = 0; k < 2; ++k) key.v[5 + k] = (kind >> 8) ? pa.edge_polys[2 * (size_t)i + k] : 0;
-    key.v[7] = (int32_t)i;
-    keys[slot] = key;
-}
-__device__ inline bool key_before(const PathKey &a, const PathKey &b) {
-    for (int k = 0; k < 7; ++k)
-        if (a.v[k] != b.v[k]) return a.v[k] < b.v[k];
-    return a.v[7] < b.v[7];
-}
-// place of every path among its receiver's paths in that order: one thread per path counts the paths before it (a
-// receiver has a handful to a few hundred), instead of one thread per receiver sorting its list.  Threads go by the
-// place in the unordered list, so that neighbouring lanes are paths of the same receiver and read the same keys, which
-// lie one after the other (reading kind, chain and edge of the other path through its index took three times as long).
-__global__ void k_rx_path_rank(PathArrays pa, const int64_t *__restrict__ off, const PathKey *__restrict__ keys,
-                               int32_t *__restrict__ ordered) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= pa.n) return;
-    const PathKey mine = keys[t];
-    const int r = pa.rx[mine.v[7]];
-    const int64_t b = off[r], e = off[r + 1];
+    const int64_t lo = s_span[0], hi = s_span[1];
     int rank = 0;
-    for (int64_t q = b; q < e; ++q) {
-        const PathKey other = keys[q];
-        if (key_before(other, mine)) ++rank;
+    for (int64_t base = lo; base < hi; base += RANK_TILE) {
+        if (base + threadIdx.x < hi) s_keys[threadIdx.x] = keys[base + threadIdx.x];
+        __syncthreads();
+        const int64_t from = b > base ? b : base, to = e < base + RANK_TILE ? e : base + RANK_TILE;
+        int64_t q = from;
+        for (; q + 4 <= to; q += 4) {  // four keys fetched together
+            const PathKey k0 = s_keys[q - base], k1 = s_keys[q - base + 1], k2 = s_keys[q - base + 2], k3 = s_keys[q - base + 3];
+            rank += (int)key_before(k0, mine) + (int)key_before(k1, mine) + (int)key_before(k2, mine) + (int)key_before(k3, mine);
+        }
+        for (; q < to; ++q) rank += (int)key_before(s_keys[q - base], mine);
+        __syncthreads();
     }
-    ordered[b + rank] = mine.v[7];
+    if (live) ordered[b + rank] = mine.index();
 }
-// Sum of the powers of a receiver's paths in row order (the order fixes the rounding): one wave per receiver, the lanes
-// fetch 64 powers at once, the additions go one after the other on values handed round from lane to lane.
-__global__ __launch_bounds__(256) void k_rx_power_sum(const int64_t *__restrict__ off, const int32_t *__restrict__ ordered,
-                                                       int64_t n_rx, int n_freq, const double *__restrict__ power,
-                                                       double *__restrict__ power_sum) {
+// Sum of the powers of a receiver's paths in row order (the order fixes the rounding), and the receiver's dB per
+// frequency (electromagnetism_utils.py:180-188): a wave per receiver, lanes = (path of a stretch, frequency), a stretch of
+// 64 / n_freq paths fetched at once, the additions one after the other on values handed from lane to lane.
+__global__ __launch_bounds__(256) void k_rx_power_db(const int64_t *__restrict__ off, const int32_t *__restrict__ ordered,
+                                                      int64_t n_rx, int n_freq, const double *__restrict__ power, double p_in,
+                                                      double *__restrict__ db) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rx) return;  // (whole waves leave)
     const int64_t b = off[r], e = off[r + 1];
-    for (int f = 0; f < n_freq; ++f) {
-        double sum = 0.0;
-        for (int64_t base = b; base < e; base += 64) {
-            const int cnt = (int)(e - base < 64 ? e - base : 64);
-            const double v = lane < cnt ? power[(size_t)ordered[base + lane] * n_freq + f] : 0.0;
-            const int v_lo = __double2loint(v), v_hi = __double2hiint(v);
-            for (int q = 0; q < cnt; ++q)
-                sum += __hiloint2double(__builtin_amdgcn_readlane(v_hi, q), __builtin_amdgcn_readlane(v_lo, q));
-        }
-        if (lane == 0) power_sum[r * n_freq + f] = sum;
+    const int per_stretch = 64 / n_freq, slot = lane / n_freq, f = lane - slot * n_freq;
+    double sum = 0.0;
+    for (int64_t base = b; base < e; base += per_stretch) {
+        const int cnt = (int)(e - base < per_stretch ? e - base : per_stretch);
+        const double v = slot < cnt ? power[(size_t)ordered[base + slot] * n_freq + f] : 0.0;
+        for (int q = 0; q < cnt; ++q) sum += __shfl(v, q * n_freq + f);
     }
+    if (lane < n_freq) db[r * n_freq + lane] = sum != 0 ? 10 * log10(sum / p_in) : -INFINITY;
 }
 
-#define STATUS_UNSET 0x7f7f7f7f /* what hipMemset(0x7f) leaves: larger than any (frequency, status) key */
 // Start values of the field step's accumulators: power sums, per-receiver counts and class counts zero, the shortest
 // lengths and their indices all ones, every status "not computed" (bytes 0x7f).
 __global__ void k_fields_start(double *__restrict__ power_sum, int64_t n_sum, unsigned long long *__restrict__ best_len,
@@ -934,13 +975,6 @@ __global__ void k_fields_start(double *__restrict__ power_sum, int64_t n_sum, un
     for (int64_t i = first; i < 2 * n_rx; i += stride) rx_counts[i] = 0;
     for (int64_t i = first; i < n_paths; i += stride) status[i] = 0x7f7f7f7f;
     if (first < 3) cls_counts[first] = 0;
-}
-
-__global__ void k_status_final(int32_t *__restrict__ status, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t key = status[i];
-    status[i] = key == STATUS_UNSET ? ST_OK : (key & 255);
 }
 
 __global__ void k_power_db(const double *__restrict__ sum, int64_t n, double p_in, double *__restrict__ db) {
@@ -1226,7 +1260,7 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
     // per-receiver path lists (counts and cursors, offsets, the paths in receiver order), class lists, tree hits
     int32_t *rx_counts = (int32_t *)dalloc(sizeof(int32_t) * 2 * n_rx);
     int64_t *rx_off = (int64_t *)dalloc(sizeof(int64_t) * (n_rx + 1));
-    int32_t *rx_order = (int32_t *)dalloc(sizeof(int32_t) * 2 * np_);  // as filled, then in the reference's order
+    int32_t *rx_order = (int32_t *)dalloc(sizeof(int32_t) * np_);  // the paths in the reference's order (long lists only)
     PathKey *rx_keys = (PathKey *)dalloc(sizeof(PathKey) * np_);
     int32_t *cls_lists = (int32_t *)dalloc(sizeof(int32_t) * 3 * np_);
     TreeHits *los_trees = (TreeHits *)dalloc(sizeof(TreeHits) * np_);
@@ -1248,42 +1282,43 @@ extern "C" int rt_fields(rt_scene *scene, const double *tx, const double *rx, in
     }
     const d3 TX = ld3(tx);
     if (n_paths > 0) {
-        const unsigned grid = (unsigned)((n_paths + 255) / 256);
-        hipLaunchKernelGGL(k_best_length, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len);
-        hipLaunchKernelGGL(k_best_index, dim3(grid), dim3(256), 0, st, pa, TX, d_rx, best_len, best_idx);
-        hipLaunchKernelGGL(k_field_classes, dim3(grid), dim3(256), 0, st, pa, cls_lists, cls_counts);
+        // six or seven launches: start values; classes, shortest lengths and counts; shortest paths, offsets and the
+        // lines of sight's trees; (a sweep: geometry;) fields and keys; places and statuses; sums and dB
+        hipLaunchKernelGGL(k_fields_pass1, dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, st, pa, TX, d_rx, best_len,
+                           cls_lists, cls_counts, rx_counts);
         if (ev[1]) F_HIP(hipEventRecord(ev[1], st));
+        const int path_blocks = (int)((n_paths + 1023) / 1024);
+        const int los_blocks = pa.e_in ? 0 : (int)std::min<int64_t>(n_rx, 2048);  // (a receiver has one line of sight at most)
+        hipLaunchKernelGGL(k_fields_pass2, dim3((unsigned)(path_blocks + 1 + los_blocks)), dim3(1024), 0, st, scene->view, pa, TX,
+                           d_rx, best_len, best_idx, rx_counts, (int64_t)n_rx, rx_off, cls_lists, cls_counts, los_trees,
+                           path_blocks);
         // the class kernels read their list's length on the device: the grids are sized for the whole batch and the
         // blocks past the end of a list leave at once
         const unsigned fblocks = (unsigned)((n_paths + 127) / 128);
         if (geom) {
-            // a sweep: the geometry of every path once (and the tree look-up of the lines of sight beside it), then a
-            // thread per (path, frequency) for what the frequency decides
-            // (at least 1 024 x parts workgroups, so that the lines of sight of a small batch get a workgroup each)
-            hipLaunchKernelGGL(k_fields<FIELDS_GEOMETRY>, dim3(std::max(fblocks, 1024u), FIELDS_GEOMETRY_PARTS, 3), dim3(128), 0, st, scene->view,
-                               pa, ft, *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, geom, (int64_t)np_);
+            // a sweep: the geometry of every path once, then a thread per (path, frequency) for what the frequency decides
+            hipLaunchKernelGGL(k_fields<FIELDS_GEOMETRY>, dim3(fblocks, FIELDS_GEOMETRY_PARTS, 3), dim3(128), 0, st, scene->view,
+                               pa, ft, *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, geom, (int64_t)np_,
+                               rx_off, rx_counts + n_rx, rx_keys);
             const int64_t per_block = 128 / n_freq;
-            hipLaunchKernelGGL(k_fields<FIELDS_FREQUENCY>, dim3((unsigned)((n_paths + per_block - 1) / per_block), 1, 3), dim3(128), 0, st, scene->view, pa,
-                               ft, *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, geom, (int64_t)np_);
+            hipLaunchKernelGGL(k_fields<FIELDS_FREQUENCY>, dim3((unsigned)((n_paths + per_block - 1) / per_block), 1, 4), dim3(128),
+                               0, st, scene->view, pa, ft, *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, geom,
+                               (int64_t)np_, rx_off, rx_counts + n_rx, rx_keys);
         } else {
-            if (!pa.e_in)
-                hipLaunchKernelGGL(k_los_trees, dim3((unsigned)std::min<int64_t>((int64_t)n_paths, 4096)), dim3(256), 0, st,
-                                   scene->view, pa, TX, d_rx, cls_lists, cls_counts, los_trees);
-            hipLaunchKernelGGL(k_fields<FIELDS_WHOLE>, dim3(fblocks, (unsigned)n_freq, 3), dim3(128), 0, st, scene->view, pa, ft,
-                               *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, (double *)nullptr, (int64_t)0);
+            hipLaunchKernelGGL(k_fields<FIELDS_WHOLE>, dim3(fblocks, (unsigned)n_freq, 4), dim3(128), 0, st, scene->view, pa, ft,
+                               *antenna, TX, d_rx, best_idx, cls_lists, cls_counts, los_trees, fo, (double *)nullptr, (int64_t)0,
+                               rx_off, rx_counts + n_rx, rx_keys);
         }
         if (ev[2]) F_HIP(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_status_final, dim3(grid), dim3(256), 0, st, fo.status, (int64_t)n_paths);
-        hipLaunchKernelGGL(k_rx_path_count, dim3(grid), dim3(256), 0, st, pa, rx_counts);
-        hipLaunchKernelGGL(k_rx_offsets, dim3(1), dim3(1024), 0, st, rx_counts, (int64_t)n_rx, rx_off);
-        hipLaunchKernelGGL(k_rx_path_fill, dim3(grid), dim3(256), 0, st, pa, rx_off, rx_counts + n_rx, rx_order,
-                           rx_keys);
-        hipLaunchKernelGGL(k_rx_path_rank, dim3(grid), dim3(256), 0, st, pa, rx_off, rx_keys, rx_order + np_);
-        hipLaunchKernelGGL(k_rx_power_sum, dim3((unsigned)((n_rx + 3) / 4)), dim3(256), 0, st, rx_off, rx_order + np_,
-                           (int64_t)n_rx, n_freq, fo.power, fo.power_sum);
+        const int rank_blocks = (int)((n_paths + RANK_TILE - 1) / RANK_TILE);
+        hipLaunchKernelGGL(k_rx_path_rank, dim3((unsigned)(2 * rank_blocks)), dim3(RANK_TILE), 0, st, pa, rx_off, rx_keys, rx_order,
+                           fo.status, rank_blocks);
+        hipLaunchKernelGGL(k_rx_power_db, dim3((unsigned)((n_rx + 3) / 4)), dim3(256), 0, st, rx_off, rx_order, (int64_t)n_rx,
+                           n_freq, fo.power, antenna->p_in, d_db);
+    } else {
+        hipLaunchKernelGGL(k_power_db, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, fo.power_sum,
+                           (int64_t)(n_rx * nf), antenna->p_in, d_db);
     }
-    hipLaunchKernelGGL(k_power_db, dim3((unsigned)((n_rx * nf + 255) / 256)), dim3(256), 0, st, fo.power_sum,
-                       (int64_t)(n_rx * nf), antenna->p_in, d_db);
     F_HIP(hipGetLastError());
     if (!on_device) {
         if (n_paths) {
