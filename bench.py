@@ -158,11 +158,12 @@ def cpu_baseline(place, tx, rx, cand, budget_s=5.0, receivers_per_core=2, per_re
 # ---------------------------------------------------------------------------------------------------------------
 # kernels whose counters make up a family of the step (names without template arguments, as scripts/counters_json.py keys them)
 FAMILY_KERNELS = {
-    "reflect": ("k_reflect_tiled", "k_reflect", "k_rx_count", "k_rx_scatter", "k_rx_boxes"),
+    # (k_rx_hints runs on the side stream beside the reflection kernel: its work falls into that kernel's time)
+    "reflect": ("k_reflect_tiled", "k_reflect", "k_rx_count", "k_rx_scatter", "k_rx_boxes", "k_rx_hints"),
     "diffract": ("k_diffract", "k_diffract_setup", "k_rd_prepare", "k_rd_filter"),
     "obstruct": ("k_obstruct_grid", "k_obstruct", "k_list_clear_flags"),
     "rejudge": ("k_rejudge_solve", "k_rejudge_solve_late", "k_rejudge_classify", "k_rejudge_scatter", "k_rejudge_copy_back"),
-    "fields": ("k_fields",),
+    "fields": ("k_fields", "k_fields_pass2"),
 }
 
 
