@@ -1,4 +1,4 @@
-"""Step time of the lln map for several receiver counts (not a test): python scripts/size_probe.py 60 71 80 100"""
+"""Step time of the lln map for several receiver counts (not a test): python scripts/size_probe.py [reference] 60 71 80 100/8/3"""
 import sys
 import time
 
@@ -17,7 +17,11 @@ cube = geom.Cube.by_point_and_side_length(tx, 0.2)
 vis, screens = scene.visibility_with_faces([(s.points, s.get_parametric(), -1) for s in cube.polygons])
 cand = scene.enumerate(vis, np.logical_or.reduce(screens), pairs, edges, 2, with_diffraction=True)
 scene.set_timing(True)
-for arg in sys.argv[1:]:
+args = sys.argv[1:]
+if args and args[0] == "reference":  # the reference-compatible mode (every found path re-judged by the reference's solver)
+    scene.set_reference_solver(True)
+    args = args[1:]
+for arg in args:
     # "71": a 71 x 71 map; "100/8": the first of eight contiguous blocks of the 100 x 100 map (one rank of eight)
     parts = arg.split("/")
     n_side = int(parts[0])
@@ -33,5 +37,6 @@ for arg in sys.argv[1:]:
         t0 = time.perf_counter()
         block = pipe.run(d_rx, [3.6e9], fields=False)
         out.append((round(1e3 * (time.perf_counter() - t0), 2),) + tuple(round(float(block.solve_timing["ms"][k]), 2)
-                                                                         for k in ("reflect", "diffract", "obstruct", "finalize")))
-    print(arg, len(rx), "paths", block.n_paths, "(wall, reflect, diffract, obstruct, finalize ms) per step:", out[1:], flush=True)
+                                                                         for k in ("reflect", "diffract", "obstruct", "finalize")) +
+                   (round(float((block.solve_timing.get("rejudge") or {}).get("ms", 0.0)), 2),))
+    print(arg, len(rx), "paths", block.n_paths, "(wall, reflect, diffract, obstruct, finalize, rejudge ms) per step:", out[1:], flush=True)
