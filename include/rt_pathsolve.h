@@ -118,6 +118,11 @@ int rt_debug_set_occlusion_mode(rt_scene *scene, int mode);
  * with an interval form of its pre-test (mode 2); mode 0, the default, picks by batch size.  Same paths either way;
  * the switch exists so that tests can check one against the other (no reference counterpart). */
 int rt_debug_set_reflect_mode(rt_scene *scene, int mode);
+/* In a large batch the diffraction kernel tries each pair's last segment on the wall that stands next to the receiver in
+ * the segment's direction before it queues the pair (on = 1, the default), or queues every pair for the obstruction
+ * walk (on = 0).  Same paths either way; the switch exists so that tests can check one against the other (no reference
+ * counterpart). */
+int rt_debug_set_wall_hints(rt_scene *scene, int on);
 /* First size of the solve's path queue in records (0 = chosen from the batch).  A queue that turns out too small is
  * grown and the chunk redone; the switch exists so that tests can take that route (no reference counterpart). */
 int rt_debug_set_path_queue_capacity(rt_scene *scene, int64_t n_paths);

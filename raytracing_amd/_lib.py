@@ -54,6 +54,7 @@ _SIGNATURES = {
     "rt_debug_set_stored_chain_limit": (c_int, [c_void_p, c_int64]),
     "rt_scene_set_reference_solver": (c_int, [c_void_p, c_int]),
     "rt_debug_set_reflect_mode": (c_int, [c_void_p, c_int]),
+    "rt_debug_set_wall_hints": (c_int, [c_void_p, c_int]),
     "rt_debug_set_path_queue_capacity": (c_int, [c_void_p, c_int64]),
     "rt_visibility_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "rt_sharp_edges": (c_int, [c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -328,6 +329,10 @@ class Scene:
     def set_reflect_mode(self, mode):
         """0: reflection kernel chosen by batch size (default); 1: receivers one by one; 2: receivers in spatial tiles."""
         _check(load().rt_debug_set_reflect_mode(self.handle, int(mode)), "rt_debug_set_reflect_mode")
+
+    def set_wall_hints(self, on):
+        """Wall hints around the receivers for the diffraction kernel of a large batch: on (default) or off."""
+        _check(load().rt_debug_set_wall_hints(self.handle, int(bool(on))), "rt_debug_set_wall_hints")
 
     def wait_for_stream(self, stream_handle):
         """Orders the scene's stream after what is queued on the caller's stream (a hipStream_t as an integer, e.g.

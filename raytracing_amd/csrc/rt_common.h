@@ -133,6 +133,7 @@ struct rt_scene {
     size_t events_used = 0;
     bool timing = true;  // per-kernel-family events around the launches of a solve
     int reflect_mode = 0;  // 0 by batch size, 1 receivers one by one, 2 receivers in spatial tiles
+    int wall_hints = 1;    // 1: the diffraction kernel of a large batch uses wall hints around the receivers (default), 0: never
     bool counters_dirty = true;  // d_counters[0..3] may be non-zero (first solve, or a solve that failed half-way)
     int64_t hint_paths = 0, hint_segments = 0, hint_clear = 0;
     int32_t *late_items = nullptr;  // items handed from the first to the second obstruction pass (grows on demand)

@@ -202,6 +202,12 @@ extern "C" int rt_debug_set_reflect_mode(rt_scene *s, int mode) {
     return 0;
 }
 
+extern "C" int rt_debug_set_wall_hints(rt_scene *s, int on) {
+    if (!s || on < 0 || on > 1) RT_FAIL("rt_debug_set_wall_hints: bad argument");
+    s->wall_hints = on;
+    return 0;
+}
+
 extern "C" int rt_debug_set_stored_chain_limit(rt_scene *s, int64_t bytes) {
     if (!s || bytes < 0) RT_FAIL("rt_debug_set_stored_chain_limit: bad argument");
     s->stored_chain_bytes_limit = bytes;

@@ -137,6 +137,29 @@ def test_frequency_sweep_matches_oracle():
         assert np.abs(res["power_db"][:, f] - want_db).max() <= DB_TOL
 
 
+def test_a_sweep_gives_what_the_frequencies_give_one_by_one():
+    """A call with several frequencies computes a path's geometry once and the frequency-dependent half per frequency
+    (FIELDS_GEOMETRY / FIELDS_FREQUENCY); a call with one frequency does both in one thread (FIELDS_WHOLE).  The halves
+    are the same arithmetic either way: fields equal to 1e-13 relative, the rest to the last bit or nearly."""
+    from raytracing_amd import electromagnetism as em
+
+    problem, oracle, polys, tx, rx, eo = _solved_small(4)
+    batch, _ = em.paths_of_problem(problem)
+    freqs = [3.5e9, 12.5e9, 28e9, 60e9]
+    sweep = batch.run(problem._device_scene(), tx, rx, freqs)
+    kinds = set(np.asarray(batch.kind).tolist()) if hasattr(batch, "kind") else None
+    assert kinds is None or (0 in kinds and any(k >= 256 for k in kinds) and any(0 < k < 256 for k in kinds))
+    for f, freq in enumerate(freqs):
+        one = batch.run(problem._device_scene(), tx, rx, [freq])
+        np.testing.assert_array_equal(one["status"], sweep["status"])
+        np.testing.assert_array_equal(one["angles"], sweep["angles"])
+        np.testing.assert_array_equal(one["time"], sweep["time"])
+        scale = np.abs(one["field"][:, 0]).max(axis=-1, keepdims=True) + 1e-300
+        assert (np.abs(one["field"][:, 0] - sweep["field"][:, f]) <= 1e-13 * scale).all()
+        np.testing.assert_allclose(one["power"][:, 0], sweep["power"][:, f], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(one["power_db"][:, 0], sweep["power_db"][:, f], rtol=0, atol=1e-10)
+
+
 def test_receiver_without_path_is_impossible(tmp_path, monkeypatch):
     from raytracing_amd import electromagnetism as em
     from raytracing_amd import geometry as geom

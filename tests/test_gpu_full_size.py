@@ -178,6 +178,31 @@ def test_large_batch_route_reports_what_the_small_batch_route_reports(lln_map):
     assert got == want  # same paths, same points bit for bit
 
 
+def test_wall_hints_change_no_path(lln_map):
+    """The diffraction kernel's wall hints (the wall next to every receiver in 256 directions, tried on a pair's last
+    segment before the pair is queued) are a short cut of the obstruction walk: with them switched off the same paths
+    come out, with the same points to the last bit."""
+    m = lln_map
+    scene, cand = m["scene"], m["cand"]
+    scene.set_wall_hints(False)
+    try:
+        bare = scene.solve_paths(cand, m["tx"], m["rx"])
+    finally:
+        scene.set_wall_hints(True)
+    with_hints = m["res"]
+    assert len(bare["rx"]) == len(with_hints["rx"]) > 100_000
+    for key in ("rx", "group", "cand", "points"):
+        np.testing.assert_array_equal(bare[key], with_hints[key], err_msg=key)
+    # and with them the obstruction walk has a fraction of the segments to look at
+    walked = {}
+    for on in (False, True):
+        scene.set_wall_hints(on)
+        scene.solve_paths(cand, m["tx"], m["rx"])
+        walked[on] = scene.last_timing()["segments"]
+    scene.set_wall_hints(True)
+    assert walked[True] < 0.4 * walked[False]
+
+
 def test_every_receiver_with_a_path_has_a_power_below_the_emitted(lln_map):
     m = lln_map
     fields = m["scene"].fields(m["tx"], m["rx"], m["res"]["rx"], m["kind"], m["chain"], m["epolys"], m["epts"],
