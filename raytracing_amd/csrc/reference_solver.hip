@@ -20,8 +20,9 @@
 
 #define REJ_MAX_GROUPS (2 * RT_MAX_ORDER)
 // evaluations after which the first pass hands a run to the second (on the lln map 97 in 100 runs of reflection +
-// diffraction systems end before, and the first pass lasts about 6 us per evaluation of its longest lane)
-#define REJ_FIRST_PASS_NFEV 96
+// diffraction systems end before 96; lln step with the hand-over at 32 / 96 / 160 / 256 / 512 evaluations: re-judging
+// 10.0 / 9.8 / 8.9 / 9.3 / 12.1 ms)
+#define REJ_FIRST_PASS_NFEV 160
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, int64_t n_masked,
                        uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_rejudge_classify(const int32_t *__restr
 // the path's record for the obstruction kernels (flag set = dropped).  Returns false when the solver ran into
 // nfev_limit (nothing is written then).  NR, HE: the shape of the group's systems as template arguments (the method
 // then runs in registers), or -1, -1.
-template <int NR, int HE>
+template <int NR, int HE, bool FLAT = false>
 __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSource &chains, const int32_t *__restrict__ edge_ids,
                                             int n_refl_rt, int has_edge_rt, const double *__restrict__ edges, d3 tx,
                                             const double *__restrict__ rx, const int32_t *__restrict__ p_rx,
@@ -136,7 +137,7 @@ __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSour
     double pts[3 * RT_MAX_ORDER];
     const int n_pts = n_refl + (has_edge ? 1 : 0);
     bool unfinished = false;
-    bool ok = rt_hybr::solve_shape<NR, HE>(origin, dest, planes, n_refl, has_edge ? edge : nullptr, pts, nullptr, nfev_limit,
+    bool ok = rt_hybr::solve_shape<NR, HE, FLAT>(origin, dest, planes, n_refl, has_edge ? edge : nullptr, pts, nullptr, nfev_limit,
                                            &unfinished);
     if (unfinished) return false;
     // The reference checks ITS solver's points (ray_tracing.py:310-313): they can sit a few 1e-7 m from the root the
@@ -182,8 +183,9 @@ __global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource 
     int64_t i = 0;
     if (k < (int64_t)*count) {
         i = list[k];
-        done = rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group,
-                                   nfev_limit, true, recs, flags);
+        // (the lanes of a wave run different systems: the method as one loop with an evaluation per trip, rt_hybr::hybr_flat)
+        done = rejudge_one<NR, HE, true>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group,
+                                         nfev_limit, true, recs, flags);
     }
     const unsigned long long m = __ballot(!done);
     if (m == 0ull) return;

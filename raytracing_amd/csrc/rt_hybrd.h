@@ -720,11 +720,193 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac, int nfev_limit =
     }
 }
 
+// hybrd again, as ONE loop with one evaluation of the zero function per trip: the same operations in the same order on
+// the same numbers as hybr above (finite-difference form, NC > 0), with the method's two nested loops turned into a
+// state -- `col` >= 0: the trip evaluates column `col` of a finite-difference Jacobian; -1: it evaluates a trial point.
+// For the lanes of a GPU wave that run different systems side by side: in the nested form a lane that needs a new
+// Jacobian waits until every other lane has left its inner loop, and the evaluations of lanes in different places
+// of the method go one after the other; here every trip evaluates for all lanes at once, and only the bookkeeping
+// between two evaluations (a third of the work) is taken in turns.
+template <int NR, int HE>
+RT_HD inline Result hybr_flat(System &sys, double *x, int nfev_limit = 0x7fffffff) {
+    constexpr int NC = 3 * NR + HE;
+    static_assert(NR >= 1 && NC >= 2, "the finite-difference form of a system whose shape is known at compile time");
+    const int n = NC;
+    const double xtol = 1.49012e-08, factor = 100.0;
+    const double p1 = 0.1, p5 = 0.5, p001 = 1e-3, p0001 = 1e-4;
+    const int maxfev = 200 * (n + 1);
+    double fvec[RT_HYBR_MAX_N], diag[RT_HYBR_MAX_N], qtf[RT_HYBR_MAX_N], wa1[RT_HYBR_MAX_N], wa2[RT_HYBR_MAX_N],
+        wa3[RT_HYBR_MAX_N], wa4[RT_HYBR_MAX_N];
+    double fjac[RT_HYBR_MAX_N * RT_HYBR_MAX_N], r[(RT_HYBR_MAX_N * (RT_HYBR_MAX_N + 1)) / 2];
+    Result res{0, 0};
+    evaluate<NR, HE>(sys, x, fvec, nullptr);
+    res.nfev = 1;
+    double fnorm = enorm(n, fvec);
+    int iter = 1, ncsuc = 0, ncfail = 0, nslow1 = 0, nslow2 = 0;
+    double delta = 0, xnorm = 0, pnorm = 0, h = 0;
+    const double eps = sqrt(RT_EPSMCH);
+    bool jeval = true, sing = false;
+    int col = 0;
+    RT_NOUNROLL
+    while (true) {
+        if (col >= 0) {  // the point of column col: x with its col-th component stepped
+            double temp = 0;
+            RT_UNROLL
+            for (int i = 0; i < n; ++i)
+                if (i == col) temp = x[i];
+            h = eps * fabs(temp);
+            if (h == 0) h = eps;
+            RT_UNROLL
+            for (int i = 0; i < n; ++i) wa2[i] = i == col ? temp + h : x[i];
+        }
+        evaluate<NR, HE>(sys, wa2, wa4, nullptr);
+        if (col >= 0) {
+            RT_UNROLL
+            for (int k = 0; k < n; ++k)
+                if (k == col) {
+                    RT_UNROLL
+                    for (int i = 0; i < n; ++i) A_(fjac, i, k) = (wa4[i] - fvec[i]) / h;
+                }
+            ++col;
+            if (col == n) {  // the Jacobian is complete: its QR factorisation and what hangs on it
+                res.nfev += n;
+                jeval = true;
+                qrfac<NC>(n, fjac, wa1, wa2, wa3);
+                if (iter == 1) {
+                    RT_UNROLL
+                    for (int j = 0; j < n; ++j) {
+                        diag[j] = wa2[j];
+                        if (wa2[j] == 0) diag[j] = 1;
+                    }
+                    RT_UNROLL
+                    for (int j = 0; j < n; ++j) wa3[j] = diag[j] * x[j];
+                    xnorm = enorm(n, wa3);
+                    delta = factor * xnorm;
+                    if (delta == 0) delta = factor;
+                }
+                RT_UNROLL
+                for (int i = 0; i < n; ++i) qtf[i] = fvec[i];
+                RT_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    if (A_(fjac, j, j) != 0) {
+                        double sum = 0;
+                        RT_UNROLL
+                        for (int i = j; i < n; ++i) sum += A_(fjac, i, j) * qtf[i];
+                        const double temp = -sum / A_(fjac, j, j);
+                        RT_UNROLL
+                        for (int i = j; i < n; ++i) qtf[i] += A_(fjac, i, j) * temp;
+                    }
+                }
+                sing = false;
+                RT_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    RT_UNROLL
+                    for (int i = 0; i < j; ++i) r[i * n - (i * (i - 1)) / 2 + (j - i)] = A_(fjac, i, j);
+                    r[j * n - (j * (j - 1)) / 2] = wa1[j];
+                    if (wa1[j] == 0) sing = true;
+                }
+                qform<NC>(n, fjac, wa1);
+                RT_UNROLL
+                for (int j = 0; j < n; ++j) diag[j] = fmax(diag[j], wa2[j]);
+                col = -1;
+            }
+        } else {  // wa4 = F(x + p): is the step any good?
+            ++res.nfev;
+            const double fnorm1 = enorm(n, wa4);
+            double actred = -1;
+            if (fnorm1 < fnorm) {
+                const double q = fnorm1 / fnorm;
+                actred = 1 - q * q;
+            }
+            RT_UNROLL
+            for (int i = 0; i < n; ++i) {
+                double sum = 0;
+                const int row = i * n - (i * (i - 1)) / 2;
+                RT_UNROLL
+                for (int j = i; j < n; ++j) sum += r[row + (j - i)] * wa1[j];
+                wa3[i] = qtf[i] + sum;
+            }
+            const double temp = enorm(n, wa3);
+            double prered = 0;
+            if (temp < fnorm) {
+                const double q = temp / fnorm;
+                prered = 1 - q * q;
+            }
+            double ratio = 0;
+            if (prered > 0) ratio = actred / prered;
+            if (ratio < p1) {
+                ncsuc = 0;
+                ++ncfail;
+                delta = p5 * delta;
+            } else {
+                ncfail = 0;
+                ++ncsuc;
+                if (ratio >= p5 || ncsuc > 1) delta = fmax(delta, pnorm / p5);
+                if (fabs(ratio - 1) <= p1) delta = pnorm / p5;
+            }
+            if (ratio >= p0001) {
+                RT_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    x[j] = wa2[j];
+                    wa2[j] = diag[j] * x[j];
+                    fvec[j] = wa4[j];
+                }
+                xnorm = enorm(n, wa2);
+                fnorm = fnorm1;
+                ++iter;
+            }
+            ++nslow1;
+            if (actred >= p001) nslow1 = 0;
+            if (jeval) ++nslow2;
+            if (actred >= p1) nslow2 = 0;
+            if (delta <= xtol * xnorm || fnorm == 0) res.info = 1;
+            if (res.info != 0) return res;
+            if (res.nfev >= nfev_limit) {
+                res.info = -1;
+                return res;
+            }
+            if (res.nfev >= maxfev) res.info = 2;
+            if (p1 * fmax(p1 * delta, pnorm) <= RT_EPSMCH * xnorm) res.info = 3;
+            if (nslow2 == 5) res.info = 4;
+            if (nslow1 == 10) res.info = 5;
+            if (res.info != 0) return res;
+            if (ncfail == 2) {
+                col = 0;  // a new Jacobian
+            } else {
+                RT_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    double sum = 0;
+                    RT_UNROLL
+                    for (int i = 0; i < n; ++i) sum += A_(fjac, i, j) * wa4[i];
+                    wa2[j] = (sum - wa3[j]) / pnorm;
+                    wa1[j] = diag[j] * ((diag[j] * wa1[j]) / pnorm);
+                    if (ratio >= p0001) qtf[j] = sum;
+                }
+                r1updt<NC>(n, r, wa1, wa2, wa3, &sing);
+                r1mpyq_both<NC>(n, fjac, qtf, wa2, wa3);
+                jeval = false;
+            }
+        }
+        if (col < 0) {  // the next trip tries a step: the dogleg step p, x + p in wa2
+            dogleg<NC>(n, r, diag, qtf, delta, wa1, wa2, wa3);
+            RT_UNROLL
+            for (int j = 0; j < n; ++j) {
+                wa1[j] = -wa1[j];
+                wa2[j] = x[j] + wa1[j];
+                wa3[j] = diag[j] * wa1[j];
+            }
+            pnorm = enorm(n, wa3);
+            if (iter == 1) delta = fmin(delta, pnorm);
+        }
+    }
+}
+
 // What the reference's solver call returns for one candidate: the solver's points (n_refl reflection points, then the
 // diffraction point) and whether SciPy would report success.  NR, HE: the shape of the system as template arguments
 // (n_refl and edge must agree with them), or -1, -1.
 // nfev_limit / unfinished: see hybr.
-template <int NR, int HE>
+// FLAT: through hybr_flat where the system has a finite-difference Jacobian and a shape known at compile time.
+template <int NR, int HE, bool FLAT = false>
 RT_HD inline bool solve_shape(const double *origin, const double *destination, const double *planes, int n_refl_rt,
                               const double *edge, double *out_points, int *nfev, int nfev_limit = 0x7fffffff,
                               bool *unfinished = nullptr) {
@@ -732,7 +914,11 @@ RT_HD inline bool solve_shape(const double *origin, const double *destination, c
     System sys;
     double x[RT_HYBR_MAX_N];
     setup<NR>(sys, origin, destination, planes, n_refl, edge, x);
-    const Result res = hybr<NR, HE>(sys, x, n_refl == 0, nfev_limit);
+    Result res;
+    if constexpr (FLAT && NR >= 1)
+        res = hybr_flat<NR, HE>(sys, x, nfev_limit);
+    else
+        res = hybr<NR, HE>(sys, x, n_refl == 0, nfev_limit);
     if (nfev) *nfev = res.nfev;
     if (unfinished) *unfinished = res.info < 0;
     RT_UNROLL
@@ -759,6 +945,21 @@ RT_HD inline bool solve_like_reference(const double *origin, const double *desti
         if (n_refl == 3) return solve_shape<3, 0>(origin, destination, planes, 3, edge, out_points, nfev);
     }
     return solve_shape<-1, -1>(origin, destination, planes, n_refl, edge, out_points, nfev);
+}
+
+// the one-loop form of the unrolled shapes (held against SciPy in the CPU test like the others)
+RT_HD inline bool solve_like_reference_flat(const double *origin, const double *destination, const double *planes, int n_refl,
+                                            const double *edge, double *out_points, int *nfev) {
+    const int shape = n_refl * 2 + (edge ? 1 : 0);
+    switch (shape) {
+        case 2: return solve_shape<1, 0, true>(origin, destination, planes, n_refl, edge, out_points, nfev);
+        case 3: return solve_shape<1, 1, true>(origin, destination, planes, n_refl, edge, out_points, nfev);
+        case 4: return solve_shape<2, 0, true>(origin, destination, planes, n_refl, edge, out_points, nfev);
+        case 5: return solve_shape<2, 1, true>(origin, destination, planes, n_refl, edge, out_points, nfev);
+        case 6: return solve_shape<3, 0, true>(origin, destination, planes, n_refl, edge, out_points, nfev);
+        default: break;
+    }
+    return solve_like_reference(origin, destination, planes, n_refl, edge, out_points, nfev);
 }
 
 // the run-time form alone (what the unrolled forms are held against in the CPU test)

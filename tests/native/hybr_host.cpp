@@ -13,3 +13,9 @@ extern "C" int rt_hybr_host_solve_generic(const double *origin, const double *de
                                           const double *edge, double *out_points, int *nfev) {
     return rt_hybr::solve_like_reference_generic(origin, destination, planes, n_refl, edge, out_points, nfev) ? 1 : 0;
 }
+
+// the one-loop form (rt_hybr::hybr_flat) for the shapes that have one
+extern "C" int rt_hybr_host_solve_flat(const double *origin, const double *destination, const double *planes, int n_refl,
+                                       const double *edge, double *out_points, int *nfev) {
+    return rt_hybr::solve_like_reference_flat(origin, destination, planes, n_refl, edge, out_points, nfev) ? 1 : 0;
+}

@@ -23,10 +23,11 @@ def host_solver():
     if not os.path.exists(lib_path) or os.path.getmtime(lib_path) < max(os.path.getmtime(src), os.path.getmtime(header)):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", lib_path, src, "-lm"])
     lib = ctypes.CDLL(lib_path)
-    lib.rt_hybr_host_solve.restype = ctypes.c_int
-    lib.rt_hybr_host_solve.argtypes = [ctypes.c_void_p] * 7
+    for name in ("rt_hybr_host_solve", "rt_hybr_host_solve_flat"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = [ctypes.c_void_p] * 7
 
-    def solve(origin, destination, planes, edge):
+    def solve(origin, destination, planes, edge, entry="rt_hybr_host_solve"):
         a = np.ascontiguousarray(origin, dtype=float).reshape(3)
         b = np.ascontiguousarray(destination, dtype=float).reshape(3)
         k = len(planes)
@@ -34,8 +35,8 @@ def host_solver():
         e = None if edge is None else np.ascontiguousarray(edge, dtype=float).reshape(2, 3)
         out = np.zeros((k + (1 if e is not None else 0), 3))
         nfev = ctypes.c_int(0)
-        ok = lib.rt_hybr_host_solve(a.ctypes.data, b.ctypes.data, pl.ctypes.data, k, e.ctypes.data if e is not None else None,
-                                    out.ctypes.data, ctypes.byref(nfev))
+        ok = getattr(lib, entry)(a.ctypes.data, b.ctypes.data, pl.ctypes.data, k, e.ctypes.data if e is not None else None,
+                                 out.ctypes.data, ctypes.byref(nfev))
         return out, bool(ok), nfev.value
 
     return solve
@@ -59,6 +60,48 @@ def test_restatement_reproduces_scipy_on_the_reference_vectors(host_solver):
                 assert case["nfev"] == nfev + 2
             n += 1
     assert n == 154
+
+
+def test_the_one_loop_form_makes_the_same_runs(host_solver):
+    """rt_hybr::hybr_flat (the method's nested loops as one loop with an evaluation per trip, which is what the lanes of
+    a GPU wave run side by side) against the reference's vectors and against the nested form on random systems: same
+    points to the last bit, same verdict, same number of evaluations."""
+    with open(os.path.join(GOLDEN, "solvers.json")) as f:
+        cases = json.load(f)
+    planes = np.load(os.path.join(GOLDEN, "helpers.npz"))["cube_planes"]
+    n = 0
+    for kind in ("reflection", "mixed"):
+        for case in cases[kind]:
+            pl = [planes[f] for f in case.get("faces", [])]
+            edge = np.array(case["edge"]) if "edge" in case else None
+            x, ok, nfev = host_solver(case["a"], case["b"], pl, edge, entry="rt_hybr_host_solve_flat")
+            assert ok == case["success"]
+            np.testing.assert_array_equal(x, np.array(case["x"]))
+            if "nfev" in case:
+                assert case["nfev"] == nfev + 2
+            n += 1
+    assert n > 100
+    rng = np.random.default_rng(11)
+    long_runs = 0
+    for trial in range(400):
+        k = int(rng.integers(1, 4))
+        with_edge = k < 3 and trial % 2 == 0
+        pl = []
+        for _ in range(k):
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            pl.append(np.concatenate([nrm, [rng.uniform(-20, 20)]]))
+        a, b = rng.uniform(-30, 30, 3), rng.uniform(-30, 30, 3)
+        edge = None
+        if with_edge:
+            p0 = rng.uniform(-30, 30, 3)
+            edge = np.stack([p0, p0 + rng.normal(size=3) * rng.uniform(0.5, 20)])
+        x0, ok0, nfev0 = host_solver(a, b, pl, edge)
+        x1, ok1, nfev1 = host_solver(a, b, pl, edge, entry="rt_hybr_host_solve_flat")
+        assert ok0 == ok1 and nfev0 == nfev1
+        np.testing.assert_array_equal(x0, x1)
+        long_runs += nfev0 > 100
+    assert long_runs > 5  # (random planes make for hard systems: runs of hundreds of evaluations are among them)
 
 
 def test_restatement_keeps_the_paths_scipy_keeps_on_config_1(host_solver):
