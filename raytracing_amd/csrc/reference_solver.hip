@@ -19,10 +19,12 @@
 #pragma clang diagnostic ignored "-Wpass-failed"
 
 #define REJ_MAX_GROUPS (2 * RT_MAX_ORDER)
-// evaluations after which the first pass hands a run to the second (on the lln map 97 in 100 runs of reflection +
-// diffraction systems end before 96; lln step with the hand-over at 32 / 96 / 160 / 256 / 512 evaluations: re-judging
-// 10.0 / 9.8 / 8.9 / 9.3 / 12.1 ms)
-#define REJ_FIRST_PASS_NFEV 160
+// evaluations after which the first pass hands a run to the second, which goes on from the state the first left (on
+// the lln map 97 in 100 runs of reflection + diffraction systems end before 96; a trip of the first pass costs about
+// twice what the same evaluation costs a run that has a wave to itself, and the second pass holds one or two
+// thousand runs at a time; lln step with the hand-over at 64 / 96 / 160 / 200 / 240 / 300 / 420 evaluations:
+// re-judging 9.0 / 8.9 / 7.9 / 7.6 / 8.1 / 8.5 / 9.0 ms)
+#define REJ_FIRST_PASS_NFEV 200
 
 int rt_launch_obstruct(rt_scene *scene, const double *d_segs, int64_t n_seg, const uint8_t *d_mask, int64_t n_masked,
                        uint8_t *d_out, const unsigned long long *d_count, int64_t count_add, int64_t n_hint,
@@ -107,14 +109,16 @@ __global__ __launch_bounds__(256) void k_rejudge_classify(const int32_t *__restr
 }
 
 // The reference's solver call on one path of a group, the checks on the solver's points that need no other polygon, and
-// the path's record for the obstruction kernels (flag set = dropped).  Returns false when the solver ran into
-// nfev_limit (nothing is written then).  NR, HE: the shape of the group's systems as template arguments (the method
+// the path's record for the obstruction kernels (flag set = dropped).  Returns false when the solver call ended
+// unfinished (nothing is written then).  NR, HE: the shape of the group's systems as template arguments (the method
 // then runs in registers), or -1, -1.
-template <int NR, int HE, bool FLAT = false>
+// `solve(origin, destination, planes, edge or null, points out, unfinished out)` is the solver call (nested or one-loop
+// form, limited or not, fresh or resumed) and returns the solver's verdict.
+template <int NR, int HE, class Solve>
 __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSource &chains, const int32_t *__restrict__ edge_ids,
                                             int n_refl_rt, int has_edge_rt, const double *__restrict__ edges, d3 tx,
                                             const double *__restrict__ rx, const int32_t *__restrict__ p_rx,
-                                            const int32_t *__restrict__ p_cand, int64_t i, int group, int nfev_limit,
+                                            const int32_t *__restrict__ p_cand, int64_t i, int group, Solve solve,
                                             bool write, PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
     const int n_refl = NR >= 0 ? NR : n_refl_rt;
     const bool has_edge = HE >= 0 ? HE != 0 : has_edge_rt != 0;
@@ -137,8 +141,7 @@ __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSour
     double pts[3 * RT_MAX_ORDER];
     const int n_pts = n_refl + (has_edge ? 1 : 0);
     bool unfinished = false;
-    bool ok = rt_hybr::solve_shape<NR, HE, FLAT>(origin, dest, planes, n_refl, has_edge ? edge : nullptr, pts, nullptr, nfev_limit,
-                                           &unfinished);
+    bool ok = solve(origin, dest, planes, has_edge ? edge : nullptr, pts, &unfinished);
     if (unfinished) return false;
     // The reference checks ITS solver's points (ray_tracing.py:310-313): they can sit a few 1e-7 m from the root the
     // closed form gives (the solver stops at xtol), which decides differently when the point is that close to the rim
@@ -169,7 +172,14 @@ __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSour
 
 // First pass: one thread per path of the group.  A solver run lasts as long as it takes evaluations (10 to 1 000), and
 // a wave as long as its longest lane, so a run that has not ended after nfev_limit evaluations is given up here and its
-// path handed to the second pass (late list: one reservation per wave).
+// path handed to the second pass.  The systems with a finite-difference Jacobian (every shape with a reflection) run
+// the method in its one-loop form (rt_hybr::hybr_flat: the lanes of a wave, which are in different places of the
+// method, evaluate together) and leave the state of their run behind, so that the second pass goes on where they
+// stopped (the first `state_cap` of a group's late paths have room for it; a later one is run again from its start).
+#define REJ_STATE_DOUBLES(NR, HE) RT_FLAT_STATE_DOUBLES(3 * (NR) + (HE))
+// waves per SIMD the second pass is compiled for: two (256 registers each) where the method's state fits them without
+// spilling -- up to four unknowns --, so that 2 048 late runs go side by side instead of 1 024
+#define REJ_LATE_WAVES(NR, HE) ((NR) >= 0 && 3 * (NR) + (HE) <= 4 ? 2 : 1)
 template <int NR, int HE>
 __global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource chains, const int32_t *__restrict__ edge_ids,
                                                        int n_refl_rt, int has_edge_rt, const double *__restrict__ edges, d3 tx,
@@ -177,41 +187,74 @@ __global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource 
                                                        const int32_t *__restrict__ p_cand, const int32_t *__restrict__ list,
                                                        const unsigned long long *__restrict__ count, int group, int nfev_limit,
                                                        int32_t *__restrict__ late, unsigned long long *late_count,
+                                                       double *__restrict__ states, int state_cap,
                                                        PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool done = true;
-    int64_t i = 0;
-    if (k < (int64_t)*count) {
-        i = list[k];
-        // (the lanes of a wave run different systems: the method as one loop with an evaluation per trip, rt_hybr::hybr_flat)
-        done = rejudge_one<NR, HE, true>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group,
-                                         nfev_limit, true, recs, flags);
+    if constexpr (NR >= 1) {
+        if (k >= (int64_t)*count) return;
+        const int64_t i = list[k];
+        auto claim = [&]() -> double * {  // a place in the late list, and room for the state with it
+            const unsigned long long slot = atomicAdd(late_count, 1ull);
+            late[slot] = (int32_t)i;
+            return slot < (unsigned long long)state_cap ? states + slot * REJ_STATE_DOUBLES(NR, HE) : nullptr;
+        };
+        auto solve = [&](const double *o, const double *d, const double *planes, const double *edge, double *pts, bool *unfinished) {
+            return rt_hybr::solve_shape_flat<NR, HE>(o, d, planes, edge, pts, nullptr, nfev_limit, nullptr, claim, unfinished);
+        };
+        rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, solve, true, recs,
+                            flags);
+    } else {
+        bool done = true;
+        int64_t i = 0;
+        if (k < (int64_t)*count) {
+            i = list[k];
+            auto solve = [&](const double *o, const double *d, const double *planes, const double *edge, double *pts, bool *unfinished) {
+                return rt_hybr::solve_shape<NR, HE>(o, d, planes, n_refl_rt, edge, pts, nullptr, nfev_limit, unfinished);
+            };
+            done = rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, solve,
+                                       true, recs, flags);
+        }
+        // late list: one reservation per wave
+        const unsigned long long m = __ballot(!done);
+        if (m == 0ull) return;
+        unsigned long long base = 0;
+        const int lane = threadIdx.x & 63;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(late_count, (unsigned long long)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (!done) late[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
     }
-    const unsigned long long m = __ballot(!done);
-    if (m == 0ull) return;
-    unsigned long long base = 0;
-    const int lane = threadIdx.x & 63;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(late_count, (unsigned long long)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (!done) late[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
 }
 
 // Second pass: the long runs, ONE PATH PER WAVE (every lane makes the same run, lane 0 writes): lanes that run
 // different systems take each other's branches as well as their own, and a wave with three long runs lasted five times
 // as long as its longest; alone, a run of a thousand evaluations takes what its own chain of operations takes.
 template <int NR, int HE>
-__global__ __launch_bounds__(64) void k_rejudge_solve_late(SceneView sc, ChainSource chains, const int32_t *__restrict__ edge_ids,
+__global__ __launch_bounds__(64, REJ_LATE_WAVES(NR, HE)) void k_rejudge_solve_late(SceneView sc, ChainSource chains, const int32_t *__restrict__ edge_ids,
                                                             int n_refl_rt, int has_edge_rt, const double *__restrict__ edges,
                                                             d3 tx, const double *__restrict__ rx,
                                                             const int32_t *__restrict__ p_rx, const int32_t *__restrict__ p_cand,
                                                             const int32_t *__restrict__ late,
-                                                            const unsigned long long *__restrict__ late_count, int group,
+                                                            const unsigned long long *__restrict__ late_count,
+                                                            const double *__restrict__ states, int state_cap, int group,
                                                             PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
     const unsigned long long n_late = *late_count;
     for (unsigned long long k = blockIdx.x; k < n_late; k += gridDim.x) {
         const int64_t i = late[k];
-        rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, 0x7fffffff,
-                            threadIdx.x == 0, recs, flags);
+        if constexpr (NR >= 1) {
+            const double *from = k < (unsigned long long)state_cap ? states + k * REJ_STATE_DOUBLES(NR, HE) : nullptr;
+            auto solve = [&](const double *o, const double *d, const double *planes, const double *edge, double *pts, bool *unfinished) {
+                return rt_hybr::solve_shape_flat<NR, HE>(o, d, planes, edge, pts, nullptr, 0x7fffffff, from, rt_hybr::NoHandOver(),
+                                                         unfinished);
+            };
+            rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, solve,
+                                threadIdx.x == 0, recs, flags);
+        } else {
+            auto solve = [&](const double *o, const double *d, const double *planes, const double *edge, double *pts, bool *unfinished) {
+                return rt_hybr::solve_shape<NR, HE>(o, d, planes, n_refl_rt, edge, pts, nullptr, 0x7fffffff, unfinished);
+            };
+            rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, solve,
+                                threadIdx.x == 0, recs, flags);
+        }
     }
 }
 
@@ -308,6 +351,17 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
                        n, n_groups, lists, counts, recs, flags);
     const d3 TX = ld3(tx);
     int max_nseg = 0;
+    // room for the state of the runs that the first pass hands over (one-loop shapes), per group
+    double *states[REJ_MAX_GROUPS] = {nullptr};
+    int state_cap[REJ_MAX_GROUPS] = {0};
+    for (int g = 0; g < n_groups; ++g) {
+        const CandGroup &G = cand->groups[g];
+        const int unknowns = 3 * G.n_refl + (G.has_edge ? 1 : 0);
+        if (G.count == 0 || G.n_refl < 1 || G.n_refl * 2 + (G.has_edge ? 1 : 0) > 6) continue;
+        state_cap[g] = (int)std::min<int64_t>(n, 32768);
+        states[g] = (double *)rt_scene_temp(scene, sizeof(double) * RT_FLAT_STATE_DOUBLES(unknowns) * (size_t)state_cap[g]);
+        if (!states[g]) state_cap[g] = 0;  // (out of memory: those runs start again in the second pass)
+    }
     static const int first_pass_nfev = [] {
         const char *e = getenv("RT_REJ_FIRST_PASS_NFEV");  // (for measurements of the hand-over point)
         const int v = e ? atoi(e) : 0;
@@ -334,11 +388,11 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
     if (pass == 0)                                                                                                               \
         hipLaunchKernelGGL((k_rejudge_solve<NR, HE>), grid1, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,       \
                            G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, lists + (size_t)g * np, counts + g, g,     \
-                           first_pass_nfev, late + (size_t)g * np, late_counts + g, recs, flags);                            \
+                           first_pass_nfev, late + (size_t)g * np, late_counts + g, states[g], state_cap[g], recs, flags);   \
     else                                                                                                                         \
         hipLaunchKernelGGL((k_rejudge_solve_late<NR, HE>), grid2, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,  \
-                           G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, late + (size_t)g * np, late_counts + g, g, \
-                           recs, flags)
+                           G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, late + (size_t)g * np, late_counts + g,    \
+                           states[g], state_cap[g], g, recs, flags)
             const int shape = G.n_refl * 2 + (G.has_edge ? 1 : 0);
             switch (shape) {
                 case 1: REJ_LAUNCH(0, 1); break;

@@ -727,8 +727,16 @@ RT_HD inline Result hybr(System &sys, double *x, bool user_jac, int nfev_limit =
 // Jacobian waits until every other lane has left its inner loop, and the evaluations of lanes in different places
 // of the method go one after the other; here every trip evaluates for all lanes at once, and only the bookkeeping
 // between two evaluations (a third of the work) is taken in turns.
-template <int NR, int HE>
-RT_HD inline Result hybr_flat(System &sys, double *x, int nfev_limit = 0x7fffffff) {
+// A run can be handed over: after trip_limit trips `claim()` is asked for room (RT_FLAT_STATE_DOUBLES(n) doubles, or null),
+// the state of the method is left there and the run ends unfinished (info -1); a later call with resume_from pointing at
+// that state goes on where this one stopped and gives, bit for bit, what one uninterrupted call gives.
+#define RT_FLAT_STATE_DOUBLES(n) (7 * (n) + (n) * (n) + ((n) * ((n) + 1)) / 2 + 13)
+struct NoHandOver {
+    RT_HD double *operator()() const { return nullptr; }
+};
+template <int NR, int HE, class Claim = NoHandOver>
+RT_HD inline Result hybr_flat(System &sys, double *x, int trip_limit = 0x7fffffff, const double *resume_from = nullptr,
+                              Claim claim = Claim()) {
     constexpr int NC = 3 * NR + HE;
     static_assert(NR >= 1 && NC >= 2, "the finite-difference form of a system whose shape is known at compile time");
     const int n = NC;
@@ -739,16 +747,51 @@ RT_HD inline Result hybr_flat(System &sys, double *x, int nfev_limit = 0x7ffffff
         wa3[RT_HYBR_MAX_N], wa4[RT_HYBR_MAX_N];
     double fjac[RT_HYBR_MAX_N * RT_HYBR_MAX_N], r[(RT_HYBR_MAX_N * (RT_HYBR_MAX_N + 1)) / 2];
     Result res{0, 0};
-    evaluate<NR, HE>(sys, x, fvec, nullptr);
-    res.nfev = 1;
-    double fnorm = enorm(n, fvec);
     int iter = 1, ncsuc = 0, ncfail = 0, nslow1 = 0, nslow2 = 0;
-    double delta = 0, xnorm = 0, pnorm = 0, h = 0;
+    double delta = 0, xnorm = 0, pnorm = 0, h = 0, fnorm = 0;
     const double eps = sqrt(RT_EPSMCH);
     bool jeval = true, sing = false;
     int col = 0;
+    // the state in the order it is kept in: seven vectors, the matrix by columns, the packed triangle, four numbers,
+    // nine counters and flags
+    auto state_io = [&](auto &&io) {
+        RT_UNROLL
+        for (int i = 0; i < n; ++i) {
+            io(x[i]); io(fvec[i]); io(diag[i]); io(qtf[i]); io(wa1[i]); io(wa2[i]); io(wa3[i]);
+        }
+        RT_UNROLL
+        for (int j = 0; j < n; ++j) {
+            RT_UNROLL
+            for (int i = 0; i < n; ++i) io(A_(fjac, i, j));
+        }
+        RT_UNROLL
+        for (int i = 0; i < (n * (n + 1)) / 2; ++i) io(r[i]);
+        io(delta); io(xnorm); io(fnorm); io(pnorm);
+    };
+    if (resume_from) {
+        const double *at = resume_from;
+        state_io([&](double &v) { v = *at++; });
+        iter = (int)at[0]; ncsuc = (int)at[1]; ncfail = (int)at[2]; nslow1 = (int)at[3]; nslow2 = (int)at[4];
+        res.nfev = (int)at[5]; col = (int)at[6]; jeval = at[7] != 0; sing = at[8] != 0;
+    } else {
+        evaluate<NR, HE>(sys, x, fvec, nullptr);
+        res.nfev = 1;
+        fnorm = enorm(n, fvec);
+    }
+    int trips = 0;
     RT_NOUNROLL
     while (true) {
+        if (trips == trip_limit) {
+            double *at = claim();
+            if (at) {
+                state_io([&](double &v) { *at++ = v; });
+                at[0] = iter; at[1] = ncsuc; at[2] = ncfail; at[3] = nslow1; at[4] = nslow2;
+                at[5] = res.nfev; at[6] = col; at[7] = jeval ? 1 : 0; at[8] = sing ? 1 : 0;
+            }
+            res.info = -1;
+            return res;
+        }
+        ++trips;
         if (col >= 0) {  // the point of column col: x with its col-th component stepped
             double temp = 0;
             RT_UNROLL
@@ -861,10 +904,6 @@ RT_HD inline Result hybr_flat(System &sys, double *x, int nfev_limit = 0x7ffffff
             if (actred >= p1) nslow2 = 0;
             if (delta <= xtol * xnorm || fnorm == 0) res.info = 1;
             if (res.info != 0) return res;
-            if (res.nfev >= nfev_limit) {
-                res.info = -1;
-                return res;
-            }
             if (res.nfev >= maxfev) res.info = 2;
             if (p1 * fmax(p1 * delta, pnorm) <= RT_EPSMCH * xnorm) res.info = 3;
             if (nslow2 == 5) res.info = 4;
@@ -916,7 +955,7 @@ RT_HD inline bool solve_shape(const double *origin, const double *destination, c
     setup<NR>(sys, origin, destination, planes, n_refl, edge, x);
     Result res;
     if constexpr (FLAT && NR >= 1)
-        res = hybr_flat<NR, HE>(sys, x, nfev_limit);
+        res = hybr_flat<NR, HE>(sys, x, nfev_limit);  // (here the limit counts trips, i.e. evaluations after the first)
     else
         res = hybr<NR, HE>(sys, x, n_refl == 0, nfev_limit);
     if (nfev) *nfev = res.nfev;
@@ -927,6 +966,28 @@ RT_HD inline bool solve_shape(const double *origin, const double *destination, c
     if (edge) {
         const double xe[3] = {sys.Xe[0], sys.Xe[1], x[3 * n_refl]};
         times_matrix_t(xe, sys.matrix, out_points + 3 * n_refl);
+    }
+    return res.info == 1;
+}
+
+// solve_shape through hybr_flat with a hand-over (see there): trip_limit trips at most, then the state goes where
+// `claim` says; resume_from: go on from a state left by an earlier call for the same system.
+template <int NR, int HE, class Claim>
+RT_HD inline bool solve_shape_flat(const double *origin, const double *destination, const double *planes, const double *edge,
+                                   double *out_points, int *nfev, int trip_limit, const double *resume_from, Claim claim,
+                                   bool *unfinished) {
+    System sys;
+    double x[RT_HYBR_MAX_N];
+    setup<NR>(sys, origin, destination, planes, NR, edge, x);
+    const Result res = hybr_flat<NR, HE, Claim>(sys, x, trip_limit, resume_from, claim);
+    if (nfev) *nfev = res.nfev;
+    if (unfinished) *unfinished = res.info < 0;
+    RT_UNROLL
+    for (int i = 0; i < NR; ++i)
+        for (int k = 0; k < 3; ++k) out_points[3 * i + k] = x[3 * i + k];
+    if (edge) {
+        const double xe[3] = {sys.Xe[0], sys.Xe[1], x[3 * NR]};
+        times_matrix_t(xe, sys.matrix, out_points + 3 * NR);
     }
     return res.info == 1;
 }
@@ -957,6 +1018,40 @@ RT_HD inline bool solve_like_reference_flat(const double *origin, const double *
         case 4: return solve_shape<2, 0, true>(origin, destination, planes, n_refl, edge, out_points, nfev);
         case 5: return solve_shape<2, 1, true>(origin, destination, planes, n_refl, edge, out_points, nfev);
         case 6: return solve_shape<3, 0, true>(origin, destination, planes, n_refl, edge, out_points, nfev);
+        default: break;
+    }
+    return solve_like_reference(origin, destination, planes, n_refl, edge, out_points, nfev);
+}
+
+// the one-loop form run in pieces of `piece` trips, each piece going on from the state the one before it left
+struct HostHandOver {
+    double *room;
+    RT_HD double *operator()() const { return room; }
+};
+template <int NR, int HE>
+RT_HD inline bool solve_shape_in_pieces(const double *origin, const double *destination, const double *planes, const double *edge,
+                                        double *out_points, int *nfev, int piece) {
+    double state[2][RT_FLAT_STATE_DOUBLES(RT_HYBR_MAX_N)];
+    bool unfinished = true, ok = false;
+    int turn = 0;
+    const double *from = nullptr;
+    while (unfinished) {
+        ok = solve_shape_flat<NR, HE>(origin, destination, planes, edge, out_points, nfev, piece, from, HostHandOver{state[turn]},
+                                      &unfinished);
+        from = state[turn];
+        turn ^= 1;
+    }
+    return ok;
+}
+RT_HD inline bool solve_like_reference_in_pieces(const double *origin, const double *destination, const double *planes, int n_refl,
+                                                 const double *edge, double *out_points, int *nfev, int piece) {
+    const int shape = n_refl * 2 + (edge ? 1 : 0);
+    switch (shape) {
+        case 2: return solve_shape_in_pieces<1, 0>(origin, destination, planes, edge, out_points, nfev, piece);
+        case 3: return solve_shape_in_pieces<1, 1>(origin, destination, planes, edge, out_points, nfev, piece);
+        case 4: return solve_shape_in_pieces<2, 0>(origin, destination, planes, edge, out_points, nfev, piece);
+        case 5: return solve_shape_in_pieces<2, 1>(origin, destination, planes, edge, out_points, nfev, piece);
+        case 6: return solve_shape_in_pieces<3, 0>(origin, destination, planes, edge, out_points, nfev, piece);
         default: break;
     }
     return solve_like_reference(origin, destination, planes, n_refl, edge, out_points, nfev);

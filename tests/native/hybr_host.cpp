@@ -19,3 +19,9 @@ extern "C" int rt_hybr_host_solve_flat(const double *origin, const double *desti
                                        const double *edge, double *out_points, int *nfev) {
     return rt_hybr::solve_like_reference_flat(origin, destination, planes, n_refl, edge, out_points, nfev) ? 1 : 0;
 }
+
+// the one-loop form in pieces of `piece` trips, each piece resumed from the state the one before it left
+extern "C" int rt_hybr_host_solve_in_pieces(const double *origin, const double *destination, const double *planes, int n_refl,
+                                            const double *edge, double *out_points, int *nfev, int piece) {
+    return rt_hybr::solve_like_reference_in_pieces(origin, destination, planes, n_refl, edge, out_points, nfev, piece) ? 1 : 0;
+}

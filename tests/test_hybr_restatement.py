@@ -26,8 +26,10 @@ def host_solver():
     for name in ("rt_hybr_host_solve", "rt_hybr_host_solve_flat"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.c_void_p] * 7
+    lib.rt_hybr_host_solve_in_pieces.restype = ctypes.c_int
+    lib.rt_hybr_host_solve_in_pieces.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int]
 
-    def solve(origin, destination, planes, edge, entry="rt_hybr_host_solve"):
+    def solve(origin, destination, planes, edge, entry="rt_hybr_host_solve", piece=None):
         a = np.ascontiguousarray(origin, dtype=float).reshape(3)
         b = np.ascontiguousarray(destination, dtype=float).reshape(3)
         k = len(planes)
@@ -35,8 +37,9 @@ def host_solver():
         e = None if edge is None else np.ascontiguousarray(edge, dtype=float).reshape(2, 3)
         out = np.zeros((k + (1 if e is not None else 0), 3))
         nfev = ctypes.c_int(0)
-        ok = getattr(lib, entry)(a.ctypes.data, b.ctypes.data, pl.ctypes.data, k, e.ctypes.data if e is not None else None,
-                                 out.ctypes.data, ctypes.byref(nfev))
+        args = (a.ctypes.data, b.ctypes.data, pl.ctypes.data, k, e.ctypes.data if e is not None else None, out.ctypes.data,
+                ctypes.byref(nfev))
+        ok = lib.rt_hybr_host_solve_in_pieces(*args, int(piece)) if piece else getattr(lib, entry)(*args)
         return out, bool(ok), nfev.value
 
     return solve
@@ -100,6 +103,10 @@ def test_the_one_loop_form_makes_the_same_runs(host_solver):
         x1, ok1, nfev1 = host_solver(a, b, pl, edge, entry="rt_hybr_host_solve_flat")
         assert ok0 == ok1 and nfev0 == nfev1
         np.testing.assert_array_equal(x0, x1)
+        # handed over every `piece` trips (the state written out and read back): the same run
+        x2, ok2, nfev2 = host_solver(a, b, pl, edge, piece=int(rng.integers(1, 40)))
+        assert ok0 == ok2 and nfev0 == nfev2
+        np.testing.assert_array_equal(x0, x2)
         long_runs += nfev0 > 100
     assert long_runs > 5  # (random planes make for hard systems: runs of hundreds of evaluations are among them)
 
