@@ -172,7 +172,7 @@ __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSour
 
 // First pass: one thread per path of the group.  A solver run lasts as long as it takes evaluations (10 to 1 000), and
 // a wave as long as its longest lane, so a run that has not ended after nfev_limit evaluations is given up here and its
-// path handed to the second pass.  The systems with a finite-difference Jacobian (every shape with a reflection) run
+// path handed to the second pass.  The systems of up to four unknowns with a finite-difference Jacobian (REJ_FLAT) run
 // the method in its one-loop form (rt_hybr::hybr_flat: the lanes of a wave, which are in different places of the
 // method, evaluate together) and leave the state of their run behind, so that the second pass goes on where they
 // stopped (the first `state_cap` of a group's late paths have room for it; a later one is run again from its start).
@@ -180,6 +180,14 @@ __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSour
 // waves per SIMD the second pass is compiled for: two (256 registers each) where the method's state fits them without
 // spilling -- up to four unknowns --, so that 2 048 late runs go side by side instead of 1 024
 #define REJ_LATE_WAVES(NR, HE) ((NR) >= 0 && 3 * (NR) + (HE) <= 4 ? 2 : 1)
+// The one-loop form with its hand-over is for the shapes of up to four unknowns (one reflection, with or without a
+// diffraction after it).  From six unknowns on its state no longer fits the registers as well as the nested form's
+// (330 against 234 for two reflections, 512 and spills for three), a run that has a wave to itself is a quarter
+// slower in it, and the first pass gains less than that costs: those shapes keep the nested form, a first pass of
+// REJ_NESTED_FIRST_PASS_NFEV evaluations and a second pass that starts the run again (config 2, whose re-judging is one
+// double-reflection run of a thousand evaluations: 3.6 ms nested, 4.6 in the one-loop form; config 4: 12.4 and 17.9).
+#define REJ_FLAT(NR, HE) ((NR) >= 1 && 3 * (NR) + (HE) <= 4)
+#define REJ_NESTED_FIRST_PASS_NFEV 96
 template <int NR, int HE>
 __global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource chains, const int32_t *__restrict__ edge_ids,
                                                        int n_refl_rt, int has_edge_rt, const double *__restrict__ edges, d3 tx,
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource 
                                                        double *__restrict__ states, int state_cap,
                                                        PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if constexpr (NR >= 1) {
+    if constexpr (REJ_FLAT(NR, HE)) {
         if (k >= (int64_t)*count) return;
         const int64_t i = list[k];
         auto claim = [&]() -> double * {  // a place in the late list, and room for the state with it
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(64, REJ_LATE_WAVES(NR, HE)) void k_rejudge_solve_la
     const unsigned long long n_late = *late_count;
     for (unsigned long long k = blockIdx.x; k < n_late; k += gridDim.x) {
         const int64_t i = late[k];
-        if constexpr (NR >= 1) {
+        if constexpr (REJ_FLAT(NR, HE)) {
             const double *from = k < (unsigned long long)state_cap ? states + k * REJ_STATE_DOUBLES(NR, HE) : nullptr;
             auto solve = [&](const double *o, const double *d, const double *planes, const double *edge, double *pts, bool *unfinished) {
                 return rt_hybr::solve_shape_flat<NR, HE>(o, d, planes, edge, pts, nullptr, 0x7fffffff, from, rt_hybr::NoHandOver(),
@@ -357,7 +365,7 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
     for (int g = 0; g < n_groups; ++g) {
         const CandGroup &G = cand->groups[g];
         const int unknowns = 3 * G.n_refl + (G.has_edge ? 1 : 0);
-        if (G.count == 0 || G.n_refl < 1 || G.n_refl * 2 + (G.has_edge ? 1 : 0) > 6) continue;
+        if (G.count == 0 || G.n_refl < 1 || unknowns > 4) continue;  // (REJ_FLAT)
         state_cap[g] = (int)std::min<int64_t>(n, 32768);
         states[g] = (double *)rt_scene_temp(scene, sizeof(double) * RT_FLAT_STATE_DOUBLES(unknowns) * (size_t)state_cap[g]);
         if (!states[g]) state_cap[g] = 0;  // (out of memory: those runs start again in the second pass)
@@ -388,7 +396,8 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
     if (pass == 0)                                                                                                               \
         hipLaunchKernelGGL((k_rejudge_solve<NR, HE>), grid1, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,       \
                            G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, lists + (size_t)g * np, counts + g, g,     \
-                           first_pass_nfev, late + (size_t)g * np, late_counts + g, states[g], state_cap[g], recs, flags);   \
+                           REJ_FLAT(NR, HE) ? first_pass_nfev : std::min(first_pass_nfev, REJ_NESTED_FIRST_PASS_NFEV),          \
+                           late + (size_t)g * np, late_counts + g, states[g], state_cap[g], recs, flags);                        \
     else                                                                                                                         \
         hipLaunchKernelGGL((k_rejudge_solve_late<NR, HE>), grid2, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,  \
                            G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, late + (size_t)g * np, late_counts + g,    \
