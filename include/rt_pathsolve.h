@@ -194,13 +194,17 @@ int32_t rt_candidates_group_count(const rt_candidates *cand);
 /* counts[group_count] = candidates per group */
 int rt_candidates_counts(const rt_candidates *cand, int64_t *counts);
 /* chains[count*n_refl] polygon indices and edge_ids[count] (-1 for reflection groups) of one group, host pointers;
- * either may be NULL. */
+ * either may be NULL.  A group of more than 2^31 - 1 candidates is not listed (an error). */
 int rt_candidates_group(const rt_candidates *cand, int32_t group, int32_t *chains, int32_t *edge_ids);
 
 /* ---- the solve: LOS + every (receiver, candidate) (ray_tracing.py:232-237, 243-390) ---------------------------------
  * tx[3], rx[n_rx*3].  Valid paths are appended, in no particular order, to
  *   out_rx[cap] receiver index, out_group[cap] group (-1 = line of sight), out_cand[cap] index inside the group,
  *   out_points[cap*RT_MAX_ORDER*3] interaction points (first n of each row used, the rest zero).
+ * An index of 2^31 or more (a deepest reflection level that is not stored can be that large: order 4 on a town) is split
+ * over the two words: out_cand holds its low 31 bits, bits 8 and up of out_group the rest, the low 8 bits of out_group
+ * the group; for every smaller index, i.e. whenever out_group is below 256, the words are group and index as they are.
+ * rt_describe_paths takes the words as they come.
  * *n_found = number of valid paths (if > capacity the surplus was dropped: call again with more room);
  * *n_attempted = n_rx * (1 + total candidates), the path-solve count of the metric.
  * on_device selects where rx and the out_* arrays live; the two counters are always host. */

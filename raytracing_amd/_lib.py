@@ -211,8 +211,7 @@ class Candidates:
 
     def describe(self, group, cand):
         """Per-path kind / chain / edge arrays (``rt_describe_paths``) of (group, candidate) pairs."""
-        group = np.ascontiguousarray(group, dtype=np.int32)
-        cand = np.ascontiguousarray(cand, dtype=np.int32)
+        group, cand = encode_group_cand(group, cand)
         n = len(group)
         kind = np.zeros(n, dtype=np.int32)
         chain = np.zeros((n, RT_MAX_ORDER), dtype=np.int32)
@@ -482,8 +481,9 @@ class Scene:
             if k <= capacity:
                 break
             capacity = k + k // 8 + 16
-        order = np.lexsort((o_cand[:k], o_group[:k], o_rx[:k]))
-        return dict(rx=o_rx[:k][order], group=o_group[:k][order], cand=o_cand[:k][order], points=o_pts[:k][order],
+        g, c = decode_group_cand(o_group[:k], o_cand[:k])
+        order = np.lexsort((c, g, o_rx[:k]))
+        return dict(rx=o_rx[:k][order], group=g[order], cand=c[order], points=o_pts[:k][order],
                     n_attempted=int(attempted[0]))
 
     def solve_paths_device(self, candidates, tx, rx_ptr, n_rx, out_rx_ptr, out_group_ptr, out_cand_ptr, out_points_ptr,
@@ -594,6 +594,34 @@ class Scene:
         return dict(ms=dict(reflect=ms[0], diffract=ms[1], obstruct=ms[2], finalize=ms[3]),
                     launches=dict(reflect=int(launches[0]), diffract=int(launches[1]), obstruct=int(launches[2]),
                                   finalize=int(launches[3])), segments=int(segs[0]))
+
+
+# ---- the two words that name a path's candidate -----------------------------------------------------------
+# (rt_common.h: a candidate index of 2^31 or more keeps its low 31 bits in the candidate word and puts the rest into
+# bits 8 and up of the group word; below 2^31 the words are the group and the index as they are)
+RT_GROUP_BITS = 8
+
+
+def decode_group_cand(group_word, cand_word):
+    """(group as int32, candidate index as int32 -- int64 when some index needs it --) of the library's two words."""
+    group_word = np.asarray(group_word, dtype=np.int32)
+    cand_word = np.asarray(cand_word, dtype=np.int32)
+    wide = group_word >= (1 << RT_GROUP_BITS)
+    if not wide.any():
+        return group_word, cand_word
+    group = np.where(group_word < 0, group_word, group_word & ((1 << RT_GROUP_BITS) - 1)).astype(np.int32)
+    high = np.where(group_word < 0, 0, group_word.astype(np.int64) >> RT_GROUP_BITS)
+    return group, (high << 31) | cand_word.astype(np.int64)
+
+
+def encode_group_cand(group, cand):
+    """The library's two int32 words of (group, candidate index) pairs."""
+    group = np.asarray(group)
+    cand = np.asarray(cand).astype(np.int64)
+    high = np.where(group < 0, 0, cand >> 31)
+    group_word = np.where(group < 0, group, group.astype(np.int64) | (high << RT_GROUP_BITS))
+    cand_word = np.where(group < 0, cand, cand & 0x7FFFFFFF)
+    return np.ascontiguousarray(group_word, dtype=np.int32), np.ascontiguousarray(cand_word, dtype=np.int32)
 
 
 # ---- entry points that need no scene ---------------------------------------------------------------------

@@ -1010,7 +1010,8 @@ __global__ void k_describe(const int32_t *__restrict__ group, const int32_t *__r
                            double *__restrict__ edge_pts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int g = group[i];
+    const int g = rt_group_of(group[i]);
+    const int64_t c = rt_cand_of(group[i], cand[i]);
     for (int k = 0; k < RT_MAX_ORDER; ++k) chain[i * RT_MAX_ORDER + k] = -1;
     edge_polys[2 * i] = edge_polys[2 * i + 1] = -1;
     for (int k = 0; k < 6; ++k) edge_pts[6 * i + k] = 0.0;
@@ -1020,9 +1021,9 @@ __global__ void k_describe(const int32_t *__restrict__ group, const int32_t *__r
     }
     const int nr = g_refl[g];
     kind[i] = nr + (g_edge[g] ? 256 : 0);
-    if (nr > 0) chain_load(g_chains[g], nr, cand[i], chain + i * RT_MAX_ORDER);
+    if (nr > 0) chain_load(g_chains[g], nr, c, chain + i * RT_MAX_ORDER);
     if (g_edge[g]) {
-        const int e = g_edge_ids[g][cand[i]];
+        const int e = g_edge_ids[g][c];
         edge_polys[2 * i] = edge_pairs[2 * e];
         edge_polys[2 * i + 1] = edge_pairs[2 * e + 1];
         for (int k = 0; k < 6; ++k) edge_pts[6 * i + k] = edges[6 * (size_t)e + k];
@@ -1052,9 +1053,9 @@ extern "C" int rt_describe_paths(rt_candidates *cand, const int32_t *path_group,
     }
     if (!on_device) {
         for (int64_t i = 0; i < n_paths; ++i) {
-            const int g = path_group[i];
+            const int g = rt_group_of(path_group[i]);
             if (g >= ng) RT_FAIL("rt_describe_paths: group out of range");
-            if (g >= 0 && (path_cand[i] < 0 || path_cand[i] >= cand->groups[g].count))
+            if (g >= 0 && (path_cand[i] < 0 || rt_cand_of(path_group[i], path_cand[i]) >= cand->groups[g].count))
                 RT_FAIL("rt_describe_paths: candidate index out of range");
         }
     }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_rejudge_classify(const int32_t *__restr
     __syncthreads();
     int g = -1, slot = 0;
     if (i < n) {
-        g = p_group[i];
+        g = rt_group_of(p_group[i]);
         if (g < 0 || g >= n_groups) {
             g = -1;
             PathRec &rec = recs[i];
@@ -118,11 +118,12 @@ template <int NR, int HE, class Solve>
 __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSource &chains, const int32_t *__restrict__ edge_ids,
                                             int n_refl_rt, int has_edge_rt, const double *__restrict__ edges, d3 tx,
                                             const double *__restrict__ rx, const int32_t *__restrict__ p_rx,
-                                            const int32_t *__restrict__ p_cand, int64_t i, int group, Solve solve,
+                                            const int32_t *__restrict__ p_group, const int32_t *__restrict__ p_cand, int64_t i,
+                                            int group, Solve solve,
                                             bool write, PathRec *__restrict__ recs, uint8_t *__restrict__ flags) {
     const int n_refl = NR >= 0 ? NR : n_refl_rt;
     const bool has_edge = HE >= 0 ? HE != 0 : has_edge_rt != 0;
-    const int64_t c = p_cand[i];
+    const int64_t c = rt_cand_of(p_group[i], p_cand[i]);
     int32_t poly[RT_MAX_ORDER];
     double planes[4 * RT_MAX_ORDER];
     if (n_refl > 0) chain_load(chains, n_refl, c, poly);
@@ -156,8 +157,8 @@ __device__ __forceinline__ bool rejudge_one(const SceneView &sc, const ChainSour
     if (write) {
         PathRec &rec = recs[i];
         rec.rx = r;
-        rec.group = group;
-        rec.cand = (int32_t)c;
+        rec.group = rt_group_word(group, c);
+        rec.cand = rt_cand_word(c);
         rec.nseg = n_pts + 1;
         rec.seg0 = 0;
         rec.seg_stride = 0;
@@ -192,6 +193,7 @@ template <int NR, int HE>
 __global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource chains, const int32_t *__restrict__ edge_ids,
                                                        int n_refl_rt, int has_edge_rt, const double *__restrict__ edges, d3 tx,
                                                        const double *__restrict__ rx, const int32_t *__restrict__ p_rx,
+                                                       const int32_t *__restrict__ p_group,
                                                        const int32_t *__restrict__ p_cand, const int32_t *__restrict__ list,
                                                        const unsigned long long *__restrict__ count, int group, int nfev_limit,
                                                        int32_t *__restrict__ late, unsigned long long *late_count,
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource 
         auto solve = [&](const double *o, const double *d, const double *planes, const double *edge, double *pts, bool *unfinished) {
             return rt_hybr::solve_shape_flat<NR, HE>(o, d, planes, edge, pts, nullptr, nfev_limit, nullptr, claim, unfinished);
         };
-        rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, solve, true, recs,
+        rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_group, p_cand, i, group, solve, true, recs,
                             flags);
     } else {
         bool done = true;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(64) void k_rejudge_solve(SceneView sc, ChainSource 
             auto solve = [&](const double *o, const double *d, const double *planes, const double *edge, double *pts, bool *unfinished) {
                 return rt_hybr::solve_shape<NR, HE>(o, d, planes, n_refl_rt, edge, pts, nullptr, nfev_limit, unfinished);
             };
-            done = rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, solve,
+            done = rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_group, p_cand, i, group, solve,
                                        true, recs, flags);
         }
         // late list: one reservation per wave
@@ -240,7 +242,8 @@ template <int NR, int HE>
 __global__ __launch_bounds__(64, REJ_LATE_WAVES(NR, HE)) void k_rejudge_solve_late(SceneView sc, ChainSource chains, const int32_t *__restrict__ edge_ids,
                                                             int n_refl_rt, int has_edge_rt, const double *__restrict__ edges,
                                                             d3 tx, const double *__restrict__ rx,
-                                                            const int32_t *__restrict__ p_rx, const int32_t *__restrict__ p_cand,
+                                                            const int32_t *__restrict__ p_rx, const int32_t *__restrict__ p_group,
+                                                            const int32_t *__restrict__ p_cand,
                                                             const int32_t *__restrict__ late,
                                                             const unsigned long long *__restrict__ late_count,
                                                             const double *__restrict__ states, int state_cap, int group,
@@ -254,13 +257,13 @@ __global__ __launch_bounds__(64, REJ_LATE_WAVES(NR, HE)) void k_rejudge_solve_la
                 return rt_hybr::solve_shape_flat<NR, HE>(o, d, planes, edge, pts, nullptr, 0x7fffffff, from, rt_hybr::NoHandOver(),
                                                          unfinished);
             };
-            rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, solve,
+            rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_group, p_cand, i, group, solve,
                                 threadIdx.x == 0, recs, flags);
         } else {
             auto solve = [&](const double *o, const double *d, const double *planes, const double *edge, double *pts, bool *unfinished) {
                 return rt_hybr::solve_shape<NR, HE>(o, d, planes, n_refl_rt, edge, pts, nullptr, 0x7fffffff, unfinished);
             };
-            rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_cand, i, group, solve,
+            rejudge_one<NR, HE>(sc, chains, edge_ids, n_refl_rt, has_edge_rt, edges, tx, rx, p_rx, p_group, p_cand, i, group, solve,
                                 threadIdx.x == 0, recs, flags);
         }
     }
@@ -395,12 +398,12 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
 #define REJ_LAUNCH(NR, HE)                                                                                                       \
     if (pass == 0)                                                                                                               \
         hipLaunchKernelGGL((k_rejudge_solve<NR, HE>), grid1, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,       \
-                           G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, lists + (size_t)g * np, counts + g, g,     \
+                           G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_group, d_out_cand, lists + (size_t)g * np, counts + g, g,     \
                            REJ_FLAT(NR, HE) ? first_pass_nfev : std::min(first_pass_nfev, REJ_NESTED_FIRST_PASS_NFEV),          \
                            late + (size_t)g * np, late_counts + g, states[g], state_cap[g], recs, flags);                        \
     else                                                                                                                         \
         hipLaunchKernelGGL((k_rejudge_solve_late<NR, HE>), grid2, block, 0, where, scene->view, G.source, G.edge_ids, G.n_refl,  \
-                           G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_cand, late + (size_t)g * np, late_counts + g,    \
+                           G.has_edge, cand->d_edges, TX, d_rx, d_out_rx, d_out_group, d_out_cand, late + (size_t)g * np, late_counts + g,    \
                            states[g], state_cap[g], g, recs, flags)
             const int shape = G.n_refl * 2 + (G.has_edge ? 1 : 0);
             switch (shape) {

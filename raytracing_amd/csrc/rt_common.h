@@ -188,8 +188,24 @@ int rt_scene_workspace(rt_scene *scene, size_t bytes, void **out);
 int rt_noalloc_setup(int device);
 
 // A path waiting for its obstruction test: its interaction points and where its segments are in the segment queue.
+// A path is named by (group, index of the candidate inside its group).  Both travel as 32-bit integers, in the path
+// records and in the arrays of rt_solve_paths / rt_describe_paths.  A reflection level that is not stored can hold more
+// than 2^31 - 1 candidates (order 4 on a town of some thousand polygons); the index is then split: its low 31 bits are
+// the "candidate" word, the bits above go into bits 8 and up of the "group" word, whose low 8 bits are the group.  For
+// every index below 2^31 the two words are what they always were; a line of sight keeps group -1.
+#define RT_GROUP_BITS 8
+#define RT_MAX_WIDE_CANDIDATES (1ll << 53)
+__host__ __device__ inline int32_t rt_group_word(int group, int64_t cand) {
+    return group < 0 ? group : (int32_t)((int64_t)group | ((cand >> 31) << RT_GROUP_BITS));
+}
+__host__ __device__ inline int32_t rt_cand_word(int64_t cand) { return (int32_t)(cand & 0x7fffffffll); }
+__host__ __device__ inline int rt_group_of(int32_t group_word) { return group_word < 0 ? group_word : (group_word & ((1 << RT_GROUP_BITS) - 1)); }
+__host__ __device__ inline int64_t rt_cand_of(int32_t group_word, int32_t cand_word) {
+    return group_word < 0 ? (int64_t)cand_word : (((int64_t)(group_word >> RT_GROUP_BITS)) << 31) | (int64_t)cand_word;
+}
+
 struct PathRec {
-    int32_t rx, group, cand, nseg;  // nseg: segments still to be tested, counted from the receiver's end
+    int32_t rx, group, cand, nseg;  // group, cand: the two words above; nseg: segments still to be tested, counted from the receiver's end
     int64_t seg0;                   // segment k of those is segs[seg0 + k * seg_stride] when the segment queue is kept
     int32_t seg_stride, npts;       // npts interaction points: emitter, pts[0..npts), receiver is the whole path
     double pts[RT_MAX_ORDER * 3];

@@ -364,8 +364,11 @@ extern "C" rt_candidates *rt_enumerate(rt_scene *scene, const uint8_t *vis, cons
                            k - 1, deg, cnt);
         int64_t total = 0;
         if (!scan_counts(cnt, par.count, off, &total)) CAND_HIP(hipErrorUnknown);
-        if (total > MAX_GROUP_CANDIDATES) {
-            rt_set_error("rt_enumerate: more than 2^31-1 candidates at reflection order " + std::to_string(k));
+        // (the deepest level, when it is not stored, may be wider than 32 bits: its paths carry a split index)
+        const bool stays_virtual = k == max_order && (int64_t)sizeof(int32_t) * total * k > scene->stored_chain_bytes_limit;
+        if (total > (stays_virtual ? RT_MAX_WIDE_CANDIDATES : MAX_GROUP_CANDIDATES)) {
+            rt_set_error("rt_enumerate: more than 2^31-1 candidates at reflection order " + std::to_string(k) +
+                         (k == max_order ? " (and more than a level that is not stored can hold)" : " (a level that has to be stored)"));
             rt_candidates_destroy(c);
             return nullptr;
         }
@@ -472,6 +475,7 @@ extern "C" int rt_candidates_group(const rt_candidates *c, int32_t group, int32_
     if (!c) RT_FAIL("rt_candidates_group: null handle");
     if (group < 0 || group >= (int)c->groups.size()) RT_FAIL("rt_candidates_group: group out of range");
     const CandGroup &g = c->groups[group];
+    if (g.count > MAX_GROUP_CANDIDATES) RT_FAIL("rt_candidates_group: a level of more than 2^31-1 candidates is not listed");
     RT_HIP(rt_use_device(c->scene->device));
     if (chains && g.n_refl > 0 && g.count > 0) {
         if (g.chains) {
@@ -615,8 +619,8 @@ __device__ inline void reflect_emit(const Queues &q, int64_t ps, int64_t ss, int
                                     const d3 *X) {
     PathRec &rec = q.paths[ps];
     rec.rx = (int32_t)r;
-    rec.group = group;
-    rec.cand = (int32_t)c;
+    rec.group = rt_group_word(group, c);
+    rec.cand = rt_cand_word(c);
     rec.nseg = K + 1;
     rec.seg0 = ss;
     rec.seg_stride = 1;

@@ -239,3 +239,21 @@ def test_tree_builders_reproduce_reference_vectors():
     sq = geom.Square.by_2_corner_points(np.array([[3.0, 4.0, 1.0], [-1.0, -2.0, 1.0]]))
     np.testing.assert_array_equal(sq.points, g["square_points"])
     np.testing.assert_array_equal(geom.Square.center(sq.points), g["square_center"])
+
+
+def test_the_two_words_of_a_wide_candidate_index_round_trip():
+    """An index of 2^31 or more is split over the group word and the candidate word (rt_common.h); below, the words are
+    the group and the index themselves."""
+    from raytracing_amd import _lib
+
+    group = np.array([-1, 0, 3, 3, 1, 7], dtype=np.int32)
+    cand = np.array([0, 5, 2**31 + 7, 2**33 + 1, 2**31 - 1, 2**52 + 12345], dtype=np.int64)
+    gw, cw = _lib.encode_group_cand(group, cand)
+    assert gw.dtype == np.int32 and cw.dtype == np.int32 and (cw >= 0).all()
+    assert gw.tolist()[:2] == [-1, 0] and cw.tolist()[:2] == [0, 5] and gw[4] == 1 and cw[4] == 2**31 - 1
+    g2, c2 = _lib.decode_group_cand(gw, cw)
+    np.testing.assert_array_equal(g2, group)
+    np.testing.assert_array_equal(c2, cand)
+    # nothing wide: the arrays pass through as they are
+    g3, c3 = _lib.decode_group_cand(np.array([-1, 2], np.int32), np.array([0, 9], np.int32))
+    assert c3.dtype == np.int32 and g3.tolist() == [-1, 2] and c3.tolist() == [0, 9]
