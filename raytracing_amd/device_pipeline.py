@@ -52,12 +52,22 @@ class PathBlock:
         import torch
 
         n = self.n_paths
-        key = (self.rx.to(torch.int64) * (1 << 40) + (self.group.to(torch.int64) + 1) * (1 << 32) + self.cand.to(torch.int64))
-        order = torch.argsort(key)
+        # group and candidate index out of the library's two words (a candidate index of 2^31 or more is split over them)
+        word_g, word_c = self.group.to(torch.int64), self.cand.to(torch.int64)
+        group = torch.where(word_g < 0, word_g, word_g & 255)
+        index = torch.where(word_g < 0, word_c, ((word_g >> 8) << 31) | word_c)
+        if n and int(index.max()) >= (1 << 31):
+            order = torch.argsort(index, stable=True)
+            order = order[torch.argsort(group[order], stable=True)]
+            order = order[torch.argsort(self.rx[order], stable=True)]
+        else:
+            order = torch.argsort(self.rx.to(torch.int64) * (1 << 40) + (group + 1) * (1 << 32) + index)
+            index = index.to(torch.int32)
+        decoded = {"group": group.to(torch.int32), "cand": index}
         out = {}
         for name in ("rx", "group", "cand", "points", "kind", "chain", "edge_polys", "edge_points", "field", "power",
                      "angles", "time", "status"):
-            t = getattr(self, name)
+            t = decoded.get(name, getattr(self, name))
             out[name] = t[order].cpu().numpy() if n else t[:0].cpu().numpy()
         out["power_db"] = self.power_db.cpu().numpy()
         return out
