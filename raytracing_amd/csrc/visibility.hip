@@ -2186,11 +2186,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
             atomicMin(&g_vis_phase[15], t_item);
             atomicAdd(&g_vis_stats[3], (unsigned long long)m);
             atomicAdd(&g_vis_stats[4], (unsigned long long)n_canvas);
-            if (f < VIS_FACE_LOG) {
-                g_vis_face_log[4 * f] = t_item;
-                g_vis_face_log[4 * f + 1] = t_end - t_item;
-                g_vis_face_log[4 * f + 2] = (unsigned long long)m;
-                g_vis_face_log[4 * f + 3] = (unsigned long long)n_canvas;
+            // (a batch of few faces logs its (face, sector) items instead)
+            const int slot = fb.n_faces * VIS_MAX_TILES <= VIS_FACE_LOG ? f * VIS_MAX_TILES + s_tile : f;
+            if (slot < VIS_FACE_LOG) {
+                g_vis_face_log[4 * slot] = t_item;
+                g_vis_face_log[4 * slot + 1] = t_end - t_item;
+                g_vis_face_log[4 * slot + 2] = (unsigned long long)m;
+                g_vis_face_log[4 * slot + 3] = (unsigned long long)n_canvas;
             }
         }
 #endif
@@ -2253,7 +2255,7 @@ __global__ void k_scene_faces(SceneView sc, int f0, int n_faces, int32_t *off, d
 static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::vector<int32_t> &a_off,
                                    const std::vector<double> &a_verts, const std::vector<double> &a_normal,
                                    const std::vector<int32_t> &a_self, int strict, uint8_t *d_out, RowsJob &job,
-                                   int scene_f0 = -1, int scene_count = 0) {
+                                   int scene_f0 = -1, int scene_count = 0, int max_blocks = 0) {
     const SceneView &sc = scene->view;
     const bool resident = scene_f0 >= 0;
     const int n_faces = resident ? scene_count : (int)a_self.size();
@@ -2265,6 +2267,7 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     // (a face may be painted as up to VIS_MAX_TILES work items)
     const int64_t max_items = strict ? n_faces : (int64_t)n_faces * VIS_MAX_TILES;
     int n_blocks = (int)std::min<int64_t>(n_faces > 256 ? 1024 : 256, max_items);
+    if (max_blocks > 0) n_blocks = std::min(n_blocks, max_blocks);
     const int64_t split_cap = 3 * (int64_t)sc.vtot + 8;
     int m_stride = 1;
     while (m_stride < sc.n) m_stride <<= 1;
@@ -2563,8 +2566,14 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
     if (!faces_on_device && d_faces.alloc(n * n_faces)) RT_FAIL("rt_visibility_with_faces: out of device memory");
     uint8_t *d_faces_dst = faces_on_device ? faces_out : (uint8_t *)d_faces.p;
     RowsJob job;  // after d_faces and the host arrays: the stream is waited for before any of them goes
+    // Beside many rows the screens get 96 workgroups instead of one per compute unit: a workgroup of the screens'
+    // painter fills its unit's registers, so with 256 of them the rows' first kernels wait until the first screens'
+    // workgroups run out of sectors (lln: 10 ms in), and the screens' longest sector lasts 44 ms however many units
+    // the others have (lln, matrix and screens: 169 -> 161 ms; the screens alone 46 -> 58 ms, which is why a call
+    // that paints few rows keeps one per unit).
+    const int beside_rows = (row_ids ? n_rows : scene->view.n) > 256 ? 96 : 0;
     int rc = visibility_rows_enqueue(scene, scene->side_stream, a_off, a_verts, a_normal, a_self, faces_strict, d_faces_dst,
-                                     job);
+                                     job, -1, 0, beside_rows);
     if (rc == 0)
         rc = row_ids ? visibility_listed_rows(scene, n_rows, row_ids, strict, rows_out, rows_on_device)
                      : rt_visibility_matrix(scene, strict, rows_out, rows_on_device);

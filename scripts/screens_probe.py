@@ -1,4 +1,6 @@
-"""Times the painting of the emitter's six screens on a scene, one by one and together (not a test)."""
+"""Where the time of the emitter's screens goes, item by item (not a test; needs a build with -DRT_VIS_STAMPS):
+python scripts/screens_probe.py"""
+import ctypes
 import sys
 import time
 
@@ -7,16 +9,41 @@ import numpy as np
 sys.path.insert(0, ".")
 from raytracing_amd import _lib, geometry as geom, scenarios  # noqa: E402
 
-place, tx, rx = scenarios.lln_grid(10) if len(sys.argv) < 2 or sys.argv[1] == "lln" else scenarios.levant_grid(8)
-polygons = place.get_polygons_list()
-scene = _lib.Scene(geom.scene_arrays_of(polygons))
-cube = geom.Cube.by_point_and_side_length(tx, 0.2)
-faces = [(s.points, s.get_parametric(), -1) for s in cube.polygons]
-scene.faces_visibility(faces[:1], False)
-for k, face in enumerate(faces):
+loaded, tx = scenarios.lln_scene()
+scene = _lib.Scene(loaded.arrays)
+scene.set_timing(True)
+cube = geom.Cube.by_point_and_side_length(np.asarray(tx, dtype=float).reshape(3), 0.2)
+screens = [(s.points, s.get_parametric(), -1) for s in cube.polygons]
+lib = _lib.load()
+for rep in range(2):
     t = time.perf_counter()
-    v = scene.faces_visibility([face], False)[0]
-    print(f"screen {k}: {time.perf_counter() - t:.3f} s, sees {int(v.sum())} of {len(polygons)}", flush=True)
-t = time.perf_counter()
-vs = scene.faces_visibility(faces, False)
-print(f"all six: {time.perf_counter() - t:.3f} s, union {int(np.logical_or.reduce(vs).sum())}")
+    vis = scene.faces_visibility(screens, False)
+    dt = time.perf_counter() - t
+    print(f"screens alone {1e3 * dt:.1f} ms, kernels {scene.visibility_timing()['faces']}, visible {vis.sum(axis=1)}", flush=True)
+for rep in range(3):
+    t = time.perf_counter()
+    scene.visibility_with_faces(screens)
+    dt = time.perf_counter() - t
+    tm = scene.visibility_timing()
+    print(f"matrix and screens together {1e3 * dt:.1f} ms; rows {tm['rows']['total']:.1f} (paint {tm['rows']['paint']:.1f}), screens {tm['faces']['total']:.1f} ms", flush=True)
+if not hasattr(lib, "rt_debug_visibility_face_log"):
+    sys.exit(0)
+T = 128
+log = np.zeros((6 * T, 4), dtype=np.uint64)
+lib.rt_debug_visibility_face_log(ctypes.c_void_p(log.ctypes.data), 6 * T)
+used = log[:, 1] > 0
+start = (log[:, 0].astype(float) - log[used, 0].min()) / 1e5
+dur = log[:, 1].astype(float) / 1e5
+for f in range(6):
+    sel = used.copy()
+    sel[: f * T] = False
+    sel[(f + 1) * T:] = False
+    if not sel.any():
+        continue
+    print(f"screen {f}: {int(sel.sum())} items, candidates per item mean {log[sel, 2].mean():.0f} max {log[sel, 2].max()}, visible per item mean "
+          f"{log[sel, 3].mean():.1f} max {log[sel, 3].max()}; item time mean {dur[sel].mean():.2f} max {dur[sel].max():.2f} ms, sum {dur[sel].sum():.1f} ms; "
+          f"first start {start[sel].min():.2f}, last end {(start[sel] + dur[sel]).max():.2f} ms", flush=True)
+order = np.argsort(-dur)[:10]
+for i in order:
+    print(f"  item (screen {i // T}, sector {i % T}): start {start[i]:.2f}, lasts {dur[i]:.2f} ms, candidates {log[i, 2]}, visible {log[i, 3]}")
+print(f"all items: sum {dur[used].sum():.1f} ms over {int(used.sum())} items; span {(start[used] + dur[used]).max():.1f} ms")
