@@ -1226,6 +1226,73 @@ __global__ void k_rx_boxes(const double *__restrict__ rxs, int64_t n, double *__
     }
 }
 
+// The three steps above in ONE launch of one workgroup, for batches whose grid fits LDS (up to 64 x 64 cells, i.e. 16 384
+// receivers): four launches of a few microseconds each cost 75 us with the gaps between them, and every kernel of the
+// solve waits for the tiles.
+#define RX_TILES_ONE_LAUNCH_CELLS 4096
+__global__ __launch_bounds__(1024) void k_rx_tiles(const double *__restrict__ rx, int n, double x0, double y0, double inv,
+                                                   int g_side, double *__restrict__ rxs, int32_t *__restrict__ perm,
+                                                   double *__restrict__ boxes) {
+    __shared__ int32_t cell_at[RX_TILES_ONE_LAUNCH_CELLS];  // count of a cell, then the place of its next receiver
+    __shared__ int32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_cells = g_side * g_side;
+    for (int c = tid; c < n_cells; c += 1024) cell_at[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&cell_at[rx_cell(rx, i, x0, y0, inv, g_side)], 1);
+    __syncthreads();
+    // exclusive scan: every thread owns a run of neighbouring cells
+    const int per = (n_cells + 1023) / 1024;
+    const int c0 = tid * per, c1 = min(n_cells, c0 + per);
+    int mine = 0;
+    for (int c = c0; c < c1; ++c) mine += cell_at[c];
+    int x = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        int v = lane < 16 ? wsum[lane] : 0;
+        for (int off = 1; off < 16; off <<= 1) {
+            const int y = __shfl_up(v, off);
+            if (lane >= off) v += y;
+        }
+        if (lane < 16) wsum[lane] = v;
+    }
+    __syncthreads();
+    int at = (wave > 0 ? wsum[wave - 1] : 0) + x - mine;
+    for (int c = c0; c < c1; ++c) {
+        const int k = cell_at[c];
+        cell_at[c] = at;
+        at += k;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int pos = atomicAdd(&cell_at[rx_cell(rx, i, x0, y0, inv, g_side)], 1);
+        rxs[3 * pos] = rx[3 * i];
+        rxs[3 * pos + 1] = rx[3 * i + 1];
+        rxs[3 * pos + 2] = rx[3 * i + 2];
+        perm[pos] = i;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int t = tid; t * RX_TILE < n; t += 1024) {
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int j = 0; j < RX_TILE && t * RX_TILE + j < n; ++j)
+            for (int a = 0; a < 3; ++a) {
+                const double v = __builtin_nontemporal_load(rxs + 3 * (t * RX_TILE + j) + a);
+                lo[a] = fmin(lo[a], v);
+                hi[a] = fmax(hi[a], v);
+            }
+        for (int a = 0; a < 3; ++a) {
+            boxes[6 * t + a] = 0.5 * (lo[a] + hi[a]);
+            boxes[6 * t + 3 + a] = 0.5 * (hi[a] - lo[a]) * (1.0 + 1e-12) + 1e-12 * (fabs(lo[a]) + fabs(hi[a]));
+        }
+    }
+}
+
 // Receiver-independent half of an (M reflections + diffraction) candidate: reflection points aimed at the edge's first
 // endpoint, their containment and spacing checks.  Candidates that pass go to `alive` with their points and their M
 // receiver-independent segments.
@@ -1977,24 +2044,30 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         const double extent = std::max(v.gside * v.gnx, v.gside * v.gny);
         const double inv = extent > 0.0 ? g_side / extent : 0.0;
         const int64_t n_cells = (int64_t)g_side * g_side, n_tiles = (n_rx + RX_TILE - 1) / RX_TILE;
-        int32_t *counts = (int32_t *)temp_alloc(sizeof(int32_t) * 2 * n_cells);
-        int64_t *cell_off = (int64_t *)temp_alloc(sizeof(int64_t) * (n_cells + 1));
         double *rxs = (double *)temp_alloc(sizeof(double) * 3 * n_rx);
         int32_t *perm = (int32_t *)temp_alloc(sizeof(int32_t) * n_rx);
         double *boxes = (double *)temp_alloc(sizeof(double) * 6 * n_tiles);
-        SOLVE_PTR(counts);
-        SOLVE_PTR(cell_off);
         SOLVE_PTR(rxs);
         SOLVE_PTR(perm);
         SOLVE_PTR(boxes);
-        SOLVE_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * n_cells, st));
-        timer.begin(0);
-        hipLaunchKernelGGL(k_rx_count, dim3(blocks_for(n_rx, 256)), dim3(256), 0, st, d_rx, n_rx, v.gx0, v.gy0, inv, g_side, counts);
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, counts, n_cells, cell_off);
-        hipLaunchKernelGGL(k_rx_scatter, dim3(blocks_for(n_rx, 256)), dim3(256), 0, st, d_rx, n_rx, v.gx0, v.gy0, inv, g_side,
-                           cell_off, counts + n_cells, rxs, perm);
-        hipLaunchKernelGGL(k_rx_boxes, dim3(blocks_for(n_tiles, 256)), dim3(256), 0, st, rxs, n_rx, boxes);
-        timer.end(0);
+        if (n_cells <= RX_TILES_ONE_LAUNCH_CELLS) {
+            timer.begin(0);
+            hipLaunchKernelGGL(k_rx_tiles, dim3(1), dim3(1024), 0, st, d_rx, (int)n_rx, v.gx0, v.gy0, inv, g_side, rxs, perm, boxes);
+            timer.end(0);
+        } else {
+            int32_t *counts = (int32_t *)temp_alloc(sizeof(int32_t) * 2 * n_cells);
+            int64_t *cell_off = (int64_t *)temp_alloc(sizeof(int64_t) * (n_cells + 1));
+            SOLVE_PTR(counts);
+            SOLVE_PTR(cell_off);
+            SOLVE_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * n_cells, st));
+            timer.begin(0);
+            hipLaunchKernelGGL(k_rx_count, dim3(blocks_for(n_rx, 256)), dim3(256), 0, st, d_rx, n_rx, v.gx0, v.gy0, inv, g_side, counts);
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, counts, n_cells, cell_off);
+            hipLaunchKernelGGL(k_rx_scatter, dim3(blocks_for(n_rx, 256)), dim3(256), 0, st, d_rx, n_rx, v.gx0, v.gy0, inv, g_side,
+                               cell_off, counts + n_cells, rxs, perm);
+            hipLaunchKernelGGL(k_rx_boxes, dim3(blocks_for(n_tiles, 256)), dim3(256), 0, st, rxs, n_rx, boxes);
+            timer.end(0);
+        }
         tiles = RxTiles{rxs, perm, boxes};
     }
     // the wall next to every receiver in 256 directions, for the diffraction kernel (large batches over a scene with a grid)

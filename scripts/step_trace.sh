@@ -6,7 +6,7 @@ import csv, collections
 rows=list(csv.DictReader(open('gpurun_out/strace_$1/st_kernel_trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # the last 5 steps: find k_rx_count launches as step starts
-starts=[i for i,r in enumerate(rows) if r['Kernel_Name'].startswith('k_rx_count')]
+starts=[i for i,r in enumerate(rows) if r['Kernel_Name'].startswith(('k_rx_count', 'k_rx_tiles'))]
 seg=rows[starts[-3]:starts[-2]]
 t0=int(seg[0]['Start_Timestamp'])
 for r in seg:
