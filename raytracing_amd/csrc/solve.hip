@@ -2076,7 +2076,10 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
     static const int hint_cells = [] { const char *e = getenv("RT_RX_HINT_CELLS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 1024 ? v : RX_HINT_CELLS; }();
     bool diffraction_groups = false;  // (any_diffraction is only known once the head has run)
     for (int m = 0; m < mo; ++m) diffraction_groups = diffraction_groups || cand->groups[mo + m].count > 0;
-    if (tiled && diffraction_groups && scene->view.cells && scene->view.gnx > 0 && scene->wall_hints && !getenv("RT_NO_RX_HINTS")) {
+    // (a quarter of a GiB of hints at most, i.e. 262 144 receivers at 256 directions: beyond that the diffraction kernel
+    // does without them, with the tests it makes itself)
+    if (tiled && diffraction_groups && scene->view.cells && scene->view.gnx > 0 && scene->wall_hints && !getenv("RT_NO_RX_HINTS") &&
+        n_rx * (int64_t)hint_bins <= (1ll << 26)) {
         rx_hints = (int32_t *)temp_alloc(sizeof(int32_t) * hint_bins * n_rx);
         SOLVE_PTR(rx_hints);
         // (made on the side stream, in front of the head and beside the reflection kernel: the side stream then has to

@@ -1585,6 +1585,7 @@ __device__ __forceinline__ int shortcuts_alone(const Store *cs, const uint16_t *
 #define VIS_GRID_WORDS (VIS_GRID * VIS_GRID / 32)
 #define VIS_GRID_MARGIN 1e-7
 #define VIS_GRID_EPS 1e-9
+#define VIS_STRETCH 256             /* candidates held against the bitmap at a time (one per thread of a four-wave workgroup) */
 #define VIS_GRID_MIN_CANDIDATES 256 /* faces with fewer candidates are painted without the bitmap */
 #ifndef VIS_GRID_MAX_CELLS
 #define VIS_GRID_MAX_CELLS 64       /* a candidate over more cells goes the usual way */
@@ -1773,7 +1774,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
         int n_cs = 0, used = 0;
         // ---- the covered-cell bitmap of this face (whole faces with enough candidates to pay for it): its domain is
         // the box of the candidates' boxes
-        const bool want_grid = !span.bounded() && m >= VIS_GRID_MIN_CANDIDATES;
+        // (a sector of a four-wave workgroup has its own: what of a candidate can show there lies in its box cut to the
+        // sector, and so does every witness of the sector's decision; the sixteen-wave workgroups that paint a handful
+        // of faces in sectors do without: lln's six screens 44 -> 47 ms with it, the bits cost what they settle)
+        const bool want_grid = (NW == 4 || !span.bounded()) && m >= VIS_GRID_MIN_CANDIDATES;
         if (want_grid) {
             double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
             for (int q = threadIdx.x; q < m; q += blockDim.x) {
@@ -1805,6 +1809,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     s_red[0][2] = fmin(s_red[0][2], s_red[w][2]);
                     s_red[0][3] = fmax(s_red[0][3], s_red[w][3]);
                 }
+                s_red[0][0] = fmax(s_red[0][0], s_span.x0);
+                s_red[0][1] = fmin(s_red[0][1], s_span.x1);
                 const double wx = s_red[0][1] - s_red[0][0], wy = s_red[0][3] - s_red[0][2];
                 const bool ok = wx > 1e-6 && wy > 1e-6 && wx < 1e3 && wy < 1e3;
                 s_grid_on = ok ? 1 : 0;
@@ -1838,7 +1844,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
         int left_k = 0, left_m = 0;   // candidates of the last stretch the resident path did not get to: s_chunk[left_k, left_m)
         bool resident = true;
         while (k < m && resident) {
-            const int chunk_n = m - k < 64 * NW ? m - k : 64 * NW;
+            const int chunk_n = m - k < VIS_STRETCH ? m - k : VIS_STRETCH;
             {
                 int B = -1;
                 bool keep = false;
@@ -1847,7 +1853,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     keep = true;
                     if (grid_on) {
                         const PolyMeta &mq = meta_f[B];
-                        keep = !grid_hides(grid, s_gdom, mq.xmin, mq.xmax, mq.ymin, mq.ymax);
+                        keep = !grid_hides(grid, s_gdom, fmax(mq.xmin, span.x0), fmin(mq.xmax, span.x1), mq.ymin, mq.ymax);
                     }
                 }
                 const unsigned long long mk = __ballot(keep);
