@@ -135,11 +135,12 @@ int rt_scene_set_timing(rt_scene *scene, int on);
  * before it (same candidates, same order, same indices).  0 = never store the deepest level.  For tests of that route.
  * No reference counterpart. */
 int rt_debug_set_stored_chain_limit(rt_scene *scene, int64_t bytes);
-/* The painter cuts a face that has at least min_candidates candidate polygons into azimuth sectors of about per_tile
- * candidates each, painted by different workgroups (a polygon is visible iff it shows in some sector); per_tile = 0
- * paints every face whole; min_candidates = -1 (the default) lets each call choose: sectors when it paints at most 256
- * faces (the emitter's screens), whole faces when it paints many (a matrix).  Same vectors either way; the switch exists so that tests can check one against the other
- * on small scenes (no reference counterpart). */
+/* The painter cuts a face that has at least min_candidates candidate polygons into tiles (rectangles of its
+ * (azimuth, polar) view) of about per_tile candidates each, painted by different workgroups (a polygon is visible iff
+ * it shows in some tile); per_tile = 0 paints every face whole; min_candidates = -1 (the default) lets each call
+ * choose: tiles when it paints at most 256 faces (the emitter's screens), whole faces when it paints a whole matrix,
+ * tiles for the largest faces of a share of one.  Same vectors either way; the switch exists so that tests can check
+ * one against the other on small scenes (no reference counterpart). */
 int rt_debug_set_visibility_tiling(rt_scene *scene, int32_t min_candidates, int32_t per_tile);
 /* Device time, in milliseconds, of the last visibility call on this scene (HIP events on the stream the kernels ran on,
  * while rt_scene_set_timing is on): ms[0] mapping to (azimuth, polar) and ring validity, ms[1] sorting by the painter's

@@ -320,7 +320,7 @@ class Scene:
         _check(load().rt_scene_set_reference_solver(self.handle, int(bool(on))), "rt_scene_set_reference_solver")
 
     def set_visibility_tiling(self, min_candidates, per_tile):
-        """Faces with at least ``min_candidates`` candidates are painted in azimuth sectors of about ``per_tile``
+        """Faces with at least ``min_candidates`` candidates are painted in tiles (rectangles of their view) of about ``per_tile``
         candidates (``per_tile`` 0: every face whole)."""
         _check(load().rt_debug_set_visibility_tiling(self.handle, int(min_candidates), int(per_tile)),
                "rt_debug_set_visibility_tiling")

@@ -144,7 +144,7 @@ struct rt_scene {
     int64_t queue_capacity_override = 0;  // > 0: first size of the path queue (tests of the grow-and-redo route)
     int occlusion_mode = 0;  // 0 = by scene size, 1 = every-polygon walk, 2 = grid walk
     bool reference_solver = false;  // re-judge every found path with the reference's own solver (reference_solver.hip)
-    // painter: a face with at least vis_tile_min candidates is painted in azimuth sectors of about vis_tile_size
+    // painter: a face with at least vis_tile_min candidates is painted in tiles (rectangles of its view) of about vis_tile_size
     // candidates each, by different workgroups (vis_tile_size 0: never)
     // vis_tile_min -1 (the default): chosen per call, sectors only when a call paints few faces
     int vis_tile_min = -1, vis_tile_size = 0;

@@ -579,16 +579,19 @@ struct CanvasSet {
     __device__ int sgn(int i) const { return st->sgns[slot(i)]; }
 };
 
-// A face with very many candidates is painted in tiles: azimuth sectors (x0, x1), each by its own workgroup, with the
+// A face with very many candidates is painted in tiles: rectangles of the (azimuth, polar) plane ("sectors" below: they
+// began as azimuth intervals), each by its own workgroup, with the
 // candidates whose box reaches into the sector and a canvas of the polygons found visible INSIDE the sector.  A polygon
 // is visible iff part of it shows in some sector.  Inside a sector the uncovered part of B is bounded by pieces of B's
-// edges, of canvas edges and of the sector's two borders, so: every edge is also cut where it crosses a border, a
+// edges, of canvas edges and of the sector's borders, so: every edge is also cut where it crosses a border, a
 // witness only counts inside the sector, and the borders themselves are examined like edges (witness on the sector's
 // inner side, inside B, outside every canvas polygon).  An unbounded span is the whole face.
+// The part of a face's view that one work item paints: a rectangle of the (azimuth, polar) plane, open-ended where it
+// is the outermost in a direction; a face painted whole has the unbounded one.
 struct TileSpan {
-    double x0, x1;
-    __device__ bool bounded() const { return x0 > -INFINITY || x1 < INFINITY; }
-    __device__ bool holds(double x) const { return x > x0 && x < x1; }
+    double x0, x1, y0, y1;
+    __device__ bool bounded() const { return x0 > -INFINITY || x1 < INFINITY || y0 > -INFINITY || y1 < INFINITY; }
+    __device__ bool holds(double x, double y) const { return x > x0 && x < x1 && y > y0 && y < y1; }
 };
 
 // Is the witness next to the middle of piece (t0, t1) of edge a->b, on side `side` (+1 = left of a->b), inside the
@@ -601,7 +604,7 @@ __device__ inline bool witness_uncovered(const Set &ps, double ax, double ay, do
     const double tm = 0.5 * (t0 + t1);
     const double wx = ax + tm * ex - side * VIS_DELTA * (ey / len);
     const double wy = ay + tm * ey + side * VIS_DELTA * (ex / len);
-    if (!tile.holds(wx)) return false;
+    if (!tile.holds(wx, wy)) return false;
     if (need_in_b) {
         if (!pip_ring(ps.x(0), ps.y(0), ps.nv(0), wx, wy)) return false;
     }
@@ -694,6 +697,11 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
             if (ta > t_lo && ta < t_hi) splits.put(k++, ta);
             if (tb > t_lo && tb < t_hi) splits.put(k++, tb);
         }
+        if (ey != 0.0) {
+            const double ta = (tile.y0 - ay) / ey, tb = (tile.y1 - ay) / ey;
+            if (ta > t_lo && ta < t_hi) splits.put(k++, ta);
+            if (tb > t_lo && tb < t_hi) splits.put(k++, tb);
+        }
         *lds_count = k;
     }
     __builtin_amdgcn_wave_barrier();
@@ -781,9 +789,10 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
             }
             const double tm = 0.5 * (t0 + t1);
             const double wx = ax + tm * ex - side * VIS_DELTA * (ey / len);
+            const double wy = ay + tm * ey + side * VIS_DELTA * (ex / len);
             splits.px[lane] = wx;
-            splits.py[lane] = ay + tm * ey + side * VIS_DELTA * (ex / len);
-            splits.pstate[lane] = ((t1 - t0) * len > VIS_MIN_PIECE && tile.holds(wx)) ? 1 : 0;
+            splits.py[lane] = wy;
+            splits.pstate[lane] = ((t1 - t0) * len > VIS_MIN_PIECE && tile.holds(wx, wy)) ? 1 : 0;
         }
         // only an entry whose box reaches the edge's can hold a witness (they stand VIS_DELTA beside the edge): those
         // are listed first, in the part of the cut buffer that this few cuts leave free (B itself, when the witnesses
@@ -1100,13 +1109,14 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
         // lanes = samples: the point, and whether it is inside B; then lanes = (sample, entry) pairs
         if (lane < n_samples) {
             double px = lane == 0 ? gx : 0.5 * (gx + x[(lane - 1) * nv / (n_samples - 1)]);
-            const double py = lane == 0 ? gy : 0.5 * (gy + y[(lane - 1) * nv / (n_samples - 1)]);
-            // a sample outside the tile proves nothing there: it is moved onto the middle line of the part of the tile
+            double py = lane == 0 ? gy : 0.5 * (gy + y[(lane - 1) * nv / (n_samples - 1)]);
+            // a sample outside the tile proves nothing there: it is moved onto the middle lines of the part of the tile
             // that B's box reaches (and then has to be inside B like any other)
-            if (!tile.holds(px)) px = 0.5 * (fmax(tile.x0, bx0) + fmin(tile.x1, bx1));
+            if (!(px > tile.x0 && px < tile.x1)) px = 0.5 * (fmax(tile.x0, bx0) + fmin(tile.x1, bx1));
+            if (!(py > tile.y0 && py < tile.y1)) py = 0.5 * (fmax(tile.y0, by0) + fmin(tile.y1, by1));
             splits.px[lane] = px;
             splits.py[lane] = py;
-            splits.pstate[lane] = (tile.holds(px) && pip_ring(x, y, nv, px, py)) ? 1 : 0;
+            splits.pstate[lane] = (tile.holds(px, py) && pip_ring(x, y, nv, px, py)) ? 1 : 0;
         }
         __builtin_amdgcn_wave_barrier();
         const int per_sample = n - 1;
@@ -1213,9 +1223,10 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
     __threadfence_block();
     PHASE(3);
     if (lane == 0 && wave == 0) VIS_STAT(2, n_work);
-    // (the tile's two borders, where they pass through B's box, are examined with them: witness on the tile's inner
-    // side, inside B like the others; a->b upwards, so side +1 is the side of smaller azimuth)
-    const int n_border = tile.bounded() ? 2 : 0;
+    // (the tile's four borders, where they pass through B's box, are examined with them: witness on the tile's inner
+    // side, inside B like the others; the vertical ones a->b upwards, so side +1 is the side of smaller azimuth; the
+    // horizontal ones a->b towards larger azimuth, so side +1 is the side of the larger polar angle)
+    const int n_border = tile.bounded() ? 4 : 0;
     for (int w = wave; w < n_work + n_border; w += n_waves) {
         if (*(volatile int *)flag) break;
         int li = -1;
@@ -1228,11 +1239,16 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
             const int u = v == 0 ? cn - 1 : v - 1;
             ax = cx[u]; ay = cy[u]; ex_ = cx[v]; ey_ = cy[v];
             side = -(double)ps.sgn(li);
-        } else {
+        } else if (w < n_work + 2) {
             const double t = w == n_work ? tile.x0 : tile.x1;
             if (!(t > bx0 && t < bx1)) continue;
             ax = t; ay = by0 - 1e-6; ex_ = t; ey_ = by1 + 1e-6;
             side = w == n_work ? -1.0 : 1.0;
+        } else {
+            const double t = w == n_work + 2 ? tile.y0 : tile.y1;
+            if (!(t > by0 && t < by1)) continue;
+            ax = bx0 - 1e-6; ay = t; ex_ = bx1 + 1e-6; ey_ = t;
+            side = w == n_work + 2 ? 1.0 : -1.0;
         }
         if (lane == 0) VIS_STAT(6, 1);
         // the part of the edge inside B's box (a little more), by clipping against the box's four sides
@@ -1387,6 +1403,8 @@ __device__ inline bool faces_viewer(const SceneView &sc, const FaceBatch &fb, in
 // the candidate count, most first; inside a class in whatever order the atomics give, which changes no result: faces are
 // independent).  A face with thousands of candidates lasts a hundred times as long as a wall with a few dozen, and taken
 // last it would keep one compute unit busy long after the others have run out of faces.
+// (A face in tiles keeps its place: placed by the candidates of one tile instead, the faces painted whole start earlier
+// and the tiles later, and a share of lln's rows takes longer, an eighth 85-100 ms instead of 78-82.)
 __global__ __launch_bounds__(1024) void k_face_queue(const int32_t *__restrict__ counts, int n_faces, int n_poly,
                                                       int32_t *__restrict__ queue) {
     __shared__ int hist[1024];
@@ -1394,8 +1412,9 @@ __global__ __launch_bounds__(1024) void k_face_queue(const int32_t *__restrict__
     hist[threadIdx.x] = 0;
     __syncthreads();
     const long long scale = n_poly > 0 ? n_poly : 1;
+    auto size_of = [&](int f) { return counts[f]; };
     for (int f = threadIdx.x; f < n_faces; f += 1024) {
-        const int cls = (int)((long long)counts[f] * 1023 / scale);
+        const int cls = (int)((long long)size_of(f) * 1023 / scale);
         atomicAdd(&hist[1023 - (cls < 0 ? 0 : (cls > 1023 ? 1023 : cls))], 1);
     }
     __syncthreads();
@@ -1408,66 +1427,211 @@ __global__ __launch_bounds__(1024) void k_face_queue(const int32_t *__restrict__
     }
     __syncthreads();
     for (int f = threadIdx.x; f < n_faces; f += 1024) {
-        const int cls = (int)((long long)counts[f] * 1023 / scale);
+        const int cls = (int)((long long)size_of(f) * 1023 / scale);
         queue[atomicAdd(&start[1023 - (cls < 0 ? 0 : (cls > 1023 ? 1023 : cls))], 1)] = f;
     }
 }
 
 #define VIS_MAX_TILES 128
 #define VIS_TILE_BINS 1024
+#define VIS_TILE_THREADS 1024
 
-// Azimuth sectors of every face: a face with fewer than min_candidates candidates is one unbounded tile; a larger one
-// gets ceil(m / per_tile) sectors (at most VIS_MAX_TILES) holding about the same number of candidate centres each
-// (quantiles of a 1 024-bin histogram of the centres' azimuth).  bounds[f * (VIS_MAX_TILES + 1) + t] .. [+ t + 1] is
-// sector t; the first and last sectors are open-ended.  One workgroup per face.
-__global__ __launch_bounds__(256) void k_vis_tiles(int n, const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
+// Tiles of every face: a face with fewer than min_candidates candidates is one unbounded tile; a larger one gets up to
+// ceil(m / per_tile) rectangles of the (azimuth, polar) plane (at most VIS_MAX_TILES) that hold about the same number of
+// candidate centres each: the tile with the most centres is cut at their median along the direction in which they
+// spread more (a 1 024-bin histogram over their range), until no tile holds more than per_tile.  Azimuth alone does
+// not do: a wall looks along the ground, every far building lies on the horizon line, and that line has ONE azimuth
+// from the wall's centre (sectors of a side-looking screen of lln's emitter held 1 000 to 1 300 candidates each where
+// 48 were asked for).  bounds[4 (f VIS_MAX_TILES + t)] .. + 3 = x0, x1, y0, y1 of tile t; the outermost tiles are
+// open-ended.  One workgroup per face.
+__global__ __launch_bounds__(VIS_TILE_THREADS) void k_vis_tiles(int n, const PolyMeta *__restrict__ meta, const int32_t *__restrict__ order,
                                                     int m_stride, const int32_t *__restrict__ counts, int min_candidates,
-                                                    int per_tile, double *__restrict__ bounds, int32_t *__restrict__ n_tiles) {
+                                                    int per_tile, const int32_t *__restrict__ queue, int top_faces,
+                                                    int top_per_tile, double *__restrict__ bounds,
+                                                    int32_t *__restrict__ n_tiles) {
     __shared__ int hist[VIS_TILE_BINS];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    __shared__ double tb[VIS_MAX_TILES][4];
+    __shared__ int tcnt[VIS_MAX_TILES];  // centres in the tile; negative once it cannot be cut further
+    __shared__ double red[VIS_TILE_THREADS / 64][4];
+    __shared__ double s_lo, s_scale;
+    __shared__ int s_sel, s_axis, s_n, s_bin, s_cum;
+    __shared__ int s_wsum[VIS_TILE_THREADS / 64];
+    static_assert(VIS_TILE_BINS == VIS_TILE_THREADS, "one bin of the histogram a thread");
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = counts[f];
-    double *b = bounds + (size_t)f * (VIS_MAX_TILES + 1);
-    int T = 1;
+    double *b = bounds + 4 * (size_t)f * VIS_MAX_TILES;
+    int T = 1, per = per_tile;
     if (m >= min_candidates && per_tile > 0) T = min(VIS_MAX_TILES, (m + per_tile - 1) / per_tile);
+    // the first top_faces faces of the queue (those with the most candidates) go in tiles of top_per_tile whatever
+    // the rule above says
+    if (T <= 1 && top_per_tile > 0 && m >= 2 * top_per_tile) {
+        bool top = false;
+        for (int i = 0; i < top_faces; ++i) top = top || queue[i] == f;
+        if (top) {
+            T = min(VIS_MAX_TILES, (m + top_per_tile - 1) / top_per_tile);
+            per = top_per_tile;
+        }
+    }
     if (T <= 1) {
         if (tid == 0) {
             b[0] = -INFINITY;
             b[1] = INFINITY;
+            b[2] = -INFINITY;
+            b[3] = INFINITY;
             n_tiles[f] = 1;
         }
         return;
     }
-    for (int i = tid; i < VIS_TILE_BINS; i += 256) hist[i] = 0;
-    __syncthreads();
     const PolyMeta *meta_f = meta + (size_t)f * n;
     const int32_t *ord = order + (size_t)f * m_stride;
-    const double scale = VIS_TILE_BINS / (2.0 * M_PI);
-    for (int k = tid; k < m; k += 256) {
-        const PolyMeta &mb = meta_f[ord[k]];
-        int bin = (int)((0.5 * (mb.xmin + mb.xmax) + M_PI) * scale);
-        bin = bin < 0 ? 0 : (bin >= VIS_TILE_BINS ? VIS_TILE_BINS - 1 : bin);
-        atomicAdd(&hist[bin], 1);
+    // the centres of this thread's candidates: in registers when eight a thread are enough (every cut reads them twice)
+    const bool cached = m <= 8 * VIS_TILE_THREADS;
+    double ccx[8], ccy[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = tid + j * VIS_TILE_THREADS;
+        ccx[j] = ccy[j] = NAN;  // (no tile holds it)
+        if (cached && k < m) {
+            const PolyMeta &mb = meta_f[ord[k]];
+            ccx[j] = 0.5 * (mb.xmin + mb.xmax);
+            ccy[j] = 0.5 * (mb.ymin + mb.ymax);
+        }
+    }
+    if (tid == 0) {
+        tb[0][0] = -INFINITY;
+        tb[0][1] = INFINITY;
+        tb[0][2] = -INFINITY;
+        tb[0][3] = INFINITY;
+        tcnt[0] = m;
+        s_n = 1;
     }
     __syncthreads();
-    if (tid == 0) {
-        int cum = 0, t = 1, used = 1;
-        b[0] = -INFINITY;
-        for (int bin = 0; bin < VIS_TILE_BINS && t < T; ++bin) {
-            cum += hist[bin];
-            bool placed = false;
-            while (t < T && (long long)cum * T >= (long long)t * m) {
-                // a border at the upper end of this bin, nudged off the round value so that it does not run along a
-                // polygon edge that sits exactly on a bin's end; one border per bin at most
-                if (!placed && bin + 1 < VIS_TILE_BINS) {
-                    b[used++] = -M_PI + (bin + 1) / scale + 1.234567e-7;
-                    placed = true;
+    for (int iter = 0; iter < 4 * VIS_MAX_TILES; ++iter) {
+        if (tid == 0) {
+            int best = -1, most = per;  // only a tile with more than `per` centres is cut
+            for (int i = 0; i < s_n; ++i)
+                if (tcnt[i] > most) {
+                    most = tcnt[i];
+                    best = i;
                 }
-                ++t;
+            s_sel = s_n < T ? best : -1;
+        }
+        __syncthreads();
+        const int sel = s_sel;
+        if (sel < 0) break;
+        const double x0 = tb[sel][0], x1 = tb[sel][1], y0 = tb[sel][2], y1 = tb[sel][3];
+        // (a centre belongs to the tile whose half-open rectangle (x0, x1] x (y0, y1] holds it)
+        double lo_x = INFINITY, hi_x = -INFINITY, lo_y = INFINITY, hi_y = -INFINITY;
+        auto widen = [&](double cx, double cy) {
+            if (cx > x0 && cx <= x1 && cy > y0 && cy <= y1) {
+                lo_x = fmin(lo_x, cx);
+                hi_x = fmax(hi_x, cx);
+                lo_y = fmin(lo_y, cy);
+                hi_y = fmax(hi_y, cy);
+            }
+        };
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) widen(ccx[j], ccy[j]);
+        } else {
+            for (int k = tid; k < m; k += VIS_TILE_THREADS) {
+                const PolyMeta &mb = meta_f[ord[k]];
+                widen(0.5 * (mb.xmin + mb.xmax), 0.5 * (mb.ymin + mb.ymax));
             }
         }
-        b[used] = INFINITY;
-        n_tiles[f] = used;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo_x = fmin(lo_x, __shfl_xor(lo_x, off));
+            hi_x = fmax(hi_x, __shfl_xor(hi_x, off));
+            lo_y = fmin(lo_y, __shfl_xor(lo_y, off));
+            hi_y = fmax(hi_y, __shfl_xor(hi_y, off));
+        }
+        if (lane == 0) {
+            red[wave][0] = lo_x;
+            red[wave][1] = hi_x;
+            red[wave][2] = lo_y;
+            red[wave][3] = hi_y;
+        }
+        for (int i = tid; i < VIS_TILE_BINS; i += VIS_TILE_THREADS) hist[i] = 0;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < VIS_TILE_THREADS / 64; ++w) {
+                red[0][0] = fmin(red[0][0], red[w][0]);
+                red[0][1] = fmax(red[0][1], red[w][1]);
+                red[0][2] = fmin(red[0][2], red[w][2]);
+                red[0][3] = fmax(red[0][3], red[w][3]);
+            }
+            const double rx = red[0][1] - red[0][0], ry = red[0][3] - red[0][2];
+            const int axis = rx >= ry ? 0 : 1;
+            const double range = axis == 0 ? rx : ry;
+            if (!(range > 1e-5)) {
+                tcnt[sel] = -tcnt[sel];  // its centres sit on one spot
+                s_axis = -1;
+            } else {
+                s_axis = axis;
+                s_lo = axis == 0 ? red[0][0] : red[0][2];
+                s_scale = VIS_TILE_BINS / range;
+            }
+        }
+        __syncthreads();
+        const int axis = s_axis;
+        if (axis < 0) continue;
+        const double lo = s_lo, scale = s_scale;
+        auto count = [&](double cx, double cy) {
+            if (cx > x0 && cx <= x1 && cy > y0 && cy <= y1) {
+                int bin = (int)(((axis == 0 ? cx : cy) - lo) * scale);
+                bin = bin < 0 ? 0 : (bin >= VIS_TILE_BINS ? VIS_TILE_BINS - 1 : bin);
+                atomicAdd(&hist[bin], 1);
+            }
+        };
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) count(ccx[j], ccy[j]);
+        } else {
+            for (int k = tid; k < m; k += VIS_TILE_THREADS) {
+                const PolyMeta &mb = meta_f[ord[k]];
+                count(0.5 * (mb.xmin + mb.xmax), 0.5 * (mb.ymin + mb.ymax));
+            }
+        }
+        __syncthreads();
+        // the bin at whose upper end half of the tile's centres are reached: a scan of the histogram over the workgroup
+        // (one bin a thread), the first such bin by an atomic minimum
+        const int cnt = tcnt[sel];
+        int cum = hist[tid];
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(cum, off);
+            if (lane >= off) cum += y;
+        }
+        if (lane == 63) s_wsum[wave] = cum;
+        if (tid == 0) s_bin = VIS_TILE_BINS - 2;  // (the last bin is never the cut: its upper end is the range's)
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) cum += s_wsum[w];
+        if (2 * cum >= cnt && tid < VIS_TILE_BINS - 2) atomicMin(&s_bin, tid);
+        __syncthreads();
+        if (tid == s_bin) s_cum = cum;
+        __syncthreads();
+        if (tid == 0) {
+            const int bin = s_bin, left = s_cum;
+            // the border at the upper end of that bin, nudged off the round value so that it does not run along a polygon
+            // edge that sits exactly on a bin's end
+            const double cut = lo + (bin + 1) / scale + 1.234567e-7;
+            if (left <= 0 || left >= cnt) {
+                tcnt[sel] = -cnt;
+            } else {
+                const int nw = s_n;
+                for (int q = 0; q < 4; ++q) tb[nw][q] = tb[sel][q];
+                tb[sel][axis == 0 ? 1 : 3] = cut;
+                tb[nw][axis == 0 ? 0 : 2] = cut;
+                tcnt[sel] = left;
+                tcnt[nw] = cnt - left;
+                s_n = nw + 1;
+            }
+        }
+        __syncthreads();
     }
+    __syncthreads();
+    const int n_out = s_n;
+    for (int i = tid; i < 4 * n_out; i += VIS_TILE_THREADS) b[i] = tb[i >> 2][i & 3];
+    if (tid == 0) n_tiles[f] = n_out;
 }
 
 // item_off[q] = tiles of the faces before place q of the queue (queue null: face order); item_off[n_faces] = all
@@ -1723,8 +1887,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
         // the sector lives in LDS and is read where it is needed: held in registers through the whole decision it
         // pushed the kernel from 138 to 219 vector registers and into scratch memory
         if (threadIdx.x == 0) {
-            s_span.x0 = tile_bounds ? tile_bounds[(size_t)f * (VIS_MAX_TILES + 1) + s_tile] : -INFINITY;
-            s_span.x1 = tile_bounds ? tile_bounds[(size_t)f * (VIS_MAX_TILES + 1) + s_tile + 1] : INFINITY;
+            const double *tb = tile_bounds ? tile_bounds + 4 * ((size_t)f * VIS_MAX_TILES + s_tile) : nullptr;
+            s_span.x0 = tb ? tb[0] : -INFINITY;
+            s_span.x1 = tb ? tb[1] : INFINITY;
+            s_span.y0 = tb ? tb[2] : -INFINITY;
+            s_span.y1 = tb ? tb[3] : INFINITY;
         }
         __syncthreads();
         const TileSpan &span = s_span;
@@ -1749,7 +1916,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                 bool take = false;
                 if (k < m) {
                     B = ord[k];
-                    take = meta_f[B].xmax > span.x0 && meta_f[B].xmin < span.x1;
+                    take = meta_f[B].xmax > span.x0 && meta_f[B].xmin < span.x1 && meta_f[B].ymax > span.y0 &&
+                           meta_f[B].ymin < span.y1;
                 }
                 const unsigned long long mk = __ballot(take);
                 if (lane == 0) s_wcnt[wave] = __popcll(mk);
@@ -1811,6 +1979,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                 }
                 s_red[0][0] = fmax(s_red[0][0], s_span.x0);
                 s_red[0][1] = fmin(s_red[0][1], s_span.x1);
+                s_red[0][2] = fmax(s_red[0][2], s_span.y0);
+                s_red[0][3] = fmin(s_red[0][3], s_span.y1);
                 const double wx = s_red[0][1] - s_red[0][0], wy = s_red[0][3] - s_red[0][2];
                 const bool ok = wx > 1e-6 && wy > 1e-6 && wx < 1e3 && wy < 1e3;
                 s_grid_on = ok ? 1 : 0;
@@ -1853,7 +2023,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     keep = true;
                     if (grid_on) {
                         const PolyMeta &mq = meta_f[B];
-                        keep = !grid_hides(grid, s_gdom, fmax(mq.xmin, span.x0), fmin(mq.xmax, span.x1), mq.ymin, mq.ymax);
+                        keep = !grid_hides(grid, s_gdom, fmax(mq.xmin, span.x0), fmin(mq.xmax, span.x1), fmax(mq.ymin, span.y0),
+                                           fmin(mq.ymax, span.y1));
                     }
                 }
                 const unsigned long long mk = __ballot(keep);
@@ -1944,13 +2115,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                         // what of B can show in this tile lies in B's box cut to the sector: only canvas polygons reaching
                         // there matter
                         const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+                        const double lymin = fmax(mb.ymin, span.y0), lymax = fmin(mb.ymax, span.y1);
                         int n_list = 0;
                         for (int base = 0; base < n_cs; base += 64) {
                             const int ci = base + lane;
                             bool take = false;
                             if (ci < n_cs) {
                                 const double *cb = cs->boxes + 4 * ci;
-                                take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                                take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < lymin || cb[2] > lymax);
                             }
                             const unsigned long long mk = __ballot(take);
                             const int at = n_list + __popcll(mk & ((1ull << lane) - 1));
@@ -1999,12 +2171,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                                 move_staged(cs, slot_b, n_cs, used);
                                 int n_list = 0;
                                 const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+                                const double lymin = fmax(mb.ymin, span.y0), lymax = fmin(mb.ymax, span.y1);
                                 for (int base = 0; base < n_cs; base += 64) {
                                     const int ci = base + lane;
                                     bool take = false;
                                     if (ci < n_cs) {
                                         const double *cb = cs->boxes + 4 * ci;
-                                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < lymin || cb[2] > lymax);
                                     }
                                     const unsigned long long mk = __ballot(take);
                                     if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = (uint16_t)ci;
@@ -2084,6 +2257,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
             const int B = q_rest < n_left ? s_chunk[left_k + q_rest] : ord[k + q_rest - n_left];  // uniform over the workgroup
             const PolyMeta mb = meta_f[B];
             const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+            const double lymin = fmax(mb.ymin, span.y0), lymax = fmin(mb.ymax, span.y1);
             if (wave == 0) {
                 // ---- canvas polygons whose box meets B's box
                 int n_list = 0;
@@ -2093,7 +2267,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     int C = -1;
                     if (ci < n_canvas) {
                         const double *cb = cbox + 4 * (size_t)ci;
-                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < mb.ymin || cb[2] > mb.ymax);
+                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < lymin || cb[2] > lymax);
                         C = canvas[ci];
                     }
                     const unsigned long long mk = __ballot(take);
@@ -2290,7 +2464,7 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         b_work.alloc(sizeof(int32_t) * 2 * (size_t)sc.vtot * n_waves) || job.b_tlist.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) ||
         job.b_grid.alloc(sizeof(uint32_t) * VIS_GRID_WORDS * (size_t)n_blocks) ||
         job.b_chunk.alloc(sizeof(int32_t) * 1024 * (size_t)n_blocks) ||
-        job.b_bounds.alloc(sizeof(double) * (VIS_MAX_TILES + 1) * (size_t)n_faces) ||
+        job.b_bounds.alloc(sizeof(double) * 4 * VIS_MAX_TILES * (size_t)n_faces) ||
         job.b_ntiles.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_itemoff.alloc(sizeof(int32_t) * ((size_t)n_faces + 1)))
         RT_FAIL("visibility: out of device memory");
     const double *d_face_verts;
@@ -2359,7 +2533,7 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     const int32_t *face_queue = nullptr, *item_off = nullptr;
     const double *tile_bounds = nullptr;
     if (!strict) {
-        // faces in order of their candidate count, most first; each cut into azimuth sectors when it has very many
+        // faces in order of their candidate count, most first; each cut into tiles ("sectors") when it has very many
         // candidates; the persistent workgroups take (face, sector) items from a counter
         hipLaunchKernelGGL(k_face_queue, dim3(1), dim3(1024), 0, st, (const int32_t *)b_counts.p, n_faces, sc.n,
                            (int32_t *)job.b_queue.p);
@@ -2381,8 +2555,16 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
                 tile_size = 1024;
             }
         }
-        hipLaunchKernelGGL(k_vis_tiles, dim3(n_faces), dim3(256), 0, st, sc.n, (const PolyMeta *)b_meta.p,
-                           (const int32_t *)b_order.p, m_stride, (const int32_t *)b_counts.p, tile_min, tile_size,
+        // A half or a quarter of a large scene's faces (a rank's share on two to five GPUs): the 64 faces with the most
+        // candidates go in tiles of 1 024 all the same.  Painted whole the share lasts as long as its longest face (lln:
+        // 100-130 ms whatever the share), in tiles a quarter of the rows takes 86 instead of 126 ms and a half 119
+        // instead of 132; tiles for every face of 4 096 candidates and more, as for smaller shares, would double the
+        // work (a half: 167 ms).  The whole scene on one GPU is bound by its work, not by its longest face: no tiles.
+        const int top_faces = 64, top_per_tile = 1024;
+        const bool top_sectors = scene->vis_tile_min < 0 && n_faces > 256 && tile_size == 0 && n_faces * 2 <= sc.n + 1;
+        hipLaunchKernelGGL(k_vis_tiles, dim3(n_faces), dim3(VIS_TILE_THREADS), 0, st, sc.n, (const PolyMeta *)b_meta.p,
+                           (const int32_t *)b_order.p, m_stride, (const int32_t *)b_counts.p, tile_min, tile_size, face_queue,
+                           top_sectors ? std::min(top_faces, n_faces) : 0, top_sectors ? top_per_tile : 0,
                            (double *)job.b_bounds.p, (int32_t *)job.b_ntiles.p);
         hipLaunchKernelGGL(k_vis_item_offsets, dim3(1), dim3(1024), 0, st, (const int32_t *)job.b_ntiles.p, face_queue, n_faces,
                            (int32_t *)job.b_itemoff.p);
@@ -2574,9 +2756,9 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
     RowsJob job;  // after d_faces and the host arrays: the stream is waited for before any of them goes
     // Beside many rows the screens get 96 workgroups instead of one per compute unit: a workgroup of the screens'
     // painter fills its unit's registers, so with 256 of them the rows' first kernels wait until the first screens'
-    // workgroups run out of sectors (lln: 10 ms in), and the screens' longest sector lasts 44 ms however many units
-    // the others have (lln, matrix and screens: 169 -> 161 ms; the screens alone 46 -> 58 ms, which is why a call
-    // that paints few rows keeps one per unit).
+    // workgroups run out of tiles (lln: 10 ms in) (lln, matrix and screens: 169 -> 161 ms when the screens were
+    // painted in azimuth sectors, 155 ms since their tiles are rectangles; a call that paints few rows keeps one
+    // workgroup per unit, which the screens alone need: 33 ms).
     const int beside_rows = (row_ids ? n_rows : scene->view.n) > 256 ? 96 : 0;
     int rc = visibility_rows_enqueue(scene, scene->side_stream, a_off, a_verts, a_normal, a_self, faces_strict, d_faces_dst,
                                      job, -1, 0, beside_rows);

@@ -13,6 +13,7 @@ from raytracing_amd import multithread_solve as mts
 torch.zeros(1, device="cuda:0").add_(1)
 place, tx = scenarios.lln_place()
 scene = _lib.Scene(geom.scene_arrays_of(place.get_polygons_list()))
+scene.set_timing(True)
 cube = geom.Cube.by_point_and_side_length(tx, 0.2)
 screens = [(s.points, s.get_parametric(), -1) for s in cube.polygons]
 mts.paint_dealt_block_on_device(scene, screens, False, 8, 3)
@@ -26,7 +27,9 @@ for setting in [(-1, 0)] + [tuple(int(v) for v in a.split(",")) for a in sys.arg
             t = time.perf_counter()
             block = mts.paint_dealt_block_on_device(scene, screens, False, world, rank)
             torch.cuda.synchronize()
-            line.append(f"W{world}r{rank} {1e3 * (time.perf_counter() - t):.0f} ms")
+            tm = scene.visibility_timing()
+            line.append(f"W{world}r{rank} {1e3 * (time.perf_counter() - t):.0f} ms (rows: mapping {tm['rows']['prepare']:.0f}, sorting {tm['rows']['sort']:.0f}, "
+                        f"painting {tm['rows']['paint']:.0f}; screens {tm['faces']['total']:.0f})")
             if world == 1:
                 if want is None:
                     want = block.clone()
