@@ -279,6 +279,33 @@ def test_every_row_of_the_lln_matrix_is_the_oracles(places):
         np.testing.assert_array_equal(alone, want[i])
 
 
+def test_every_share_of_the_lln_rows_is_the_oracles(places):
+    """The rows of the lln matrix dealt to 2, 4 and 8 ranks, every rank's share painted on the one GPU with the tile
+    rules the library chooses for a share of that size (its largest faces in tiles), against the oracle's rows
+    (tests/golden/lln_matrix_rows.npz): all 58 million entries, three times over."""
+    import os
+
+    import torch
+
+    from conftest import GOLDEN
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import multithread_solve as mts
+
+    z = np.load(os.path.join(GOLDEN, "lln_matrix_rows.npz"))
+    n = int(z["n"])
+    want = np.unpackbits(z["bits"])[: n * n].reshape(n, n).astype(bool)
+    scene = geom.scene_arrays_of(places("lln").get_polygons_list()).device_scene()
+    assert scene.n == n
+    for world in (2, 4, 8):
+        for rank in range(world):
+            block = mts.paint_dealt_block_on_device(scene, [], False, world, rank)
+            torch.cuda.synchronize()
+            mine = np.arange(rank, n, world)
+            got = block.cpu().numpy()[: len(mine)].astype(bool)
+            bad = np.argwhere(got != want[mine])
+            assert len(bad) == 0, f"world {world} rank {rank}: {len(bad)} entries differ, first {bad[:10].tolist()}"
+
+
 @pytest.mark.parametrize("name", ["small", "ny", "place_levant", "place_saint_jean/place_saint_jean"])
 def test_sharp_edges_match_oracle(places, name):
     from oracle import geometry_oracle as go
