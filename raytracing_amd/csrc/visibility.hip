@@ -1346,16 +1346,16 @@ __global__ __launch_bounds__(VIS_SORT_THREADS) void k_vis_sort(int n, const Poly
         };
         for (int k = 2; k <= m_pad; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < m_pad; i += VIS_SORT_THREADS) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const bool up = (i & k) == 0;
-                        if (up ? less(l, i) : less(i, l)) {
-                            const int ti = s_id[i];
-                            const double t1 = s_k1[i];
-                            s_id[i] = s_id[l]; s_k1[i] = s_k1[l];
-                            s_id[l] = ti; s_k1[l] = t1;
-                        }
+                // a thread per pair (i, i + j): i = the pair's number with a zero put in at bit j
+                for (int p = tid; p < (m_pad >> 1); p += VIS_SORT_THREADS) {
+                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    const int l = i | j;
+                    const bool up = (i & k) == 0;
+                    if (up ? less(l, i) : less(i, l)) {
+                        const int ti = s_id[i];
+                        const double t1 = s_k1[i];
+                        s_id[i] = s_id[l]; s_k1[i] = s_k1[l];
+                        s_id[l] = ti; s_k1[l] = t1;
                     }
                 }
                 __syncthreads();
