@@ -504,6 +504,7 @@ struct GlobalSet {
         x0 = m.xmin; x1 = m.xmax; y0 = m.ymin; y1 = m.ymax;
     }
     __device__ int sgn(int i) const { return meta_f[poly(i)].sgn; }
+    __device__ uint32_t twin_mask(int) const { return 0u; }
 };
 
 #define LS_MAX_POLY 96
@@ -527,6 +528,7 @@ struct LocalSet {
         x0 = st->boxes[4 * i]; x1 = st->boxes[4 * i + 1]; y0 = st->boxes[4 * i + 2]; y1 = st->boxes[4 * i + 3];
     }
     __device__ int sgn(int i) const { return st->sgns[i]; }
+    __device__ uint32_t twin_mask(int) const { return 0u; }
 };
 
 // The canvas of the face being painted, resident in LDS: every polygon found visible so far with its box and mapped
@@ -538,12 +540,17 @@ struct LocalSet {
 template <int CS_MAX_POLY, int CS_MAX_COORD>
 struct CanvasStore {
     static constexpr int max_poly = CS_MAX_POLY, max_coord = CS_MAX_COORD;  // coordinates in doubles
-    int nvs[CS_MAX_POLY], offs[CS_MAX_POLY], sgns[CS_MAX_POLY];
+    // (narrow types: every byte of LDS counts here, three workgroups share a compute unit's)
+    uint16_t nvs[CS_MAX_POLY], offs[CS_MAX_POLY];
+    int8_t sgns[CS_MAX_POLY];
     // a list of any length, for the candidate that is decided on its own (the waves' own lists are short):
     uint16_t list[CS_MAX_POLY];      // slots listed for the candidate
     uint16_t lpre[CS_MAX_POLY + 2];  // vertices before entry i of the set (entry 0 = the candidate, then the listed)
     double boxes[CS_MAX_POLY * 4];
     double xy[CS_MAX_COORD];
+    // bit v of twin[slot]: edge v (from vertex v - 1 to v) of the canvas polygon in that slot is also an edge of another
+    // canvas polygon that covers the strip along its outer side (mark_twins); such an edge is not examined
+    uint32_t twin[CS_MAX_POLY];
 };
 using SmallCanvasStore = CanvasStore<320, 3072>;
 using LargeCanvasStore = CanvasStore<768, 6144>;
@@ -578,6 +585,7 @@ struct CanvasSet {
         x0 = st->boxes[4 * k]; x1 = st->boxes[4 * k + 1]; y0 = st->boxes[4 * k + 2]; y1 = st->boxes[4 * k + 3];
     }
     __device__ int sgn(int i) const { return st->sgns[slot(i)]; }
+    __device__ uint32_t twin_mask(int i) const { return i == 0 ? 0u : st->twin[slot(i)]; }
 };
 
 // A face with very many candidates is painted in tiles: rectangles of the (azimuth, polar) plane ("sectors" below: they
@@ -1175,7 +1183,10 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
                 const double *cx = ps.x(li), *cy = ps.y(li);
                 const int u = v == 0 ? cn - 1 : v - 1;
                 const double ax = cx[u], ay = cy[u], ex = cx[v], ey = cy[v];
-                if (!(fmax(ax, ex) < bx0 || fmin(ax, ex) > bx1 || fmax(ay, ey) < by0 || fmin(ay, ey) > by1)) {
+                // (an edge that a neighbouring canvas polygon shares and covers from outside has no witness: every one
+                // would stand inside that neighbour, which is in the list whenever the edge reaches into B's box)
+                const bool buried = v < 32 && ((ps.twin_mask(li) >> v) & 1u) != 0u;
+                if (!buried && !(fmax(ax, ex) < bx0 || fmin(ax, ex) > bx1 || fmax(ay, ey) < by0 || fmin(ay, ey) > by1)) {
                     rel = pip_ring(x, y, nv, ax, ay) || pip_ring(x, y, nv, ex, ey);
                     for (int q = 0; q < nv && !rel; ++q) {
                         const int p = q == 0 ? nv - 1 : q - 1;
@@ -1734,6 +1745,73 @@ __device__ __forceinline__ int shortcuts_alone(const Store *cs, const uint16_t *
     return VIS_UNSETTLED;
 }
 
+// ---- Shared edges.  Two walls of a building share the edge where they meet, a wall and its roof the wall's top: in the
+// canvas such an edge appears twice, once per polygon, and the strip along the outer side of either copy lies inside the
+// other polygon.  A third of the canvas edges that the full decisions examine are of that kind (lln: 3.6 of 10.9
+// million), and examining one can never find a witness: a witness stands VIS_DELTA outside its edge, next to the middle
+// of a piece at least VIS_MIN_PIECE long, i.e. at least 2 VIS_DELTA from the edge's ends, and that point is inside the
+// neighbour when the neighbour is convex (or has four vertices at most), has the edge bit for bit (in either direction), and leaves it at both ends at
+// an interior angle of 30 degrees or more towards vertices that lie at least VIS_TWIN_REACH beyond the edge's line on
+// the witness side (the hull of the edge and those two vertices then holds the point, and a convex polygon holds the
+// hull of its vertices).  The polygon that has just been put into canvas slot s is held against every older canvas
+// polygon, both ways round; the flags only ever grow, like the canvas.  Threads first, first + stride, ... share the
+// older polygons.
+#define VIS_TWIN_REACH 1e-7
+#define VIS_TWIN_COS 0.86602540378443865 /* 30 degrees: the point stands 2 VIS_DELTA from the end, cot 30 = 1.73 < 2 */
+template <typename Store>
+__device__ inline bool twin_covers(const Store *cs, int cover, int jc, bool reversed, double ax, double ay, double bx, double by,
+                                   double outer) {
+    // does polygon `cover`, whose edge jc (from its vertex jc - 1 to jc) is a->b (or b->a when reversed), hold the strip
+    // along the side `outer` (+1 left of a->b, -1 right) of a->b?
+    const int nv = cs->nvs[cover];
+    const double *x = cs->xy + cs->offs[cover], *y = x + nv;
+    // (a ring of three or four vertices needs no convexity: with both other vertices on the witness side of the edge's
+    // line, VIS_TWIN_REACH away, nothing of its boundary but the two edges that leave the shared one comes near the strip)
+    if (nv > 4 && !ring_turns_one_way(x, y, nv, (double)cs->sgns[cover])) return false;
+    const int j0 = jc == 0 ? nv - 1 : jc - 1;
+    const int before = j0 == 0 ? nv - 1 : j0 - 1, after = jc + 1 == nv ? 0 : jc + 1;
+    // the cover's vertices next to a and to b
+    const int ia = reversed ? after : before, ib = reversed ? before : after;
+    const double ex = bx - ax, ey = by - ay;
+    const double len = sqrt(ex * ex + ey * ey);
+    if (!(len > VIS_MIN_PIECE)) return false;
+    const double qax = x[ia] - ax, qay = y[ia] - ay, qbx = x[ib] - bx, qby = y[ib] - by;
+    const double ha = outer * (ex * qay - ey * qax), hb = outer * (ex * qby - ey * qbx);  // heights over the line, times len
+    if (!(ha >= VIS_TWIN_REACH * len && hb >= VIS_TWIN_REACH * len)) return false;
+    const double la = sqrt(qax * qax + qay * qay), lb = sqrt(qbx * qbx + qby * qby);
+    // interior angles at a (between b - a and qa) and at b (between a - b and qb) of 30 degrees or more
+    return (ex * qax + ey * qay) <= VIS_TWIN_COS * len * la && -(ex * qbx + ey * qby) <= VIS_TWIN_COS * len * lb;
+}
+template <typename Store>
+__device__ inline void mark_twins(Store *cs, int s, int first, int stride) {
+    const int nvp = cs->nvs[s];
+    if (nvp > 32) return;
+    const double *px = cs->xy + cs->offs[s], *py = px + nvp;
+    const double outer_p = -(double)cs->sgns[s];  // a canvas edge's witness stands on the side -sgn of its direction
+    for (int c = first; c < s; c += stride) {
+        const int nvc = cs->nvs[c];
+        if (nvc > 32) continue;
+        const double *bp = cs->boxes + 4 * s, *bc = cs->boxes + 4 * c;
+        if (bc[1] < bp[0] || bc[0] > bp[1] || bc[3] < bp[2] || bc[2] > bp[3]) continue;
+        const double *cx = cs->xy + cs->offs[c], *cy = cx + nvc;
+        const double outer_c = -(double)cs->sgns[c];
+        for (int k = 0; k < nvc; ++k) {
+            const int k0 = k == 0 ? nvc - 1 : k - 1;
+            const double ax = cx[k0], ay = cy[k0], bx = cx[k], by = cy[k];
+            for (int j = 0; j < nvp; ++j) {
+                const int j0 = j == 0 ? nvp - 1 : j - 1;
+                const bool same = px[j0] == ax && py[j0] == ay && px[j] == bx && py[j] == by;
+                const bool reversed = px[j0] == bx && py[j0] == by && px[j] == ax && py[j] == ay;
+                if (!same && !reversed) continue;
+                // the new polygon over the outer side of the older one's edge k (a->b) ...
+                if (twin_covers(cs, s, j, reversed, ax, ay, bx, by, outer_c)) atomicOr(&cs->twin[c], 1u << k);
+                // ... and the older one over the outer side of the new polygon's edge j (its own direction)
+                if (twin_covers(cs, c, k, reversed, px[j0], py[j0], px[j], py[j], outer_p)) atomicOr(&cs->twin[s], 1u << j);
+            }
+        }
+    }
+}
+
 // ---- The covered-cell bitmap.  Nine candidates in ten are hidden behind ONE nearer polygon, and finding that out took
 // most of the painter's time although the answer is usually obvious: the candidate is a far wall a few cells of view
 // wide, the nearer polygon a wall that fills a tenth of the view.  So the (azimuth, polar) box of a face's candidates is
@@ -2208,6 +2286,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                         }
                         if (v == 1) {
                             if (wave_u == j && !in_place) move_staged(cs, slot_b, n_cs, used);
+                            if (threadIdx.x == 0) cs->twin[n_cs] = 0u;
                             __syncthreads();  // the moved ring is part of the canvas for what comes after
                             if (threadIdx.x == 0) {
                                 const int Bj = s_gB[j];
@@ -2223,6 +2302,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             used += nv2_j;
                             ++n_canvas;
                             ++shown;
+                            // the edges it shares with older canvas polygons (read by the next full decision, which
+                            // begins behind a barrier)
+                            mark_twins(cs, n_cs - 1, (int)threadIdx.x, (int)blockDim.x);
                             if (grid_on) {
                                 // (no fence: a test that does not see a bit yet only sends its candidate the usual way)
                                 grid_mark(cs, n_cs - 1, grid, s_gdom, (int)threadIdx.x, (int)blockDim.x);
