@@ -46,6 +46,14 @@ extern "C" int rt_debug_visibility_face_log(unsigned long long *out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vis_face_log), sizeof(unsigned long long) * 4 * (size_t)n) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef RT_VIS_STAMPS
+__device__ unsigned long long g_vis_hist[64];
+extern "C" int rt_debug_visibility_hist(unsigned long long *out64) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_vis_hist), sizeof(g_vis_hist)) != hipSuccess) return -1;
+    unsigned long long z[64] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_vis_hist), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int rt_debug_visibility_phases(unsigned long long *out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_vis_phase), sizeof(g_vis_phase)) != hipSuccess) return -1;
     unsigned long long z[16] = {0};
@@ -1284,8 +1292,23 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
             }
         }
         if (!(t_hi > t_lo)) continue;  // it passes B's box by
-        if (edge_has_witness(ps, li, ax, ay, ex_, ey_, side, true, splits, lds_count, tile, t_lo, t_hi) && lane == 0)
-            *flag = 1;
+#ifdef RT_VIS_STAMPS
+        const unsigned long long t_ex0 = wall_clock64();
+#endif
+        const bool w_found = edge_has_witness(ps, li, ax, ay, ex_, ey_, side, true, splits, lds_count, tile, t_lo, t_hi);
+#ifdef RT_VIS_STAMPS
+        if (lane == 0) {
+            const unsigned long long dt = wall_clock64() - t_ex0;
+            const int ns = *lds_count;  // cuts of the examined part
+            int b = 0;
+            while (b < 7 && (1 << b) < ns) ++b;  // 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, more
+            int c = 0;
+            while (c < 3 && (8 << c) < n) ++c;  // entries: up to 8, 16, 32, more
+            atomicAdd(&g_vis_hist[8 * c + b], dt);
+            atomicAdd(&g_vis_hist[32 + 8 * c + b], 1ull);
+        }
+#endif
+        if (w_found && lane == 0) *flag = 1;
     }
     __syncthreads();
     PHASE(4);
