@@ -1136,14 +1136,18 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
             splits.pstate[lane] = (tile.holds(px, py) && pip_ring(x, y, nv, px, py)) ? 1 : 0;
         }
         __builtin_amdgcn_wave_barrier();
+        // the samples are dealt to the waves (wave w holds samples w, w + n_waves, ... against every other entry): all
+        // waves used to make all the tests, and a barrier costs less than three quarters of them
         const int per_sample = n - 1;
-        const int n_pairs = n_samples * per_sample;
+        const int my_samples = wave < n_samples ? (n_samples - wave + n_waves - 1) / n_waves : 0;
+        const int n_pairs = my_samples * per_sample;
         const SmallDivisor by_sample(per_sample > 0 ? per_sample : 1);
         for (int base = 0; base < n_pairs; base += 64) {
             const int pair = base + lane;
             if (pair < n_pairs) {
                 int sidx, li;
                 by_sample.split(pair, sidx, li);
+                sidx = wave + sidx * n_waves;
                 li += 1;
                 if (splits.pstate[sidx]) {
                     const double px = splits.px[sidx], py = splits.py[sidx];
@@ -1161,8 +1165,17 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
             }
         }
         __builtin_amdgcn_wave_barrier();
-        visible = __any(lane < n_samples && splits.pstate[lane] != 0);
-        if (visible && lane == 0) VIS_STAT(4, 1);
+        // (a sample without another entry to be held against, per_sample = 0, stands as it is: wave 0 reports those)
+        const bool mine = lane < n_samples && (per_sample == 0 ? wave == 0 : lane % n_waves == wave) && splits.pstate[lane] != 0;
+        // The flag says 2 for a sample, 1 for a witness on an edge: a wave that is quick to leave the barrier may find
+        // a witness on one of B's own edges before a slow one has read the flag, and only a 2 may send a wave out of
+        // here (every wave has to take the same way through the barriers).
+        if (__any(mine) && lane == 0) {
+            VIS_STAT(4, 1);
+            *flag = 2;
+        }
+        __syncthreads();
+        visible = *(volatile int *)flag == 2;
     }
     PHASE(1);
     if (visible) return true;
@@ -1175,7 +1188,12 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
     }
     __syncthreads();
     PHASE(2);
-    if (*(volatile int *)flag) return true;
+    // (only a witness on one of B's own edges, a 1, sends the waves out here: a wave that is quick to leave the barrier
+    // can have found a witness on another entry's edge, a 4, before a slow one reads the flag, and a wave that left here
+    // on that would miss the barrier below while the quick one waits in it.  This was so from the first version of this
+    // routine and went unseen because few decisions end with such a witness; cut into small tiles, whose borders are
+    // examined like edges and often hold one, a painting in a dozen came out wrong or did not end.)
+    if (*(volatile int *)flag == 1) return true;
     // ---- edges of the other entries that enter B (an endpoint inside B or a crossing with B's ring): collected with
     // lanes = entries, then examined one by one, witness on their outer side
     int n_work = 0;
@@ -1308,7 +1326,7 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
             atomicAdd(&g_vis_hist[32 + 8 * c + b], 1ull);
         }
 #endif
-        if (w_found && lane == 0) *flag = 1;
+        if (w_found && lane == 0) *flag = 4;
     }
     __syncthreads();
     PHASE(4);
