@@ -2681,7 +2681,7 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         }
         // A half or a quarter of a large scene's faces (a rank's share on two to five GPUs): the 64 faces with the most
         // candidates go in tiles of 1 024 all the same.  Painted whole the share lasts as long as its longest face (lln:
-        // 100-130 ms whatever the share), in tiles a quarter of the rows takes 100 instead of 126 ms and a half 120
+        // 100-130 ms whatever the share), in tiles a quarter of the rows takes 84 instead of 126 ms and a half 124
         // instead of 132; tiles for every face of 4 096 candidates and more, as for smaller shares, would double the
         // work (a half: 167 ms).  The whole scene on one GPU is bound by its work, not by its longest face: no tiles.
         const int top_faces = 64, top_per_tile = 1024;
@@ -2696,13 +2696,10 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         item_off = (const int32_t *)job.b_itemoff.p;
     }
     if (job.ev[2]) RT_HIP(hipEventRecord(job.ev[2], st));
-    // The bitmap inside tiles is switched off.  It took an eighth of lln's rows from 87-91 to 78-88 ms, and with tiles of
-    // 1 024 candidates every share of those rows on 2, 4 and 8 ranks equalled the rows painted whole; but with tiles of
-    // 256 forced on an eighth (14 000 tiles a painting) one painting in a dozen differed in a few entries and one did
-    // not end, and the cause has not been found.  At that rate per tile the library's own tile sizes would fail one
-    // painting in a few hundred, which thirty good ones do not rule out: so tiles are painted without the bitmap, as
-    // they were before it was tried (the kernel keeps the switch).
-    const int grid_in_tiles = 0;
+    // The bitmap inside the tiles of four-wave workgroups (an eighth of lln's rows 91-94 -> 75-80 ms).  It was off for a
+    // while: with it, small forced tiles once gave a wrong painting and one that did not end; the cause was the flag of
+    // the full decision (polygon_uncovered), not the bitmap.
+    const int grid_in_tiles = 1;
     PaintScratch ps{(int32_t *)b_list.p, (int32_t *)b_canvas.p, (double *)b_cbox.p, (double *)b_splits.p, split_cap,
                     (int32_t *)b_work.p, (int32_t *)job.b_tlist.p, (uint32_t *)job.b_grid.p,
                     (int32_t *)job.b_chunk.p, grid_in_tiles};
