@@ -306,6 +306,35 @@ def test_every_share_of_the_lln_rows_is_the_oracles(places):
             assert len(bad) == 0, f"world {world} rank {rank}: {len(bad)} entries differ, first {bad[:10].tolist()}"
 
 
+def test_small_tiles_on_a_share_of_the_lln_rows(places):
+    """An eighth of lln's rows with every face of 512 candidates and more forced into tiles of 256 (some 14 000 tiles,
+    whose borders are examined like edges): the oracle's rows, painting after painting.  Before the phases of a full
+    decision wrote flag values of their own, one such painting in a dozen came out wrong or did not end."""
+    import os
+
+    import torch
+
+    from conftest import GOLDEN
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import multithread_solve as mts
+
+    z = np.load(os.path.join(GOLDEN, "lln_matrix_rows.npz"))
+    n = int(z["n"])
+    want = np.unpackbits(z["bits"])[: n * n].reshape(n, n).astype(bool)
+    scene = geom.scene_arrays_of(places("lln").get_polygons_list()).device_scene()
+    mine = np.arange(0, n, 8)
+    try:
+        scene.set_visibility_tiling(512, 256)
+        for rep in range(4):
+            block = mts.paint_dealt_block_on_device(scene, [], False, 8, 0)
+            torch.cuda.synchronize()
+            got = block.cpu().numpy()[: len(mine)].astype(bool)
+            bad = np.argwhere(got != want[mine])
+            assert len(bad) == 0, f"painting {rep}: {len(bad)} entries differ, first {bad[:10].tolist()}"
+    finally:
+        scene.set_visibility_tiling(-1, 0)
+
+
 @pytest.mark.parametrize("name", ["small", "ny", "place_levant", "place_saint_jean/place_saint_jean"])
 def test_sharp_edges_match_oracle(places, name):
     from oracle import geometry_oracle as go
