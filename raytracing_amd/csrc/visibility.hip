@@ -2679,12 +2679,13 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
                 tile_size = 1024;
             }
         }
-        // A half or a quarter of a large scene's faces (a rank's share on two to five GPUs): the 64 faces with the most
-        // candidates go in tiles of 1 024 all the same.  Painted whole the share lasts as long as its longest face (lln:
-        // 100-130 ms whatever the share), in tiles a quarter of the rows takes 84 instead of 126 ms and a half 124
+        // A half or a quarter of a large scene's faces (a rank's share on two to five GPUs): the 128 faces with the most
+        // candidates go in tiles of 2 048 all the same (64 faces in tiles of 1 024: a half 117-124 ms, a quarter 84-88).
+        // Painted whole the share lasts as long as its longest face (lln:
+        // 100-130 ms whatever the share), in tiles a quarter of the rows takes 80 instead of 126 ms and a half 111
         // instead of 132; tiles for every face of 4 096 candidates and more, as for smaller shares, would double the
         // work (a half: 167 ms).  The whole scene on one GPU is bound by its work, not by its longest face: no tiles.
-        const int top_faces = 64, top_per_tile = 1024;
+        const int top_faces = 128, top_per_tile = 2048;
         const bool top_sectors = scene->vis_tile_min < 0 && n_faces > 256 && tile_size == 0 && n_faces * 2 <= sc.n + 1;
         hipLaunchKernelGGL(k_vis_tiles, dim3(n_faces), dim3(VIS_TILE_THREADS), 0, st, sc.n, (const PolyMeta *)b_meta.p,
                            (const int32_t *)b_order.p, m_stride, (const int32_t *)b_counts.p, tile_min, tile_size, face_queue,
