@@ -2495,7 +2495,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
             if (slot < VIS_FACE_LOG) {
                 g_vis_face_log[4 * slot] = t_item;
                 g_vis_face_log[4 * slot + 1] = t_end - t_item;
-                g_vis_face_log[4 * slot + 2] = (unsigned long long)m;
+                g_vis_face_log[4 * slot + 2] = (unsigned long long)m | ((unsigned long long)s_tile << 32) |
+                                               ((unsigned long long)(span.bounded() ? 1 : 0) << 48);
                 g_vis_face_log[4 * slot + 3] = (unsigned long long)n_canvas;
             }
         }

@@ -43,7 +43,7 @@ if hasattr(_lib.load(), "rt_debug_visibility_face_log"):
     _lib.load().rt_debug_visibility_face_log(ctypes.c_void_p(log.ctypes.data), n)
     start = (log[:, 0] - log[:, 0].min()).astype(float) / 1e5
     dur = log[:, 1].astype(float) / 1e5
-    cand, shown = log[:, 2].astype(int), log[:, 3].astype(int)
+    cand, shown = (log[:, 2] & np.uint64(0xffffffff)).astype(int), log[:, 3].astype(int)  # (high bits: tile number)
     end = start + dur
     print(f"faces: span {end.max():.1f} ms; durations: mean {dur.mean():.2f}, p50 {np.median(dur):.2f}, p99 {np.percentile(dur, 99):.1f}, max {dur.max():.1f} ms")
     for f in np.argsort(-dur)[:12]:

@@ -40,10 +40,10 @@ for f in range(6):
     sel[(f + 1) * T:] = False
     if not sel.any():
         continue
-    print(f"screen {f}: {int(sel.sum())} items, candidates per item mean {log[sel, 2].mean():.0f} max {log[sel, 2].max()}, visible per item mean "
+    print(f"screen {f}: {int(sel.sum())} items, candidates per item mean {(log[sel, 2] & np.uint64(0xffffffff)).mean():.0f} max {(log[sel, 2] & np.uint64(0xffffffff)).max()}, visible per item mean "
           f"{log[sel, 3].mean():.1f} max {log[sel, 3].max()}; item time mean {dur[sel].mean():.2f} max {dur[sel].max():.2f} ms, sum {dur[sel].sum():.1f} ms; "
           f"first start {start[sel].min():.2f}, last end {(start[sel] + dur[sel]).max():.2f} ms", flush=True)
 order = np.argsort(-dur)[:10]
 for i in order:
-    print(f"  item (screen {i // T}, sector {i % T}): start {start[i]:.2f}, lasts {dur[i]:.2f} ms, candidates {log[i, 2]}, visible {log[i, 3]}")
+    print(f"  item (screen {i // T}, sector {i % T}): start {start[i]:.2f}, lasts {dur[i]:.2f} ms, candidates {int(log[i, 2]) & 0xffffffff}, visible {log[i, 3]}")
 print(f"all items: sum {dur[used].sum():.1f} ms over {int(used.sum())} items; span {(start[used] + dur[used]).max():.1f} ms")

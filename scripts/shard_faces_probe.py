@@ -30,6 +30,7 @@ dur = log[:, 1].astype(float) / 1e5
 end = start + dur
 print(f"{int(used.sum())} faces logged (a face in sectors: its last item); span {end[used].max():.1f} ms; sum of the logged times {dur[used].sum():.0f} ms")
 for f in np.argsort(-end)[:12]:
-    print(f"  ends last: face {f}: start {start[f]:.1f}, lasts {dur[f]:.1f} ms, candidates {log[f, 2]}, visible {log[f, 3]}")
+    print(f"  ends last: face {f}: start {start[f]:.1f}, lasts {dur[f]:.1f} ms, candidates {int(log[f, 2]) & 0xffffffff}, visible {log[f, 3]}, "
+          f"tile {(int(log[f, 2]) >> 32) & 0xffff}{' (in tiles)' if (int(log[f, 2]) >> 48) & 1 else ' (whole)'}")
 for t in (10, 25, 50, 75, 100):
     print(f"  at {t} ms: {int((used & (start <= t) & (end > t)).sum())} in flight, {int((used & (start > t)).sum())} not started")
