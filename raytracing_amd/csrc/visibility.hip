@@ -47,10 +47,10 @@ extern "C" int rt_debug_visibility_face_log(unsigned long long *out, int n) {
 }
 #endif
 #ifdef RT_VIS_STAMPS
-__device__ unsigned long long g_vis_hist[64];
-extern "C" int rt_debug_visibility_hist(unsigned long long *out64) {
-    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_vis_hist), sizeof(g_vis_hist)) != hipSuccess) return -1;
-    unsigned long long z[64] = {0};
+__device__ unsigned long long g_vis_hist[96];
+extern "C" int rt_debug_visibility_hist(unsigned long long *out96) {
+    if (hipMemcpyFromSymbol(out96, HIP_SYMBOL(g_vis_hist), sizeof(g_vis_hist)) != hipSuccess) return -1;
+    unsigned long long z[96] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_vis_hist), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -2320,7 +2320,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             v = s_again[j];
                             if (v == VIS_UNSETTLED) {
                                 const CanvasSet<Store> cv{cs, cs->list, cs->lpre, n_cs, s_nlist + 1};
+#ifdef RT_VIS_STAMPS
+                                const unsigned long long t_dec = wall_clock64();
+#endif
                                 v = polygon_uncovered(cv, splits, lds_count, work, &s_flag, span, true) ? 1 : 0;
+#ifdef RT_VIS_STAMPS
+                                if (threadIdx.x == 0) {
+                                    // (measurement) by the width of the candidate's box: up to 0.25, 0.5, 1, 2, 4 rad, more
+                                    const double wbox = cs->boxes[4 * n_cs + 1] - cs->boxes[4 * n_cs];
+                                    int c = 0;
+                                    while (c < 5 && wbox > 0.25 * (1 << c)) ++c;
+                                    atomicAdd(&g_vis_hist[64 + c], wall_clock64() - t_dec);
+                                    atomicAdd(&g_vis_hist[72 + c], 1ull);
+                                    atomicAdd(&g_vis_hist[80 + c], (unsigned long long)(v ? 1 : 0));
+                                }
+#endif
                                 __syncthreads();  // the flag and the list are the next unsettled candidate's after this
                             }
                             in_place = true;

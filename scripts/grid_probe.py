@@ -28,11 +28,13 @@ if hasattr(_lib.load(), "rt_debug_visibility_phases"):
     full = sum(ph[2 * i] for i in range(5))
     print("full decisions: " + ", ".join(f"{nm} {ph[2 * i] / 1e5:.1f} ms x{ph[2 * i + 1]}" for i, nm in enumerate(names)), flush=True)
     if hasattr(_lib.load(), "rt_debug_visibility_hist"):
-        hh = (ctypes.c_ulonglong * 64)()
+        hh = (ctypes.c_ulonglong * 96)()
         _lib.load().rt_debug_visibility_hist(hh)
         print("examinations of canvas edges by entries of the decision (rows: <=8, <=16, <=32, more) and cuts of the part (1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, more): wave-ms / count")
         for c in range(4):
             print("   " + "  ".join(f"{hh[8 * c + b] / 1e5:8.0f}/{hh[32 + 8 * c + b]:<8d}" for b in range(8)))
+        print("full decisions by the width of the candidate's box (up to 0.25, 0.5, 1, 2, 4 rad, more): workgroup-ms / count / found visible")
+        print("   " + "  ".join(f"{hh[64 + c] / 1e5:8.0f}/{hh[72 + c]}/{hh[80 + c]}" for c in range(6)))
     print(f"faces: {ph[12] / 1e5:.1f} ms summed over the workgroups (longest {ph[13] / 1e5:.2f} ms), of which full decisions "
           f"{full / 1e5:.1f} ms; span of the launch {(ph[14] - ph[15]) / 1e5:.1f} ms", flush=True)
 if hasattr(_lib.load(), "rt_debug_visibility_face_log"):
