@@ -704,6 +704,18 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
     const double ex = bx - ax, ey = by - ay;
     const double len = sqrt(ex * ex + ey * ey);
     if (!(len > VIS_MIN_PIECE)) return false;
+#if defined(RT_VIS_STAMPS) && !defined(RT_VIS_ITEMS_ONLY)
+    unsigned long long t_st = clock64();
+    const bool ex_on = ((t_st >> 5) & 63ull) == 0ull;  // one examination in 64: every one of them would queue on five words
+#define EX_STAMP(i)                                                          \
+    do {                                                                     \
+        const unsigned long long now_ = clock64();                           \
+        if (lane == 0 && ex_on) atomicAdd(&g_vis_hist[86 + (i)], now_ - t_st); \
+        t_st = now_;                                                         \
+    } while (0)
+#else
+#define EX_STAMP(i)
+#endif
     // ---- gather the cuts: lanes = entries, each walks its own ring
     if (lane == 0) {
         int k = 1;
@@ -785,6 +797,7 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
         }
     }
     __builtin_amdgcn_wave_barrier();
+    EX_STAMP(0);
     int n_splits = *lds_count;
     n_splits = __builtin_amdgcn_readfirstlane(n_splits);
     if (n_splits > SPLIT_LDS) __threadfence_block();
@@ -811,6 +824,7 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
             splits.py[lane] = wy;
             splits.pstate[lane] = ((t1 - t0) * len > VIS_MIN_PIECE && tile.holds(wx, wy)) ? 1 : 0;
         }
+        EX_STAMP(1);
         // only an entry whose box reaches the edge's can hold a witness (they stand VIS_DELTA beside the edge): those
         // are listed first, in the part of the cut buffer that this few cuts leave free (B itself, when the witnesses
         // have to be inside it, is always listed)
@@ -839,14 +853,18 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
         }
         const bool listed = n_near <= near_cap;
         __builtin_amdgcn_wave_barrier();
+        EX_STAMP(2);
         const int per_piece = listed ? n_near : n - first;
         const int n_pairs = n_splits * per_piece;
-        const SmallDivisor by_piece(per_piece > 0 ? per_piece : 1);
+        // entry by entry, every piece at once: most pieces lie inside one of the first few entries, and a piece that
+        // has been found covered is not tested again; when none is left the edge has no witness
+        const SmallDivisor by_entry(n_splits);
         for (int base = 0; base < n_pairs; base += 64) {
+            if (!__any(lane < n_splits && splits.pstate[lane] != 0)) break;
             const int pair = base + lane;
             if (pair < n_pairs) {
                 int j, at;
-                by_piece.split(pair, j, at);
+                by_entry.split(pair, at, j);
                 const int i = listed ? near_list[at] : first + at;
                 if (splits.pstate[j]) {
                     const double wx = splits.px[j], wy = splits.py[j];
@@ -862,6 +880,7 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
             }
         }
         __builtin_amdgcn_wave_barrier();
+        EX_STAMP(3);
         return __any(lane < n_splits && splits.pstate[lane] != 0);
     }
     bool found = false;
@@ -879,6 +898,7 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
         }
         found = __any(mine);
     }
+    EX_STAMP(4);
     return found;
 }
 
@@ -2700,9 +2720,14 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         // Painted whole the share lasts as long as its longest face (lln:
         // 100-130 ms whatever the share), in tiles a quarter of the rows takes 80 instead of 126 ms and a half 111
         // instead of 132; tiles for every face of 4 096 candidates and more, as for smaller shares, would double the
-        // work (a half: 167 ms).  The whole scene on one GPU is bound by its work, not by its longest face: no tiles.
-        const int top_faces = 128, top_per_tile = 2048;
-        const bool top_sectors = scene->vis_tile_min < 0 && n_faces > 256 && tile_size == 0 && n_faces * 2 <= sc.n + 1;
+        // work (a half: 167 ms).
+        // The whole scene on one GPU is bound by its work but for the one or two faces that see all of it (lln's
+        // ground polygon: 7 605 candidates, 121 ms whole while every other face is done after 100): the four faces
+        // with the most candidates go in tiles of 1 024 (lln's matrix 117 -> 94 ms; 1 to 64 faces in tiles of 512 to
+        // 2 048 all give 94-96).
+        const bool share = n_faces * 2 <= sc.n + 1;
+        const int top_faces = share ? 128 : 4, top_per_tile = share ? 2048 : 1024;
+        const bool top_sectors = scene->vis_tile_min < 0 && n_faces > 256 && tile_size == 0;
         hipLaunchKernelGGL(k_vis_tiles, dim3(n_faces), dim3(VIS_TILE_THREADS), 0, st, sc.n, (const PolyMeta *)b_meta.p,
                            (const int32_t *)b_order.p, m_stride, (const int32_t *)b_counts.p, tile_min, tile_size, face_queue,
                            top_sectors ? std::min(top_faces, n_faces) : 0, top_sectors ? top_per_tile : 0,

@@ -35,6 +35,8 @@ if hasattr(_lib.load(), "rt_debug_visibility_phases"):
             print("   " + "  ".join(f"{hh[8 * c + b] / 1e5:8.0f}/{hh[32 + 8 * c + b]:<8d}" for b in range(8)))
         print("full decisions by the width of the candidate's box (up to 0.25, 0.5, 1, 2, 4 rad, more): workgroup-ms / count / found visible")
         print("   " + "  ".join(f"{hh[64 + c] / 1e5:8.0f}/{hh[72 + c]}/{hh[80 + c]}" for c in range(6)))
+        print("inside an examination (own and other entries' edges), shader cycles / 1e9: " + ", ".join(
+            f"{nm} {hh[86 + i] / 1e9:.1f}" for i, nm in enumerate(["gathering the cuts", "pieces", "entries near the part", "(piece, entry) tests", "more than 64 cuts"])))
     print(f"faces: {ph[12] / 1e5:.1f} ms summed over the workgroups (longest {ph[13] / 1e5:.2f} ms), of which full decisions "
           f"{full / 1e5:.1f} ms; span of the launch {(ph[14] - ph[15]) / 1e5:.1f} ms", flush=True)
 if hasattr(_lib.load(), "rt_debug_visibility_face_log"):
