@@ -47,10 +47,11 @@ extern "C" int rt_debug_visibility_face_log(unsigned long long *out, int n) {
 }
 #endif
 #ifdef RT_VIS_STAMPS
-__device__ unsigned long long g_vis_hist[96];
-extern "C" int rt_debug_visibility_hist(unsigned long long *out96) {
-    if (hipMemcpyFromSymbol(out96, HIP_SYMBOL(g_vis_hist), sizeof(g_vis_hist)) != hipSuccess) return -1;
-    unsigned long long z[96] = {0};
+#define VIS_HIST_ADD(i, v) atomicAdd(&g_vis_hist[i], v)
+__device__ unsigned long long g_vis_hist[128];
+extern "C" int rt_debug_visibility_hist(unsigned long long *out128) {
+    if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_vis_hist), sizeof(g_vis_hist)) != hipSuccess) return -1;  // 128 words
+    unsigned long long z[128] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_vis_hist), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -2155,6 +2156,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
         bool resident = true;
         while (k < m && resident) {
             const int chunk_n = m - k < VIS_STRETCH ? m - k : VIS_STRETCH;
+#if defined(RT_VIS_STAMPS) && !defined(RT_VIS_ITEMS_ONLY)
+            unsigned long long t_g = clock64();
+#define G_STAMP(i, on)                                                                 \
+    do {                                                                               \
+        const unsigned long long now_ = clock64();                                     \
+        if (lane == 0 && (on)) atomicAdd(&g_vis_hist[96 + (i)], now_ - t_g);           \
+        t_g = now_;                                                                    \
+    } while (0)
+#else
+#define G_STAMP(i, on)
+#endif
             {
                 int B = -1;
                 bool keep = false;
@@ -2182,6 +2194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                 __syncthreads();
             }
             const int m_c = __builtin_amdgcn_readfirstlane(s_mc);
+            G_STAMP(6, wave_u == 0);
             if (threadIdx.x == 0 && grid_on) {  // (two updates per stretch of 256 candidates: kept in every build)
                 atomicAdd(&g_vis_stats[6], (unsigned long long)chunk_n);
                 atomicAdd(&g_vis_stats[7], (unsigned long long)(chunk_n - m_c));
@@ -2213,6 +2226,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     }
                     const int mine = kc + wave_u;
                     const bool have = mine < m_c;
+#if defined(RT_VIS_STAMPS) && !defined(RT_VIS_ITEMS_ONLY)
+                    const bool g_on = ((kc / NW) & 7) == 0;  // (profiling builds: one group in eight is timed)
+                    G_STAMP(7, false);
+                    if (lane == 0 && g_on && wave_u == 0) VIS_HIST_ADD(127, 1ull);
+#endif
                     const int B = have ? place(mine, kc) : 0;
                     PolyMeta mb;
                     {
@@ -2239,6 +2257,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                         s_gB[wave_u] = B;
                     }
                     __syncthreads();
+                    G_STAMP(0, g_on);
                     int before = 0, total = 0;  // coordinates the group's earlier members / all its members stage
                     for (int w = 0; w < NW; ++w) {
                         const int c = s_gnv[w];
@@ -2283,22 +2302,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             VIS_STAT(0, 1);
                             VIS_STAT(1, n_list);
                         }
+                        G_STAMP(1, g_on);
                         if (n_list > VIS_WAVE_LIST) {
                             verdict = VIS_UNSETTLED;
                         } else {
                             canvas_prefix(cs, my_list, n_list, nv2 / 2, my_lpre);
                             __builtin_amdgcn_wave_barrier();
                             verdict = shortcuts_alone(cs, my_list, my_lpre, slot_b, n_list, span);
+                            G_STAMP(2, g_on);
                             // hidden behind the canvas as it stood, and the bitmap had not said so: the cells inside it
                             // are covered too (by this wave, now: once the verdicts are gone through, a member that
                             // shows is moved over the staged rings of the members before it)
                             if (verdict == 0 && grid_on) grid_mark(cs, slot_b, grid, s_gdom, lane, 64);
+                            G_STAMP(3, g_on);
                         }
                     }
                     if (lane == 0) s_verdict[wave_u] = verdict;
                     __syncthreads();
+                    G_STAMP(4, g_on);
                     // ---- the group's verdicts in order
                     int shown = 0;
+#if defined(RT_VIS_STAMPS) && !defined(RT_VIS_ITEMS_ONLY)
+                    const unsigned long long t_keep = t_g;  // (the finer stamps below move t_g; the loop's own stamp counts from here)
+#endif
                     for (int j = 0; j < NW && kc + j < m_c; ++j) {
                         int v = s_verdict[j];
                         const int nv2_j = s_gnv[j];
@@ -2337,6 +2363,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                                 }
                             }
                             __syncthreads();
+                            G_STAMP(8, g_on && wave_u == 0);
                             v = s_again[j];
                             if (v == VIS_UNSETTLED) {
                                 const CanvasSet<Store> cv{cs, cs->list, cs->lpre, n_cs, s_nlist + 1};
@@ -2356,6 +2383,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                                 }
 #endif
                                 __syncthreads();  // the flag and the list are the next unsettled candidate's after this
+                                G_STAMP(9, g_on && wave_u == 0);
                             }
                             in_place = true;
                         }
@@ -2379,11 +2407,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             ++shown;
                             // the edges it shares with older canvas polygons (read by the next full decision, which
                             // begins behind a barrier)
+                            G_STAMP(10, g_on && wave_u == 0);
                             mark_twins(cs, n_cs - 1, (int)threadIdx.x, (int)blockDim.x);
+                            G_STAMP(11, g_on && wave_u == 0);
                             if (grid_on) {
                                 // (no fence: a test that does not see a bit yet only sends its candidate the usual way)
                                 grid_mark(cs, n_cs - 1, grid, s_gdom, (int)threadIdx.x, (int)blockDim.x);
                             }
+                            G_STAMP(12, g_on && wave_u == 0);
                         } else if (grid_on && in_place && nv2_j > 0) {
                             // hidden by the full decision, and the bitmap had not said so: the cells inside it are
                             // covered too (its ring is in the slot it was moved to, which the next member that shows
@@ -2397,6 +2428,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     xy0 = xy1;
                     kc += NW;
                     __syncthreads();  // the staging slots and the verdicts are rewritten by the next group
+#if defined(RT_VIS_STAMPS) && !defined(RT_VIS_ITEMS_ONLY)
+                    t_g = t_keep;
+#endif
+                    G_STAMP(5, g_on);
                 }
             }
             k += chunk_n;

@@ -28,7 +28,7 @@ if hasattr(_lib.load(), "rt_debug_visibility_phases"):
     full = sum(ph[2 * i] for i in range(5))
     print("full decisions: " + ", ".join(f"{nm} {ph[2 * i] / 1e5:.1f} ms x{ph[2 * i + 1]}" for i, nm in enumerate(names)), flush=True)
     if hasattr(_lib.load(), "rt_debug_visibility_hist"):
-        hh = (ctypes.c_ulonglong * 96)()
+        hh = (ctypes.c_ulonglong * 128)()
         _lib.load().rt_debug_visibility_hist(hh)
         print("examinations of canvas edges by entries of the decision (rows: <=8, <=16, <=32, more) and cuts of the part (1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, more): wave-ms / count")
         for c in range(4):
@@ -37,6 +37,12 @@ if hasattr(_lib.load(), "rt_debug_visibility_phases"):
         print("   " + "  ".join(f"{hh[64 + c] / 1e5:8.0f}/{hh[72 + c]}/{hh[80 + c]}" for c in range(6)))
         print("inside an examination (own and other entries' edges), shader cycles / 1e9: " + ", ".join(
             f"{nm} {hh[86 + i] / 1e9:.1f}" for i, nm in enumerate(["gathering the cuts", "pieces", "entries near the part", "(piece, entry) tests", "more than 64 cuts"])))
+        names_g = ["waiting for the group to gather", "listing and staging", "the shortcuts", "marking cells", "waiting for the group's verdicts",
+                   "going through the verdicts (full decisions with them)", "a stretch's bitmap tests (every stretch, wave 0)"]
+        print(f"a group of candidates, one in eight timed ({hh[127]} groups), shader cycles / 1e9 summed over the waves: " + ", ".join(
+            f"{nm} {hh[96 + i] / 1e9:.2f}" for i, nm in enumerate(names_g)))
+        names_v = ["a member made ready for its full decision", "the full decision", "a member that shows, until it is on the canvas", "its shared edges", "its cells"]
+        print("  inside the verdicts, wave 0 only: " + ", ".join(f"{nm} {hh[104 + i] / 1e9:.2f}" for i, nm in enumerate(names_v)))
     print(f"faces: {ph[12] / 1e5:.1f} ms summed over the workgroups (longest {ph[13] / 1e5:.2f} ms), of which full decisions "
           f"{full / 1e5:.1f} ms; span of the launch {(ph[14] - ph[15]) / 1e5:.1f} ms", flush=True)
 if hasattr(_lib.load(), "rt_debug_visibility_face_log"):
