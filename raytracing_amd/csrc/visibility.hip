@@ -811,13 +811,21 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
         // lanes = pieces: the witness point of each; then lanes = (piece, entry) pairs: a witness outside B (when it has
         // to be inside) or inside another entry proves nothing.  Same tests as witness_uncovered, spread over the lanes
         // instead of one lane walking every entry.
-        if (lane < n_splits) {
-            const double t0 = splits.get(lane);
-            double t1 = t_hi;
+        // (the cuts are few enough for a lane each: the next larger one is found from the lanes' registers, every lane
+        // taking part, instead of every lane reading every cut from LDS)
+        const double t0 = lane < n_splits ? splits.lds[lane] : INFINITY;
+        double t1 = t_hi;
+        {
+            const long long bits = __double_as_longlong(t0);
+            const int lo = (int)bits, hi = (int)(bits >> 32);
             for (int i = 0; i < n_splits; ++i) {
-                const double ti = splits.get(i);
+                const unsigned long long b = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(lo, i) |
+                                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, i) << 32);
+                const double ti = __longlong_as_double((long long)b);
                 if (ti > t0 && ti < t1) t1 = ti;
             }
+        }
+        if (lane < n_splits) {
             const double tm = 0.5 * (t0 + t1);
             const double wx = ax + tm * ex - side * VIS_DELTA * (ey / len);
             const double wy = ay + tm * ey + side * VIS_DELTA * (ex / len);
@@ -1860,15 +1868,22 @@ __device__ inline void mark_twins(Store *cs, int s, int first, int stride) {
         for (int k = 0; k < nvc; ++k) {
             const int k0 = k == 0 ? nvc - 1 : k - 1;
             const double ax = cx[k0], ay = cy[k0], bx = cx[k], by = cy[k];
-            for (int j = 0; j < nvp; ++j) {
-                const int j0 = j == 0 ? nvp - 1 : j - 1;
-                const bool same = px[j0] == ax && py[j0] == ay && px[j] == bx && py[j] == by;
-                const bool reversed = px[j0] == bx && py[j0] == by && px[j] == ax && py[j] == ay;
-                if (!same && !reversed) continue;
-                // the new polygon over the outer side of the older one's edge k (a->b) ...
-                if (twin_covers(cs, s, j, reversed, ax, ay, bx, by, outer_c)) atomicOr(&cs->twin[c], 1u << k);
-                // ... and the older one over the outer side of the new polygon's edge j (its own direction)
-                if (twin_covers(cs, c, k, reversed, px[j0], py[j0], px[j], py[j], outer_p)) atomicOr(&cs->twin[s], 1u << j);
+            // (looked for through the vertex of the new polygon that is b: nearly every pair of polygons has no vertex
+            // in common, and this way that costs one comparison per pair of vertices)
+            for (int m = 0; m < nvp; ++m) {
+                if (px[m] != bx || py[m] != by) continue;
+                const int m0 = m == 0 ? nvp - 1 : m - 1, m1 = m + 1 == nvp ? 0 : m + 1;
+                for (int way = 0; way < 2; ++way) {
+                    // the new polygon's edge j, from j0 to j: a->b itself (it ends in m), or b->a (it starts in m)
+                    const bool reversed = way == 1;
+                    const int j = reversed ? m1 : m, j0 = reversed ? m : m0;
+                    const int at_a = reversed ? m1 : m0;
+                    if (px[at_a] != ax || py[at_a] != ay) continue;
+                    // the new polygon over the outer side of the older one's edge k (a->b) ...
+                    if (twin_covers(cs, s, j, reversed, ax, ay, bx, by, outer_c)) atomicOr(&cs->twin[c], 1u << k);
+                    // ... and the older one over the outer side of the new polygon's edge j (its own direction)
+                    if (twin_covers(cs, c, k, reversed, px[j0], py[j0], px[j], py[j], outer_p)) atomicOr(&cs->twin[s], 1u << j);
+                }
             }
         }
     }
