@@ -32,6 +32,7 @@
 #define VIS_DELTA 2.5e-10    /* witness offset from its edge, radians */
 #define VIS_MIN_PIECE 1e-9   /* shorter pieces of an edge are not examined */
 #define VIS_ON_LINE 1e-9     /* an endpoint this close to an edge's line cuts the edge at its foot */
+#define VIS_RING_MARGIN 1e-8 /* ring edges this near a polygon's box are listed for its decision (the examined parts reach 4 VIS_ON_LINE out of the box, a cutting end lies VIS_ON_LINE from them) */
 
 // Work counters of the painter (candidates, listed polygons, edges examined, pieces examined, shortcut hits, polygons
 // shown visible, edge_has_witness calls from canvas edges, cut gathers), summed over a launch; read by the profiling scripts.
@@ -480,7 +481,7 @@ struct PaintScratch {
     double *cbox;     // per wave [n*4]: their boxes (xmin, xmax, ymin, ymax)
     double *splits;   // per wave [split_cap]
     int64_t split_cap;
-    int32_t *work;    // per wave [2 * vtot]: (entry, vertex) of canvas edges that enter the current polygon
+    int32_t *work;    // per wave [3 * vtot]: (entry, vertex) of canvas edges that enter the current polygon, then the ring list
     int32_t *tlist;   // per workgroup [n]: candidates of the tile being painted
     uint32_t *grid;   // per workgroup [VIS_GRID_WORDS]: the covered-cell bitmap of the face being painted
     int32_t *chunk;   // per workgroup [1024]: the candidates of the current stretch that are left to paint
@@ -685,6 +686,7 @@ struct SplitBuf {
     int64_t cap;
     double *px, *py; // [PIECE_LDS] witness points of the pieces of the edge being examined
     int *pstate;     // [PIECE_LDS] 1 while the witness is still a proof of visibility
+    int32_t *ring;   // [vtot] the ring edges near the polygon being decided, (entry << 16) | vertex (see polygon_uncovered)
     __device__ void put(int i, double t) const {
         if (i < SPLIT_LDS) lds[i] = t;
         else if (i < cap) glob[i] = t;
@@ -697,7 +699,7 @@ struct SplitBuf {
 template <typename Set>
 __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, double ax, double ay, double bx, double by, double side,
                                  bool need_in_b, const SplitBuf &splits, int *lds_count, const TileSpan &tile,
-                                 double t_lo = 0.0, double t_hi = 1.0) {
+                                 double t_lo = 0.0, double t_hi = 1.0, int n_ring = -1) {
     // (t_lo, t_hi): the part of the edge that is examined.  An edge of a canvas polygon is often many times as long
     // as B is wide, and a witness has to be inside B: only the part inside B's box is cut into pieces, and only the
     // entries that reach that part are looked at.
@@ -739,13 +741,20 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
     // the examined part's own ends and box
     const double pax = ax + t_lo * ex, pay = ay + t_lo * ey, pbx = ax + t_hi * ex, pby = ay + t_hi * ey;
     if (Set::flat) {
-        // lanes = ring edges of all entries
-        const int tv = ps.total_vertices();
+        // lanes = ring edges of all entries, or those of them that the caller has listed (n_ring >= 0: the ones that
+        // come near the polygon being decided, where the examined part lies; no other can cut it)
+        const int tv = n_ring >= 0 ? n_ring : ps.total_vertices();
         for (int base = 0; base < tv; base += 64) {
             const int e = base + lane;
             if (e >= tv) continue;
             int li, v;
-            ps.locate(e, li, v);
+            if (n_ring >= 0) {
+                const int packed = splits.ring[e];
+                li = packed >> 16;
+                v = packed & 0xffff;
+            } else {
+                ps.locate(e, li, v);
+            }
             if (li == owner) continue;
             double x0, x1, y0, y1;
             ps.box(li, x0, x1, y0, y1);
@@ -1208,12 +1217,41 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
     }
     PHASE(1);
     if (visible) return true;
+    // ---- the ring edges that come near B's box, listed once (by every wave for itself): everything that is examined
+    // from here on lies in that box (B's own edges; of another entry's edge the part inside the box and 4 VIS_ON_LINE
+    // more), a ring edge cuts an examined part where they cross or where one of its ends lies within VIS_ON_LINE of the
+    // part, and the examinations used to walk every ring edge of every entry, a dozen times per decision, to find those.
+    int n_ring = -1;
+    if (Set::flat) {
+        n_ring = 0;
+        const int tv = ps.total_vertices();
+        for (int base = 0; base < tv; base += 64) {
+            const int e = base + lane;
+            bool take = false;
+            int li = 0, v = 0;
+            if (e < tv) {
+                ps.locate(e, li, v);
+                const int cn = ps.nv(li);
+                const double *cx = ps.x(li), *cy = ps.y(li);
+                const int u = v == 0 ? cn - 1 : v - 1;
+                const double ax = cx[u], ay = cy[u], ex = cx[v], ey = cy[v];
+                take = !(fmax(ax, ex) < bx0 - VIS_RING_MARGIN || fmin(ax, ex) > bx1 + VIS_RING_MARGIN ||
+                         fmax(ay, ey) < by0 - VIS_RING_MARGIN || fmin(ay, ey) > by1 + VIS_RING_MARGIN);
+            }
+            const unsigned long long mk = __ballot(take);
+            if (take) splits.ring[n_ring + __popcll(mk & ((1ull << lane) - 1))] = (li << 16) | v;
+            n_ring += __popcll(mk);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
     // ---- B's own edges, witness on B's inner side
     const double sgn_b = (double)ps.sgn(0);
     for (int v = wave; v < nv; v += n_waves) {
         if (*(volatile int *)flag) break;
         const int u = v == 0 ? nv - 1 : v - 1;
-        if (edge_has_witness(ps, 0, x[u], y[u], x[v], y[v], sgn_b, false, splits, lds_count, tile) && lane == 0) *flag = 1;
+        if (edge_has_witness(ps, 0, x[u], y[u], x[v], y[v], sgn_b, false, splits, lds_count, tile, 0.0, 1.0, n_ring) && lane == 0)
+            *flag = 1;
     }
     __syncthreads();
     PHASE(2);
@@ -1227,13 +1265,14 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
     // lanes = entries, then examined one by one, witness on their outer side
     int n_work = 0;
     if (Set::flat) {
-        const int tv = ps.total_vertices();
-        for (int base = nv; base < tv; base += 64) {  // entry 0 (B itself) owns the first nv
+        for (int base = nv; base < n_ring; base += 64) {  // entry 0 (B itself) owns the first nv, all of them listed
             const int e = base + lane;
             bool rel = false;
             int li = 0, v = 0;
-            if (e < tv) {
-                ps.locate(e, li, v);
+            if (e < n_ring) {
+                const int packed = splits.ring[e];
+                li = packed >> 16;
+                v = packed & 0xffff;
                 const int cn = ps.nv(li);
                 const double *cx = ps.x(li), *cy = ps.y(li);
                 const int u = v == 0 ? cn - 1 : v - 1;
@@ -1342,7 +1381,7 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
 #ifdef RT_VIS_STAMPS
         const unsigned long long t_ex0 = wall_clock64();
 #endif
-        const bool w_found = edge_has_witness(ps, li, ax, ay, ex_, ey_, side, true, splits, lds_count, tile, t_lo, t_hi);
+        const bool w_found = edge_has_witness(ps, li, ax, ay, ex_, ey_, side, true, splits, lds_count, tile, t_lo, t_hi, n_ring);
 #ifdef RT_VIS_STAMPS
         if (lane == 0) {
             const unsigned long long dt = wall_clock64() - t_ex0;
@@ -2010,9 +2049,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
     int32_t *canvas = ps.canvas + (int64_t)blockIdx.x * sc.n;
     double *cbox = ps.cbox + (int64_t)blockIdx.x * sc.n * 4;
     const int64_t wave_id = (int64_t)blockIdx.x * NW + wave;
+    int32_t *work = ps.work + wave_id * 3 * (int64_t)sc.vtot;  // 2 vtot for the collected edges, vtot for the ring list
     const SplitBuf splits{lds_splits[wave], ps.splits + wave_id * ps.split_cap, ps.split_cap,
-                          lds_px[wave],     lds_py[wave],                        lds_pstate[wave]};
-    int32_t *work = ps.work + wave_id * 2 * (int64_t)sc.vtot;
+                          lds_px[wave],     lds_py[wave],                        lds_pstate[wave], work + 2 * (int64_t)sc.vtot};
     int *lds_count = &lds_counts[wave];
     for (;;) {
         __syncthreads();
@@ -2670,7 +2709,7 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         b_cbox.alloc(sizeof(double) * 4 * (size_t)sc.n * n_blocks) || b_splits.alloc(sizeof(double) * (size_t)split_cap * n_waves) ||
         b_counter.alloc(sizeof(unsigned long long)) || b_order.alloc(sizeof(int32_t) * (size_t)m_stride * n_faces) ||
         b_counts.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_queue.alloc(sizeof(int32_t) * (size_t)n_faces) ||
-        b_work.alloc(sizeof(int32_t) * 2 * (size_t)sc.vtot * n_waves) || job.b_tlist.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) ||
+        b_work.alloc(sizeof(int32_t) * 3 * (size_t)sc.vtot * n_waves) || job.b_tlist.alloc(sizeof(int32_t) * (size_t)sc.n * n_blocks) ||
         job.b_grid.alloc(sizeof(uint32_t) * VIS_GRID_WORDS * (size_t)n_blocks) ||
         job.b_chunk.alloc(sizeof(int32_t) * 1024 * (size_t)n_blocks) ||
         job.b_bounds.alloc(sizeof(double) * 4 * VIS_MAX_TILES * (size_t)n_faces) ||
