@@ -873,29 +873,38 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
         __builtin_amdgcn_wave_barrier();
         EX_STAMP(2);
         const int per_piece = listed ? n_near : n - first;
-        const int n_pairs = n_splits * per_piece;
-        // entry by entry, every piece at once: most pieces lie inside one of the first few entries, and a piece that
-        // has been found covered is not tested again; when none is left the edge has no witness
-        const SmallDivisor by_entry(n_splits);
-        for (int base = 0; base < n_pairs; base += 64) {
-            if (!__any(lane < n_splits && splits.pstate[lane] != 0)) break;
-            const int pair = base + lane;
-            if (pair < n_pairs) {
-                int j, at;
-                by_entry.split(pair, at, j);
-                const int i = listed ? near_list[at] : first + at;
-                if (splits.pstate[j]) {
-                    const double wx = splits.px[j], wy = splits.py[j];
-                    if (i == 0) {
-                        if (!pip_ring(ps.x(0), ps.y(0), ps.nv(0), wx, wy)) splits.pstate[j] = 0;
-                    } else {
-                        double x0, x1, y0, y1;
-                        ps.box(i, x0, x1, y0, y1);
-                        if (!(wx < x0 || wx > x1 || wy < y0 || wy > y1) && pip_ring(ps.x(i), ps.y(i), ps.nv(i), wx, wy))
-                            splits.pstate[j] = 0;
-                    }
+        // Entry by entry, the pieces that are still uncovered at once: most pieces lie inside one of the first few
+        // entries, and a piece found covered is not tested again -- the pieces left are counted again before every
+        // trip, and a trip holds them against as many entries as the lanes allow (64 / pieces left); when none is
+        // left the edge has no witness.
+        int *alive_list = (int *)splits.lds;  // (the cuts themselves are no longer needed: the witness points are made)
+        for (int at0 = 0; at0 < per_piece;) {
+            const bool alive = lane < n_splits && splits.pstate[lane] != 0;
+            const unsigned long long am = __ballot(alive);
+            const int na = __popcll(am);
+            if (na == 0) break;
+            if (alive) alive_list[__popcll(am & ((1ull << lane) - 1))] = lane;
+            __builtin_amdgcn_wave_barrier();
+            const SmallDivisor by_alive(na);
+            int per_trip = by_alive.quotient(64);
+            if (per_trip > per_piece - at0) per_trip = per_piece - at0;
+            if (lane < per_trip * na) {
+                int eo, r;
+                by_alive.split(lane, eo, r);
+                const int j = alive_list[r];
+                const int i = listed ? near_list[at0 + eo] : first + at0 + eo;
+                const double wx = splits.px[j], wy = splits.py[j];
+                if (i == 0) {
+                    if (!pip_ring(ps.x(0), ps.y(0), ps.nv(0), wx, wy)) splits.pstate[j] = 0;
+                } else {
+                    double x0, x1, y0, y1;
+                    ps.box(i, x0, x1, y0, y1);
+                    if (!(wx < x0 || wx > x1 || wy < y0 || wy > y1) && pip_ring(ps.x(i), ps.y(i), ps.nv(i), wx, wy))
+                        splits.pstate[j] = 0;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            at0 += per_trip;
         }
         __builtin_amdgcn_wave_barrier();
         EX_STAMP(3);
