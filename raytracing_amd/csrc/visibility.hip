@@ -1188,12 +1188,15 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
         const int per_sample = n - 1;
         const int my_samples = wave < n_samples ? (n_samples - wave + n_waves - 1) / n_waves : 0;
         const int n_pairs = my_samples * per_sample;
-        const SmallDivisor by_sample(per_sample > 0 ? per_sample : 1);
+        // (entry by entry, the wave's samples at once: when the last of them has been found covered the rest of the
+        // entries need not be looked at)
+        const SmallDivisor by_entry(my_samples > 0 ? my_samples : 1);
         for (int base = 0; base < n_pairs; base += 64) {
+            if (!__any(lane < my_samples && splits.pstate[wave + lane * n_waves] != 0)) break;
             const int pair = base + lane;
             if (pair < n_pairs) {
                 int sidx, li;
-                by_sample.split(pair, sidx, li);
+                by_entry.split(pair, li, sidx);
                 sidx = wave + sidx * n_waves;
                 li += 1;
                 if (splits.pstate[sidx]) {
