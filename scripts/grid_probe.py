@@ -1,4 +1,4 @@
-"""How many candidates the painter's covered-cell bitmap settles (not a test): python scripts/grid_probe.py lln"""
+"""How many candidates the painter's covered-cell bitmap settles (not a test): python scripts/grid_probe.py lln | ny8"""
 import ctypes
 import sys
 import time
@@ -7,8 +7,12 @@ sys.path.insert(0, ".")
 from raytracing_amd import _lib, geometry as geom  # noqa: E402
 
 name = sys.argv[1]
-loaded = geom.load_scene(f"data/{name}.geojson")
-scene = _lib.Scene(loaded.arrays)
+if name == "ny8":  # ny.geojson tiled 8 x 8, as the bench's fourth configuration has it
+    from raytracing_amd import scenarios
+
+    scene = _lib.Scene(geom.scene_arrays_of(scenarios.ny_tiled(8)[0].get_polygons_list()))
+else:
+    scene = _lib.Scene(geom.load_scene(f"data/{name}.geojson").arrays)
 st = (ctypes.c_ulonglong * 8)()
 _lib.load().rt_debug_visibility_stats(st)
 for rep in range(2):
