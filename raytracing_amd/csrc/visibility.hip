@@ -686,7 +686,7 @@ struct SplitBuf {
     int64_t cap;
     double *px, *py; // [PIECE_LDS] witness points of the pieces of the edge being examined
     int *pstate;     // [PIECE_LDS] 1 while the witness is still a proof of visibility
-    int32_t *ring;   // [vtot] the ring edges near the polygon being decided, (entry << 16) | vertex (see polygon_uncovered)
+    int32_t *ring;   // [vtot], one per workgroup: the ring edges near the polygon being decided, (entry << 16) | vertex (see polygon_uncovered)
     __device__ void put(int i, double t) const {
         if (i < SPLIT_LDS) lds[i] = t;
         else if (i < cap) glob[i] = t;
@@ -1159,6 +1159,36 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
     // contradicts it (a point of B is then a point of that entry).
     if (!inside_one_done && inside_one_entry(ps)) return false;
     PHASE(0);
+    // ---- the ring edges that come near B's box, listed once per decision (the waves share the work; the list is
+    // complete behind the barrier that ends the samples): everything that is examined further down lies in that box
+    // (B's own edges; of another entry's edge the part inside the box and 4 VIS_ON_LINE more), a ring edge cuts an
+    // examined part where they cross or where one of its ends lies within VIS_ON_LINE of the part, and the
+    // examinations used to walk every ring edge of every entry, a dozen times per decision, to find those.
+    if (Set::flat) {
+        const int tv = ps.total_vertices();
+        for (int base = 64 * wave; base < tv; base += 64 * n_waves) {
+            const int e = base + lane;
+            bool take = false;
+            int li = 0, v = 0;
+            if (e < tv) {
+                ps.locate(e, li, v);
+                const int cn = ps.nv(li);
+                const double *cx = ps.x(li), *cy = ps.y(li);
+                const int u = v == 0 ? cn - 1 : v - 1;
+                const double ax = cx[u], ay = cy[u], ex = cx[v], ey = cy[v];
+                take = !(fmax(ax, ex) < bx0 - VIS_RING_MARGIN || fmin(ax, ex) > bx1 + VIS_RING_MARGIN ||
+                         fmax(ay, ey) < by0 - VIS_RING_MARGIN || fmin(ay, ey) > by1 + VIS_RING_MARGIN);
+            }
+            const unsigned long long mk = __ballot(take);
+            if (mk != 0ull) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(flag + 1, __popcll(mk));
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (take) splits.ring[at + __popcll(mk & ((1ull << lane) - 1))] = (li << 16) | v;
+            }
+        }
+        __threadfence_block();
+    }
     // ---- shortcut: a few points inside B (vertex average and the points halfway to some vertices); one of them
     // outside every other entry proves B visible.  Lanes = entries.
     {
@@ -1229,34 +1259,7 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
     }
     PHASE(1);
     if (visible) return true;
-    // ---- the ring edges that come near B's box, listed once (by every wave for itself): everything that is examined
-    // from here on lies in that box (B's own edges; of another entry's edge the part inside the box and 4 VIS_ON_LINE
-    // more), a ring edge cuts an examined part where they cross or where one of its ends lies within VIS_ON_LINE of the
-    // part, and the examinations used to walk every ring edge of every entry, a dozen times per decision, to find those.
-    int n_ring = -1;
-    if (Set::flat) {
-        n_ring = 0;
-        const int tv = ps.total_vertices();
-        for (int base = 0; base < tv; base += 64) {
-            const int e = base + lane;
-            bool take = false;
-            int li = 0, v = 0;
-            if (e < tv) {
-                ps.locate(e, li, v);
-                const int cn = ps.nv(li);
-                const double *cx = ps.x(li), *cy = ps.y(li);
-                const int u = v == 0 ? cn - 1 : v - 1;
-                const double ax = cx[u], ay = cy[u], ex = cx[v], ey = cy[v];
-                take = !(fmax(ax, ex) < bx0 - VIS_RING_MARGIN || fmin(ax, ex) > bx1 + VIS_RING_MARGIN ||
-                         fmax(ay, ey) < by0 - VIS_RING_MARGIN || fmin(ay, ey) > by1 + VIS_RING_MARGIN);
-            }
-            const unsigned long long mk = __ballot(take);
-            if (take) splits.ring[n_ring + __popcll(mk & ((1ull << lane) - 1))] = (li << 16) | v;
-            n_ring += __popcll(mk);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-    }
+    const int n_ring = Set::flat ? *(volatile int *)(flag + 1) : -1;  // (listed before the samples, see there)
     // ---- B's own edges, witness on B's inner side
     const double sgn_b = (double)ps.sgn(0);
     for (int v = wave; v < nv; v += n_waves) {
@@ -1277,7 +1280,7 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
     // lanes = entries, then examined one by one, witness on their outer side
     int n_work = 0;
     if (Set::flat) {
-        for (int base = nv; base < n_ring; base += 64) {  // entry 0 (B itself) owns the first nv, all of them listed
+        for (int base = 0; base < n_ring; base += 64) {
             const int e = base + lane;
             bool rel = false;
             int li = 0, v = 0;
@@ -1285,6 +1288,8 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
                 const int packed = splits.ring[e];
                 li = packed >> 16;
                 v = packed & 0xffff;
+            }
+            if (li != 0) {  // (entry 0 is B itself)
                 const int cn = ps.nv(li);
                 const double *cx = ps.x(li), *cy = ps.y(li);
                 const int u = v == 0 ? cn - 1 : v - 1;
@@ -2045,7 +2050,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
     __shared__ double lds_splits[NW][SPLIT_LDS];
     __shared__ double lds_px[NW][PIECE_LDS], lds_py[NW][PIECE_LDS];
     __shared__ int lds_pstate[NW][PIECE_LDS];
-    __shared__ int s_face, s_nlist, s_fits, s_flag;
+    __shared__ int s_face, s_nlist, s_fits, s_flag[2];  // s_flag: the full decision's exit flag, and the length of its ring list
     // (every byte of LDS counts here: three workgroups share a compute unit, and 1.2 KB more per workgroup made it two)
     __shared__ int s_mc, s_grid_on;
     __shared__ GridDomain s_gdom;
@@ -2061,9 +2066,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
     int32_t *canvas = ps.canvas + (int64_t)blockIdx.x * sc.n;
     double *cbox = ps.cbox + (int64_t)blockIdx.x * sc.n * 4;
     const int64_t wave_id = (int64_t)blockIdx.x * NW + wave;
-    int32_t *work = ps.work + wave_id * 3 * (int64_t)sc.vtot;  // 2 vtot for the collected edges, vtot for the ring list
+    int32_t *work = ps.work + wave_id * 3 * (int64_t)sc.vtot;  // 2 vtot for the collected edges; the workgroup's ring list is in its first wave's third
     const SplitBuf splits{lds_splits[wave], ps.splits + wave_id * ps.split_cap, ps.split_cap,
-                          lds_px[wave],     lds_py[wave],                        lds_pstate[wave], work + 2 * (int64_t)sc.vtot};
+                          lds_px[wave],     lds_py[wave],                        lds_pstate[wave],
+                          ps.work + ((int64_t)blockIdx.x * NW * 3 + 2) * (int64_t)sc.vtot};
     int *lds_count = &lds_counts[wave];
     for (;;) {
         __syncthreads();
@@ -2425,7 +2431,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                                     // and every wave has to take the same way through the barriers)
                                     s_again[j] = again;
                                     s_nlist = n_list;
-                                    s_flag = 0;
+                                    s_flag[0] = 0;
+                                    s_flag[1] = 0;
                                 }
                             }
                             __syncthreads();
@@ -2436,7 +2443,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
 #ifdef RT_VIS_STAMPS
                                 const unsigned long long t_dec = wall_clock64();
 #endif
-                                v = polygon_uncovered(cv, splits, lds_count, work, &s_flag, span, true) ? 1 : 0;
+                                v = polygon_uncovered(cv, splits, lds_count, work, s_flag, span, true) ? 1 : 0;
 #ifdef RT_VIS_STAMPS
                                 if (threadIdx.x == 0) {
                                     // (measurement) by the width of the candidate's box: up to 0.25, 0.5, 1, 2, 4 rad, more
@@ -2586,7 +2593,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                 if (lane == 0) {
                     s_nlist = n_list;
                     s_fits = fits ? 1 : 0;
-                    s_flag = 0;
+                    s_flag[0] = 0;
+                    s_flag[1] = 0;
                 }
             }
             __syncthreads();
@@ -2597,10 +2605,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
             if (!visible) {
                 if (s_fits) {
                     LocalSet ls{store, n_list + 1};
-                    visible = polygon_uncovered(ls, splits, lds_count, work, &s_flag, span, false);
+                    visible = polygon_uncovered(ls, splits, lds_count, work, s_flag, span, false);
                 } else {
                     GlobalSet gs{&sc, sph_f, meta_f, list, B, n_list + 1};
-                    visible = polygon_uncovered(gs, splits, lds_count, work, &s_flag, span, false);
+                    visible = polygon_uncovered(gs, splits, lds_count, work, s_flag, span, false);
                 }
             }
             if (visible) {
