@@ -687,6 +687,7 @@ struct SplitBuf {
     double *px, *py; // [PIECE_LDS] witness points of the pieces of the edge being examined
     int *pstate;     // [PIECE_LDS] 1 while the witness is still a proof of visibility
     int32_t *ring;   // [vtot], one per workgroup: the ring edges near the polygon being decided, (entry << 16) | vertex (see polygon_uncovered)
+    int32_t *work_shared;  // [2 vtot], one per workgroup: (entry, vertex) of the edges that enter the polygon being decided
     __device__ void put(int i, double t) const {
         if (i < SPLIT_LDS) lds[i] = t;
         else if (i < cap) glob[i] = t;
@@ -1268,19 +1269,11 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
         if (edge_has_witness(ps, 0, x[u], y[u], x[v], y[v], sgn_b, false, splits, lds_count, tile, 0.0, 1.0, n_ring) && lane == 0)
             *flag = 1;
     }
-    __syncthreads();
-    PHASE(2);
-    // (only a witness on one of B's own edges, a 1, sends the waves out here: a wave that is quick to leave the barrier
-    // can have found a witness on another entry's edge, a 4, before a slow one reads the flag, and a wave that left here
-    // on that would miss the barrier below while the quick one waits in it.  This was so from the first version of this
-    // routine and went unseen because few decisions end with such a witness; cut into small tiles, whose borders are
-    // examined like edges and often hold one, a painting in a dozen came out wrong or did not end.)
-    if (*(volatile int *)flag == 1) return true;
-    // ---- edges of the other entries that enter B (an endpoint inside B or a crossing with B's ring): collected with
-    // lanes = entries, then examined one by one, witness on their outer side
-    int n_work = 0;
-    if (Set::flat) {
-        for (int base = 0; base < n_ring; base += 64) {
+    // ---- the edges of the other entries that enter B (an endpoint inside B or a crossing with B's ring), for the step
+    // after this one: every wave collects its share of the ring list into one list of the workgroup, which the barrier
+    // below completes (for nothing when a witness has just been found; the order of the list changes no result)
+    if (Set::flat && !*(volatile int *)flag) {
+        for (int base = 64 * wave; base < n_ring; base += 64 * n_waves) {
             const int e = base + lane;
             bool rel = false;
             int li = 0, v = 0;
@@ -1306,13 +1299,34 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
                 }
             }
             const unsigned long long mk = __ballot(rel);
-            if (rel) {
-                const int slot = n_work + __popcll(mk & ((1ull << lane) - 1));
-                work[2 * slot] = li;
-                work[2 * slot + 1] = v;
+            if (mk != 0ull) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(flag + 2, __popcll(mk));
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (rel) {
+                    const int slot = at + __popcll(mk & ((1ull << lane) - 1));
+                    splits.work_shared[2 * slot] = li;
+                    splits.work_shared[2 * slot + 1] = v;
+                }
             }
-            n_work += __popcll(mk);
         }
+        __threadfence_block();
+    }
+    __syncthreads();
+    PHASE(2);
+    // (only a witness on one of B's own edges, a 1, sends the waves out here: a wave that is quick to leave the barrier
+    // can have found a witness on another entry's edge, a 4, before a slow one reads the flag, and a wave that left here
+    // on that would miss the barrier below while the quick one waits in it.  This was so from the first version of this
+    // routine and went unseen because few decisions end with such a witness; cut into small tiles, whose borders are
+    // examined like edges and often hold one, a painting in a dozen came out wrong or did not end.)
+    if (*(volatile int *)flag == 1) return true;
+    // ---- edges of the other entries that enter B (an endpoint inside B or a crossing with B's ring): collected with
+    // lanes = entries, then examined one by one, witness on their outer side
+    int n_work = 0;
+    const int32_t *collected = work;
+    if (Set::flat) {
+        n_work = *(volatile int *)(flag + 2);  // (collected ahead of the barrier above, the waves sharing the work)
+        collected = splits.work_shared;
     } else
     for (int base = 1; base < n; base += 64) {
         const int li = base + lane;
@@ -1355,8 +1369,8 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
         int li = -1;
         double ax, ay, ex_, ey_, side;
         if (w < n_work) {
-            li = work[2 * w];
-            const int v = work[2 * w + 1];
+            li = collected[2 * w];
+            const int v = collected[2 * w + 1];
             const int cn = ps.nv(li);
             const double *cx = ps.x(li), *cy = ps.y(li);
             const int u = v == 0 ? cn - 1 : v - 1;
@@ -2050,7 +2064,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
     __shared__ double lds_splits[NW][SPLIT_LDS];
     __shared__ double lds_px[NW][PIECE_LDS], lds_py[NW][PIECE_LDS];
     __shared__ int lds_pstate[NW][PIECE_LDS];
-    __shared__ int s_face, s_nlist, s_fits, s_flag[2];  // s_flag: the full decision's exit flag, and the length of its ring list
+    __shared__ int s_face, s_nlist, s_fits, s_flag[3];  // s_flag: the full decision's exit flag, the lengths of its ring list and of its collected edges
     // (every byte of LDS counts here: three workgroups share a compute unit, and 1.2 KB more per workgroup made it two)
     __shared__ int s_mc, s_grid_on;
     __shared__ GridDomain s_gdom;
@@ -2069,7 +2083,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
     int32_t *work = ps.work + wave_id * 3 * (int64_t)sc.vtot;  // 2 vtot for the collected edges; the workgroup's ring list is in its first wave's third
     const SplitBuf splits{lds_splits[wave], ps.splits + wave_id * ps.split_cap, ps.split_cap,
                           lds_px[wave],     lds_py[wave],                        lds_pstate[wave],
-                          ps.work + ((int64_t)blockIdx.x * NW * 3 + 2) * (int64_t)sc.vtot};
+                          ps.work + ((int64_t)blockIdx.x * NW * 3 + 2) * (int64_t)sc.vtot,
+                          ps.work + (int64_t)blockIdx.x * NW * 3 * (int64_t)sc.vtot};
     int *lds_count = &lds_counts[wave];
     for (;;) {
         __syncthreads();
@@ -2433,6 +2448,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                                     s_nlist = n_list;
                                     s_flag[0] = 0;
                                     s_flag[1] = 0;
+                                    s_flag[2] = 0;
                                 }
                             }
                             __syncthreads();
@@ -2595,6 +2611,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     s_fits = fits ? 1 : 0;
                     s_flag[0] = 0;
                     s_flag[1] = 0;
+                    s_flag[2] = 0;
                 }
             }
             __syncthreads();
