@@ -2066,7 +2066,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
     __shared__ int lds_pstate[NW][PIECE_LDS];
     __shared__ int s_face, s_nlist, s_fits, s_flag[3];  // s_flag: the full decision's exit flag, the lengths of its ring list and of its collected edges
     // (every byte of LDS counts here: three workgroups share a compute unit, and 1.2 KB more per workgroup made it two)
-    __shared__ int s_mc, s_grid_on;
+    __shared__ int s_mc, s_grid_on, s_own;
     __shared__ GridDomain s_gdom;
     double (*s_red)[PIECE_LDS] = lds_px;  // free between two decisions: scratch of the reduction over the candidates' boxes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2357,6 +2357,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                     }
                     const int slot_b = n_cs + wave_u, at_b = used + before;
                     int verdict = 0;  // 0 hidden, 1 shows, or unsettled
+                    int n_list_mine = VIS_WAVE_LIST + 1;  // how many canvas polygons this wave listed for its candidate
                     if (have) {
                         // what of B can show in this tile lies in B's box cut to the sector: only canvas polygons reaching
                         // there matter
@@ -2375,6 +2376,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             if (take && at < VIS_WAVE_LIST) my_list[at] = (uint16_t)ci;
                             n_list += __popcll(mk);
                         }
+                        n_list_mine = n_list;
                         const double *src = sph_f + (size_t)b_v0 * 2;
                         if (lane < nv2) cs->xy[at_b + lane] = b_xy;
                         for (int q = 64 + lane; q < nv2; q += 64) cs->xy[at_b + q] = src[q];
@@ -2422,30 +2424,37 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             // canvas has grown since they were tried)
                             if (wave_u == j) {
                                 move_staged(cs, slot_b, n_cs, used);
-                                int n_list = 0;
-                                const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
-                                const double lymin = fmax(mb.ymin, span.y0), lymax = fmin(mb.ymax, span.y1);
-                                for (int base = 0; base < n_cs; base += 64) {
-                                    const int ci = base + lane;
-                                    bool take = false;
-                                    if (ci < n_cs) {
-                                        const double *cb = cs->boxes + 4 * ci;
-                                        take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < lymin || cb[2] > lymax);
-                                    }
-                                    const unsigned long long mk = __ballot(take);
-                                    if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = (uint16_t)ci;
-                                    n_list += __popcll(mk);
-                                }
-                                canvas_prefix(cs, cs->list, n_list, nv2 / 2, cs->lpre);
-                                __builtin_amdgcn_wave_barrier();
+                                // (no member of the group has shown yet and the wave's own list holds: the canvas is
+                                // what it was when the wave listed it, and the shortcuts have been tried against it)
+                                const bool own = shown == 0 && v == VIS_UNSETTLED && n_list_mine <= VIS_WAVE_LIST;
+                                int n_list = n_list_mine;
                                 int again = VIS_UNSETTLED;
-                                if (shown > 0 || v != VIS_UNSETTLED || n_list > VIS_WAVE_LIST)
-                                    again = shortcuts_alone(cs, cs->list, cs->lpre, n_cs, n_list, span);
+                                if (!own) {
+                                    n_list = 0;
+                                    const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
+                                    const double lymin = fmax(mb.ymin, span.y0), lymax = fmin(mb.ymax, span.y1);
+                                    for (int base = 0; base < n_cs; base += 64) {
+                                        const int ci = base + lane;
+                                        bool take = false;
+                                        if (ci < n_cs) {
+                                            const double *cb = cs->boxes + 4 * ci;
+                                            take = !(cb[1] < lxmin || cb[0] > lxmax || cb[3] < lymin || cb[2] > lymax);
+                                        }
+                                        const unsigned long long mk = __ballot(take);
+                                        if (take) cs->list[n_list + __popcll(mk & ((1ull << lane) - 1))] = (uint16_t)ci;
+                                        n_list += __popcll(mk);
+                                    }
+                                    canvas_prefix(cs, cs->list, n_list, nv2 / 2, cs->lpre);
+                                    __builtin_amdgcn_wave_barrier();
+                                    if (shown > 0 || v != VIS_UNSETTLED || n_list > VIS_WAVE_LIST)
+                                        again = shortcuts_alone(cs, cs->list, cs->lpre, n_cs, n_list, span);
+                                }
                                 if (lane == 0) {
                                     // (slots of their own: a wave that is late may still be reading the first verdict,
                                     // and every wave has to take the same way through the barriers)
                                     s_again[j] = again;
                                     s_nlist = n_list;
+                                    s_own = own ? 1 : 0;
                                     s_flag[0] = 0;
                                     s_flag[1] = 0;
                                     s_flag[2] = 0;
@@ -2455,7 +2464,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                             G_STAMP(8, g_on && wave_u == 0);
                             v = s_again[j];
                             if (v == VIS_UNSETTLED) {
-                                const CanvasSet<Store> cv{cs, cs->list, cs->lpre, n_cs, s_nlist + 1};
+                                const bool own = s_own != 0;
+                                const CanvasSet<Store> cv{cs, own ? s_wlist[j] : cs->list, own ? s_wlpre[j] : cs->lpre, n_cs, s_nlist + 1};
 #ifdef RT_VIS_STAMPS
                                 const unsigned long long t_dec = wall_clock64();
 #endif
