@@ -494,6 +494,8 @@ struct PaintScratch {
 // the same loops run out of LDS).
 struct GlobalSet {
     static constexpr bool flat = false;  // no running vertex count: loops go entry by entry
+    __device__ int coord_offset(int) const { return 0; }
+    __device__ const double *coords() const { return nullptr; }
     __device__ int total_vertices() const { return 0; }
     __device__ void locate(int, int &i, int &v) const { i = v = 0; }
     const SceneView *sc;
@@ -526,6 +528,8 @@ struct LocalStore {
 };
 struct LocalSet {
     static constexpr bool flat = false;
+    __device__ int coord_offset(int) const { return 0; }
+    __device__ const double *coords() const { return nullptr; }
     __device__ int total_vertices() const { return 0; }
     __device__ void locate(int, int &i, int &v) const { i = v = 0; }
     LocalStore *st;
@@ -596,6 +600,9 @@ struct CanvasSet {
     }
     __device__ int sgn(int i) const { return st->sgns[slot(i)]; }
     __device__ uint32_t twin_mask(int i) const { return i == 0 ? 0u : st->twin[slot(i)]; }
+    // where entry i's coordinates begin in the store (x first, then y), and the store's coordinates
+    __device__ int coord_offset(int i) const { return st->offs[slot(i)]; }
+    __device__ const double *coords() const { return st->xy; }
 };
 
 // A face with very many candidates is painted in tiles: rectangles of the (azimuth, polar) plane ("sectors" below: they
@@ -686,7 +693,7 @@ struct SplitBuf {
     int64_t cap;
     double *px, *py; // [PIECE_LDS] witness points of the pieces of the edge being examined
     int *pstate;     // [PIECE_LDS] 1 while the witness is still a proof of visibility
-    int32_t *ring;   // [vtot], one per workgroup: the ring edges near the polygon being decided, (entry << 16) | vertex (see polygon_uncovered)
+    int32_t *ring;   // [2 vtot], one per workgroup: the ring edges near the polygon being decided, two words each (see polygon_uncovered, edge_has_witness)
     int32_t *work_shared;  // [2 vtot], one per workgroup: (entry, vertex) of the edges that enter the polygon being decided
     __device__ void put(int i, double t) const {
         if (i < SPLIT_LDS) lds[i] = t;
@@ -742,29 +749,24 @@ __device__ __forceinline__ bool edge_has_witness(const Set &ps, int owner, doubl
     // the examined part's own ends and box
     const double pax = ax + t_lo * ex, pay = ay + t_lo * ey, pbx = ax + t_hi * ex, pby = ay + t_hi * ey;
     if (Set::flat) {
-        // lanes = ring edges of all entries, or those of them that the caller has listed (n_ring >= 0: the ones that
-        // come near the polygon being decided, where the examined part lies; no other can cut it)
-        const int tv = n_ring >= 0 ? n_ring : ps.total_vertices();
-        for (int base = 0; base < tv; base += 64) {
+        // lanes = the ring edges that the caller has listed (the ones that come near the polygon being decided, where
+        // the examined part lies; no other can cut it): two words each, (entry, vertex) and (where the entry's
+        // coordinates begin, how many vertices it has), so that an edge's ends are two reads away
+        const double *xy = ps.coords();
+        const double px0 = fmin(pax, pbx) - 2 * VIS_ON_LINE, px1 = fmax(pax, pbx) + 2 * VIS_ON_LINE;
+        const double py0 = fmin(pay, pby) - 2 * VIS_ON_LINE, py1 = fmax(pay, pby) + 2 * VIS_ON_LINE;
+        for (int base = 0; base < n_ring; base += 64) {
             const int e = base + lane;
-            if (e >= tv) continue;
-            int li, v;
-            if (n_ring >= 0) {
-                const int packed = splits.ring[e];
-                li = packed >> 16;
-                v = packed & 0xffff;
-            } else {
-                ps.locate(e, li, v);
-            }
+            if (e >= n_ring) continue;
+            const int2 rec = ((const int2 *)splits.ring)[e];
+            const int li = rec.x >> 16, v = rec.x & 0xffff;
             if (li == owner) continue;
-            double x0, x1, y0, y1;
-            ps.box(li, x0, x1, y0, y1);
-            const bool near = !(x1 < fmin(pax, pbx) - VIS_ON_LINE || x0 > fmax(pax, pbx) + VIS_ON_LINE ||
-                                y1 < fmin(pay, pby) - VIS_ON_LINE || y0 > fmax(pay, pby) + VIS_ON_LINE);
-            if (!near) continue;
-            const int nv = ps.nv(li);
-            const double *x = ps.x(li), *y = ps.y(li);
+            const int nv = rec.y & 0xffff;
+            const double *x = xy + (int)((unsigned)rec.y >> 16), *y = x + nv;
             const int u = v == 0 ? nv - 1 : v - 1;
+            // (a ring edge cuts the part where they cross or where one of its ends lies within VIS_ON_LINE of it: its
+            // own box then comes that near the part's)
+            if (fmax(x[u], x[v]) < px0 || fmin(x[u], x[v]) > px1 || fmax(y[u], y[v]) < py0 || fmin(y[u], y[v]) > py1) continue;
             double t[3];
             int k = edge_cuts(ax, ay, bx, by, x[u], y[u], x[v], y[v], t);
             int kept = 0;
@@ -1185,7 +1187,9 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
                 int at = 0;
                 if (lane == 0) at = atomicAdd(flag + 1, __popcll(mk));
                 at = __builtin_amdgcn_readfirstlane(at);
-                if (take) splits.ring[at + __popcll(mk & ((1ull << lane) - 1))] = (li << 16) | v;
+                if (take)
+                    ((int2 *)splits.ring)[at + __popcll(mk & ((1ull << lane) - 1))] =
+                        make_int2((li << 16) | v, (int)(((unsigned)ps.coord_offset(li) << 16) | (unsigned)ps.nv(li)));
             }
         }
         __threadfence_block();
@@ -1278,7 +1282,7 @@ __device__ __forceinline__ bool polygon_uncovered(const Set &ps, const SplitBuf 
             bool rel = false;
             int li = 0, v = 0;
             if (e < n_ring) {
-                const int packed = splits.ring[e];
+                const int packed = splits.ring[2 * e];
                 li = packed >> 16;
                 v = packed & 0xffff;
             }
@@ -2080,10 +2084,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
     int32_t *canvas = ps.canvas + (int64_t)blockIdx.x * sc.n;
     double *cbox = ps.cbox + (int64_t)blockIdx.x * sc.n * 4;
     const int64_t wave_id = (int64_t)blockIdx.x * NW + wave;
-    int32_t *work = ps.work + wave_id * 3 * (int64_t)sc.vtot;  // 2 vtot for the collected edges; the workgroup's ring list is in its first wave's third
+    // per wave 3 vtot words: 2 vtot for the edges a decision collects (the decisions on the resident canvas collect into
+    // the first wave's, for the workgroup); the workgroup's ring list, 2 vtot words from an even offset, begins in its
+    // first wave's last third and runs into the second wave's words, which only the other decisions use
+    int32_t *work = ps.work + wave_id * 3 * (int64_t)sc.vtot;
     const SplitBuf splits{lds_splits[wave], ps.splits + wave_id * ps.split_cap, ps.split_cap,
                           lds_px[wave],     lds_py[wave],                        lds_pstate[wave],
-                          ps.work + ((int64_t)blockIdx.x * NW * 3 + 2) * (int64_t)sc.vtot,
+                          ps.work + ((((int64_t)blockIdx.x * NW * 3 + 2) * (int64_t)sc.vtot + 1) & ~(int64_t)1),
                           ps.work + (int64_t)blockIdx.x * NW * 3 * (int64_t)sc.vtot};
     int *lds_count = &lds_counts[wave];
     for (;;) {
