@@ -2701,9 +2701,44 @@ struct DevBuf {
 
 // Device buffers of one batch of faces: they live until the batch's kernels have run.
 struct RowsJob {
-    DevBuf b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work,
-        b_queue, b_tlist, b_bounds, b_ntiles, b_itemoff, b_big, b_grid, b_chunk;
+    // The batch's buffers are parts of ONE allocation (a dozen gigabytes for a town's matrix in some twenty pieces:
+    // allocated and freed piece by piece that was 3 ms a call, and a call that asks for other sizes than the one before
+    // it could wait a hundred milliseconds and more for the driver to give memory back and map it again).  A part is
+    // asked for with alloc(), which only notes its size; commit() allocates and hands out the addresses.
+    struct Part {
+        void *p = nullptr;
+        size_t bytes = 0;
+        std::vector<Part *> *asked = nullptr;
+        int alloc(size_t b) {
+            bytes = b;
+            asked->push_back(this);
+            return 0;
+        }
+    };
+    std::vector<Part *> asked;
+    DevBuf arena;
+    Part b_off, b_verts, b_normal, b_self, b_sph, b_meta, b_list, b_canvas, b_cbox, b_splits, b_counter, b_order, b_counts, b_work,
+        b_queue, b_tlist, b_bounds, b_ntiles, b_itemoff, b_grid, b_chunk;
+    DevBuf b_big;  // (its size is known later than the others')
     std::vector<int32_t> h_big;
+    RowsJob() {
+        for (Part *q : {&b_off, &b_verts, &b_normal, &b_self, &b_sph, &b_meta, &b_list, &b_canvas, &b_cbox, &b_splits, &b_counter,
+                        &b_order, &b_counts, &b_work, &b_queue, &b_tlist, &b_bounds, &b_ntiles, &b_itemoff, &b_grid, &b_chunk})
+            q->asked = &asked;
+    }
+    RowsJob(const RowsJob &) = delete;
+    RowsJob &operator=(const RowsJob &) = delete;
+    int commit() {
+        size_t total = 0;
+        for (const Part *q : asked) total += (q->bytes + 255) & ~(size_t)255;
+        if (arena.alloc(total)) return -1;
+        char *at = (char *)arena.p;
+        for (Part *q : asked) {
+            q->p = at;
+            at += (q->bytes + 255) & ~(size_t)255;
+        }
+        return 0;
+    }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, mapped, sorted, painted
     ~RowsJob() {
         for (hipEvent_t e : ev)
@@ -2742,9 +2777,10 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
     const bool resident = scene_f0 >= 0;
     const int n_faces = resident ? scene_count : (int)a_self.size();
     if (n_faces == 0) return 0;
-    DevBuf &b_off = job.b_off, &b_verts = job.b_verts, &b_normal = job.b_normal, &b_self = job.b_self, &b_sph = job.b_sph,
-           &b_meta = job.b_meta, &b_list = job.b_list, &b_canvas = job.b_canvas, &b_cbox = job.b_cbox, &b_splits = job.b_splits,
-           &b_counter = job.b_counter, &b_order = job.b_order, &b_counts = job.b_counts, &b_work = job.b_work;
+    RowsJob::Part &b_off = job.b_off, &b_verts = job.b_verts, &b_normal = job.b_normal, &b_self = job.b_self, &b_sph = job.b_sph,
+                  &b_meta = job.b_meta, &b_list = job.b_list, &b_canvas = job.b_canvas, &b_cbox = job.b_cbox,
+                  &b_splits = job.b_splits, &b_counter = job.b_counter, &b_order = job.b_order, &b_counts = job.b_counts,
+                  &b_work = job.b_work;
     // persistent workgroups of 4 waves, one face per workgroup at a time
     // (a face may be painted as up to VIS_MAX_TILES work items)
     const int64_t max_items = strict ? n_faces : (int64_t)n_faces * VIS_MAX_TILES;
@@ -2767,7 +2803,8 @@ static int visibility_rows_enqueue(rt_scene *scene, hipStream_t st, const std::v
         job.b_grid.alloc(sizeof(uint32_t) * VIS_GRID_WORDS * (size_t)n_blocks) ||
         job.b_chunk.alloc(sizeof(int32_t) * 1024 * (size_t)n_blocks) ||
         job.b_bounds.alloc(sizeof(double) * 4 * VIS_MAX_TILES * (size_t)n_faces) ||
-        job.b_ntiles.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_itemoff.alloc(sizeof(int32_t) * ((size_t)n_faces + 1)))
+        job.b_ntiles.alloc(sizeof(int32_t) * (size_t)n_faces) || job.b_itemoff.alloc(sizeof(int32_t) * ((size_t)n_faces + 1)) ||
+        job.commit())
         RT_FAIL("visibility: out of device memory");
     const double *d_face_verts;
     if (resident) {
