@@ -381,7 +381,7 @@ int rt_rejudge_paths(rt_scene *scene, const rt_candidates *cand, const double *t
     // The groups that end with a diffraction on the scene's stream, the pure reflections beside them on its side stream
     // (same priority): a group's second pass lasts as long as its longest run and fills a fraction of the chip, and
     // the two kinds have about the same to do.  Each stream: first passes, then second passes.
-    if (!scene->side_stream) RT_HIP(hipStreamCreateWithFlags(&scene->side_stream, hipStreamNonBlocking));
+    if (!scene->side_stream) RT_HIP(rt_take_stream(scene->device, &scene->side_stream));
     if (!scene->side_event) RT_HIP(hipEventCreateWithFlags(&scene->side_event, hipEventDisableTiming));
     if (!scene->rejudge_event) RT_HIP(hipEventCreateWithFlags(&scene->rejudge_event, hipEventDisableTiming));
     RT_HIP(hipEventRecord(scene->rejudge_event, st));

@@ -29,6 +29,12 @@ void rt_set_error(const std::string &msg);
 // Makes `device` current and forgets an error that another user of the HIP runtime in this process left behind:
 // hipGetLastError reports the last failure of any call on the thread (PyTorch's included) until somebody reads it, and a
 // check after one of this library's launches must speak of that launch only.
+// Streams of the default priority, kept for the life of the process: a scene takes its streams from here and hands them
+// back when it is destroyed (making one costs 2 to 3 ms, a tenth of what some scenes take to set up).  The device must
+// be current.  Defined in scene.hip.
+hipError_t rt_take_stream(int device, hipStream_t *out);
+void rt_give_stream(int device, hipStream_t stream);
+
 static inline hipError_t rt_use_device(int device) {
     const hipError_t e = hipSetDevice(device);
     (void)hipGetLastError();

@@ -1,5 +1,7 @@
 // Scene handle: uploads the polygon list once and derives frames, bounding boxes and in-plane coordinates.
 #include <algorithm>
+#include <mutex>
+#include <utility>
 #include <cmath>
 #include <cstring>
 
@@ -249,6 +251,29 @@ extern "C" int rt_scene_synchronize(rt_scene *s) {
     return 0;
 }
 
+static std::mutex g_stream_mutex;
+static std::vector<std::pair<int, hipStream_t>> g_idle_streams;  // (device, stream)
+
+hipError_t rt_take_stream(int device, hipStream_t *out) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        for (size_t i = 0; i < g_idle_streams.size(); ++i)
+            if (g_idle_streams[i].first == device) {
+                *out = g_idle_streams[i].second;
+                g_idle_streams.erase(g_idle_streams.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void rt_give_stream(int device, hipStream_t stream) {
+    if (!stream) return;
+    (void)hipStreamSynchronize(stream);
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    g_idle_streams.emplace_back(device, stream);
+}
+
 extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *vert_off, const double *verts,
                                      const double *planes, const int32_t *material_id, const int32_t *building_id) {
     if (n_poly <= 0 || !vert_off || !verts || !planes) {
@@ -360,7 +385,8 @@ extern "C" rt_scene *rt_scene_create(int device, int32_t n_poly, const int32_t *
         ok = false;
     }
     if (ok && rt_noalloc_setup(device) != 0) ok = false;
-    if (ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+    // (both streams now: the second used to be made on its first use, in the middle of the first painting or solve)
+    if (ok && (rt_take_stream(device, &s->stream) != hipSuccess || rt_take_stream(device, &s->side_stream) != hipSuccess)) {
         rt_set_error("rt_scene_create: hipStreamCreate failed");
         ok = false;
     }
@@ -380,14 +406,8 @@ extern "C" void rt_scene_destroy(rt_scene *s) {
     if (s->caller_event) (void)hipEventDestroy(s->caller_event);
     if (s->side_event) (void)hipEventDestroy(s->side_event);
     if (s->rejudge_event) (void)hipEventDestroy(s->rejudge_event);
-    if (s->side_stream) {
-        (void)hipStreamSynchronize(s->side_stream);
-        (void)hipStreamDestroy(s->side_stream);
-    }
-    if (s->stream) {
-        (void)hipStreamSynchronize(s->stream);
-        (void)hipStreamDestroy(s->stream);
-    }
+    rt_give_stream(s->device, s->side_stream);
+    rt_give_stream(s->device, s->stream);
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     for (void *p : s->allocations) (void)hipFree(p);
     if (s->ws) (void)hipFree(s->ws);

@@ -2142,7 +2142,7 @@ extern "C" int rt_solve_paths(rt_scene *scene, rt_candidates *cand, const double
         }
         if (!head_done) {
             // beside the reflection launch just queued: the head on the side stream, then the main stream waits for it
-            if (!scene->side_stream) SOLVE_HIP(hipStreamCreateWithFlags(&scene->side_stream, hipStreamNonBlocking));
+            if (!scene->side_stream) SOLVE_HIP(rt_take_stream(scene->device, &scene->side_stream));
             if (!scene->side_event) SOLVE_HIP(hipEventCreateWithFlags(&scene->side_event, hipEventDisableTiming));
             // (the head takes blocks of the scene's temporary memory that a call before this one may have handed back
             // with its kernels still queued on the main stream — the deferred forms of the description and the field

@@ -3094,7 +3094,7 @@ extern "C" int rt_visibility_with_faces(rt_scene *scene, int32_t n_rows, const i
     }
     RT_HIP(rt_use_device(scene->device));
     // a second stream of the default priority (streams of different priorities are not used anywhere in this library)
-    if (!scene->side_stream) RT_HIP(hipStreamCreateWithFlags(&scene->side_stream, hipStreamNonBlocking));
+    if (!scene->side_stream) RT_HIP(rt_take_stream(scene->device, &scene->side_stream));
     const size_t n = (size_t)scene->view.n;
     std::vector<int32_t> a_off(face_off, face_off + n_faces + 1), a_self(n_faces, -1);
     if (self_index) a_self.assign(self_index, self_index + n_faces);
