@@ -2557,6 +2557,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
             const PolyMeta mb = meta_f[B];
             const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
             const double lymin = fmax(mb.ymin, span.y0), lymax = fmin(mb.ymax, span.y1);
+            // (the bitmap goes on serving here: the same test as in the stretches above, the same for every thread --
+            // nobody writes the workgroup's bitmap while it is read)
+            if (grid_on && grid_hides(grid, s_gdom, lxmin, lxmax, lymin, lymax)) continue;
             if (wave == 0) {
                 // ---- canvas polygons whose box meets B's box
                 int n_list = 0;
@@ -2656,6 +2659,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
                 }
                 ++n_canvas;
             }
+            // (shown or hidden, the cells inside B are behind the canvas now; its ring is entry 0 of the staged store)
+            if (grid_on && s_fits && n_list > 0) grid_mark(store, 0, grid, s_gdom, (int)threadIdx.x, (int)blockDim.x);
             __syncthreads();  // canvas / LDS store are rewritten for the next candidate
         }
 #ifdef RT_VIS_STAMPS
