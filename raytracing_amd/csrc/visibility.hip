@@ -2557,9 +2557,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void k_vis_paint(SceneVie
             const PolyMeta mb = meta_f[B];
             const double lxmin = fmax(mb.xmin, span.x0), lxmax = fmin(mb.xmax, span.x1);
             const double lymin = fmax(mb.ymin, span.y0), lymax = fmin(mb.ymax, span.y1);
-            // (the bitmap goes on serving here: the same test as in the stretches above, the same for every thread --
-            // nobody writes the workgroup's bitmap while it is read)
-            if (grid_on && grid_hides(grid, s_gdom, lxmin, lxmax, lymin, lymax)) continue;
+            // (the bitmap goes on serving here: the same test as in the stretches above.  Every thread makes it and the
+            // candidate is passed by only when all of them find it hidden: a bit that another wave has set a moment ago
+            // may not have arrived for every reader -- a barrier does not wait for writes to global memory -- and the
+            // waves must take the same way through the barriers below; a reader that misses a bit only sends the
+            // candidate the usual way)
+            if (grid_on && __syncthreads_and(grid_hides(grid, s_gdom, lxmin, lxmax, lymin, lymax) ? 1 : 0)) continue;
             if (wave == 0) {
                 // ---- canvas polygons whose box meets B's box
                 int n_list = 0;
