@@ -335,6 +335,30 @@ def test_small_tiles_on_a_share_of_the_lln_rows(places):
         scene.set_visibility_tiling(-1, 0)
 
 
+def test_faces_whose_canvas_outgrows_the_resident_store():
+    """ny.geojson tiled 8 x 8: its large faces see five hundred polygons each, more than the four-wave painter's resident
+    canvas holds (320), so what is left of such a face is decided one candidate at a time, with the covered-cell bitmap
+    still in front.  The same rows painted 128 at a time go through the sixteen-wave painter instead, in tiles, whose
+    canvas holds them: the two must agree entry for entry."""
+    from raytracing_amd import geometry as geom
+    from raytracing_amd import scenarios
+
+    scene = geom.scene_arrays_of(scenarios.ny_tiled(8)[0].get_polygons_list()).device_scene()
+    n = scene.n
+    rows = np.unique(np.concatenate([np.arange(0, n, 17), [733, 1461, 2189, 2857, 2917, 3585, 3736, 4860]])).astype(np.int32)
+    assert len(rows) > 256
+    try:
+        scene.set_visibility_tiling(0, 0)  # every face whole: the large ones outgrow the store
+        whole = np.asarray(scene.visibility_rows(rows)).astype(bool)
+    finally:
+        scene.set_visibility_tiling(-1, 0)
+    assert whole.sum(axis=1).max() > 320, "no row of this choice outgrows the resident store"
+    for k0 in range(0, len(rows), 128):
+        part = np.asarray(scene.visibility_rows(rows[k0:k0 + 128])).astype(bool)
+        bad = np.argwhere(part != whole[k0:k0 + 128])
+        assert len(bad) == 0, f"rows {k0}..: {len(bad)} entries differ, first {bad[:10].tolist()}"
+
+
 @pytest.mark.parametrize("name", ["small", "ny", "place_levant", "place_saint_jean/place_saint_jean"])
 def test_sharp_edges_match_oracle(places, name):
     from oracle import geometry_oracle as go
