@@ -1594,8 +1594,9 @@ __global__ __launch_bounds__(1024) void k_face_queue(const int32_t *__restrict__
 
 // Tiles of every face: a face with fewer than min_candidates candidates is one unbounded tile; a larger one gets up to
 // ceil(m / per_tile) rectangles of the (azimuth, polar) plane (at most VIS_MAX_TILES) that hold about the same number of
-// candidate centres each: the tile with the most centres is cut at their median along the direction in which they
-// spread more (a 1 024-bin histogram over their range), until no tile holds more than per_tile.  Azimuth alone does
+// candidate centres each: the tile with the most centres is cut at their median (a 1 024-bin histogram over their
+// range) along azimuth or along the polar angle, whichever cut has fewer of the tile's boxes lying across it, until no
+// tile holds more than per_tile.  Azimuth alone does
 // not do: a wall looks along the ground, every far building lies on the horizon line, and that line has ONE azimuth
 // from the wall's centre (sectors of a side-looking screen of lln's emitter held 1 000 to 1 300 candidates each where
 // 48 were asked for).  bounds[4 (f VIS_MAX_TILES + t)] .. + 3 = x0, x1, y0, y1 of tile t; the outermost tiles are
@@ -1605,12 +1606,12 @@ __global__ __launch_bounds__(VIS_TILE_THREADS) void k_vis_tiles(int n, const Pol
                                                     int per_tile, const int32_t *__restrict__ queue, int top_faces,
                                                     int top_per_tile, double *__restrict__ bounds,
                                                     int32_t *__restrict__ n_tiles) {
-    __shared__ int hist[VIS_TILE_BINS];
+    __shared__ int hist[2 * VIS_TILE_BINS];  // along azimuth, then along the polar angle
     __shared__ double tb[VIS_MAX_TILES][4];
     __shared__ int tcnt[VIS_MAX_TILES];  // centres in the tile; negative once it cannot be cut further
     __shared__ double red[VIS_TILE_THREADS / 64][4];
-    __shared__ double s_lo, s_scale;
-    __shared__ int s_sel, s_axis, s_n, s_bin, s_cum;
+    __shared__ double s_lo[2], s_scale[2], s_range[2], s_cut[2];
+    __shared__ int s_sel, s_n, s_bin[2], s_cum[2], s_straddle[2];
     __shared__ int s_wsum[VIS_TILE_THREADS / 64];
     static_assert(VIS_TILE_BINS == VIS_TILE_THREADS, "one bin of the histogram a thread");
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1640,19 +1641,36 @@ __global__ __launch_bounds__(VIS_TILE_THREADS) void k_vis_tiles(int n, const Pol
     }
     const PolyMeta *meta_f = meta + (size_t)f * n;
     const int32_t *ord = order + (size_t)f * m_stride;
-    // the centres of this thread's candidates: in registers when eight a thread are enough (every cut reads them twice)
+    // the centres and half widths of this thread's candidates' boxes: in registers when eight a thread are enough (every
+    // cut reads them three times)
     const bool cached = m <= 8 * VIS_TILE_THREADS;
     double ccx[8], ccy[8];
+    float chx[8], chy[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = tid + j * VIS_TILE_THREADS;
         ccx[j] = ccy[j] = NAN;  // (no tile holds it)
+        chx[j] = chy[j] = 0.0f;
         if (cached && k < m) {
             const PolyMeta &mb = meta_f[ord[k]];
             ccx[j] = 0.5 * (mb.xmin + mb.xmax);
             ccy[j] = 0.5 * (mb.ymin + mb.ymax);
+            chx[j] = (float)(0.5 * (mb.xmax - mb.xmin));
+            chy[j] = (float)(0.5 * (mb.ymax - mb.ymin));
         }
     }
+    // fn(centre x, centre y, half width x, half width y) for each of this thread's candidates
+    auto each = [&](auto fn) {
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fn(ccx[j], ccy[j], (double)chx[j], (double)chy[j]);
+        } else {
+            for (int k = tid; k < m; k += VIS_TILE_THREADS) {
+                const PolyMeta &mb = meta_f[ord[k]];
+                fn(0.5 * (mb.xmin + mb.xmax), 0.5 * (mb.ymin + mb.ymax), 0.5 * (mb.xmax - mb.xmin), 0.5 * (mb.ymax - mb.ymin));
+            }
+        }
+    };
     if (tid == 0) {
         tb[0][0] = -INFINITY;
         tb[0][1] = INFINITY;
@@ -1678,23 +1696,14 @@ __global__ __launch_bounds__(VIS_TILE_THREADS) void k_vis_tiles(int n, const Pol
         const double x0 = tb[sel][0], x1 = tb[sel][1], y0 = tb[sel][2], y1 = tb[sel][3];
         // (a centre belongs to the tile whose half-open rectangle (x0, x1] x (y0, y1] holds it)
         double lo_x = INFINITY, hi_x = -INFINITY, lo_y = INFINITY, hi_y = -INFINITY;
-        auto widen = [&](double cx, double cy) {
+        each([&](double cx, double cy, double, double) {
             if (cx > x0 && cx <= x1 && cy > y0 && cy <= y1) {
                 lo_x = fmin(lo_x, cx);
                 hi_x = fmax(hi_x, cx);
                 lo_y = fmin(lo_y, cy);
                 hi_y = fmax(hi_y, cy);
             }
-        };
-        if (cached) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) widen(ccx[j], ccy[j]);
-        } else {
-            for (int k = tid; k < m; k += VIS_TILE_THREADS) {
-                const PolyMeta &mb = meta_f[ord[k]];
-                widen(0.5 * (mb.xmin + mb.xmax), 0.5 * (mb.ymin + mb.ymax));
-            }
-        }
+        });
         for (int off = 32; off > 0; off >>= 1) {
             lo_x = fmin(lo_x, __shfl_xor(lo_x, off));
             hi_x = fmax(hi_x, __shfl_xor(hi_x, off));
@@ -1707,7 +1716,7 @@ __global__ __launch_bounds__(VIS_TILE_THREADS) void k_vis_tiles(int n, const Pol
             red[wave][2] = lo_y;
             red[wave][3] = hi_y;
         }
-        for (int i = tid; i < VIS_TILE_BINS; i += VIS_TILE_THREADS) hist[i] = 0;
+        for (int i = tid; i < 2 * VIS_TILE_BINS; i += VIS_TILE_THREADS) hist[i] = 0;
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < VIS_TILE_THREADS / 64; ++w) {
@@ -1716,64 +1725,87 @@ __global__ __launch_bounds__(VIS_TILE_THREADS) void k_vis_tiles(int n, const Pol
                 red[0][2] = fmin(red[0][2], red[w][2]);
                 red[0][3] = fmax(red[0][3], red[w][3]);
             }
-            const double rx = red[0][1] - red[0][0], ry = red[0][3] - red[0][2];
-            const int axis = rx >= ry ? 0 : 1;
-            const double range = axis == 0 ? rx : ry;
-            if (!(range > 1e-5)) {
-                tcnt[sel] = -tcnt[sel];  // its centres sit on one spot
-                s_axis = -1;
-            } else {
-                s_axis = axis;
-                s_lo = axis == 0 ? red[0][0] : red[0][2];
-                s_scale = VIS_TILE_BINS / range;
+            // a cut is looked for along both directions; one along which the centres sit on one spot is no cut
+            for (int a = 0; a < 2; ++a) {
+                const double range = red[0][2 * a + 1] - red[0][2 * a];
+                s_range[a] = range;
+                s_lo[a] = red[0][2 * a];
+                s_scale[a] = range > 1e-5 ? VIS_TILE_BINS / range : 0.0;
+                s_straddle[a] = 0;
             }
         }
         __syncthreads();
-        const int axis = s_axis;
-        if (axis < 0) continue;
-        const double lo = s_lo, scale = s_scale;
-        auto count = [&](double cx, double cy) {
+        const double lo_a[2] = {s_lo[0], s_lo[1]}, scale_a[2] = {s_scale[0], s_scale[1]};
+        each([&](double cx, double cy, double, double) {
             if (cx > x0 && cx <= x1 && cy > y0 && cy <= y1) {
-                int bin = (int)(((axis == 0 ? cx : cy) - lo) * scale);
-                bin = bin < 0 ? 0 : (bin >= VIS_TILE_BINS ? VIS_TILE_BINS - 1 : bin);
-                atomicAdd(&hist[bin], 1);
+                for (int a = 0; a < 2; ++a) {
+                    if (scale_a[a] == 0.0) continue;
+                    int bin = (int)(((a == 0 ? cx : cy) - lo_a[a]) * scale_a[a]);
+                    bin = bin < 0 ? 0 : (bin >= VIS_TILE_BINS ? VIS_TILE_BINS - 1 : bin);
+                    atomicAdd(&hist[a * VIS_TILE_BINS + bin], 1);
+                }
             }
-        };
-        if (cached) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) count(ccx[j], ccy[j]);
-        } else {
-            for (int k = tid; k < m; k += VIS_TILE_THREADS) {
-                const PolyMeta &mb = meta_f[ord[k]];
-                count(0.5 * (mb.xmin + mb.xmax), 0.5 * (mb.ymin + mb.ymax));
-            }
-        }
+        });
         __syncthreads();
-        // the bin at whose upper end half of the tile's centres are reached: a scan of the histogram over the workgroup
-        // (one bin a thread), the first such bin by an atomic minimum
+        // along each direction, the bin at whose upper end half of the tile's centres are reached: a scan of the
+        // histogram over the workgroup (one bin a thread), the first such bin by an atomic minimum
         const int cnt = tcnt[sel];
-        int cum = hist[tid];
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(cum, off);
-            if (lane >= off) cum += y;
+        for (int a = 0; a < 2; ++a) {
+            int cum = hist[a * VIS_TILE_BINS + tid];
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(cum, off);
+                if (lane >= off) cum += y;
+            }
+            if (lane == 63) s_wsum[wave] = cum;
+            if (tid == 0) s_bin[a] = VIS_TILE_BINS - 2;  // (the last bin is never the cut: its upper end is the range's)
+            __syncthreads();
+            for (int w = 0; w < wave; ++w) cum += s_wsum[w];
+            if (2 * cum >= cnt && tid < VIS_TILE_BINS - 2) atomicMin(&s_bin[a], tid);
+            __syncthreads();
+            if (tid == s_bin[a]) {
+                s_cum[a] = cum;
+                // the border at the upper end of that bin, nudged off the round value so that it does not run along a
+                // polygon edge that sits exactly on a bin's end
+                s_cut[a] = scale_a[a] > 0.0 ? lo_a[a] + (tid + 1) / scale_a[a] + 1.234567e-7 : 0.0;
+            }
+            __syncthreads();
         }
-        if (lane == 63) s_wsum[wave] = cum;
-        if (tid == 0) s_bin = VIS_TILE_BINS - 2;  // (the last bin is never the cut: its upper end is the range's)
-        __syncthreads();
-        for (int w = 0; w < wave; ++w) cum += s_wsum[w];
-        if (2 * cum >= cnt && tid < VIS_TILE_BINS - 2) atomicMin(&s_bin, tid);
-        __syncthreads();
-        if (tid == s_bin) s_cum = cum;
+        // Of the two cuts the one that fewer boxes lie across is taken: a box across the cut is a candidate of both
+        // tiles.  (The centres of a wall's far candidates spread widest in azimuth although nearly all of them sit at
+        // the horizon's one azimuth: a median there has most boxes across it, and four tiles of a face of 6 200
+        // candidates held 6 200, 4 800, 3 100 and 2 000 of them.)
+        {
+            const double cut_x = s_cut[0], cut_y = s_cut[1];
+            int across_x = 0, across_y = 0;
+            each([&](double cx, double cy, double hx, double hy) {
+                if (cx > x0 && cx <= x1 && cy > y0 && cy <= y1) {
+                    across_x += (cx - hx < cut_x && cx + hx > cut_x) ? 1 : 0;
+                    across_y += (cy - hy < cut_y && cy + hy > cut_y) ? 1 : 0;
+                }
+            });
+            for (int off = 32; off > 0; off >>= 1) {
+                across_x += __shfl_xor(across_x, off);
+                across_y += __shfl_xor(across_y, off);
+            }
+            if (lane == 0) {
+                atomicAdd(&s_straddle[0], across_x);
+                atomicAdd(&s_straddle[1], across_y);
+            }
+        }
         __syncthreads();
         if (tid == 0) {
-            const int bin = s_bin, left = s_cum;
-            // the border at the upper end of that bin, nudged off the round value so that it does not run along a polygon
-            // edge that sits exactly on a bin's end
-            const double cut = lo + (bin + 1) / scale + 1.234567e-7;
-            if (left <= 0 || left >= cnt) {
-                tcnt[sel] = -cnt;
+            bool ok[2];
+            for (int a = 0; a < 2; ++a) ok[a] = s_scale[a] > 0.0 && s_cum[a] > 0 && s_cum[a] < cnt;
+            int axis = -1;
+            if (ok[0] && ok[1])
+                axis = s_straddle[0] != s_straddle[1] ? (s_straddle[0] < s_straddle[1] ? 0 : 1) : (s_range[0] >= s_range[1] ? 0 : 1);
+            else if (ok[0] || ok[1])
+                axis = ok[0] ? 0 : 1;
+            if (axis < 0) {
+                tcnt[sel] = -cnt;  // its centres sit on one spot, or all to one side of every cut
             } else {
-                const int nw = s_n;
+                const int nw = s_n, left = s_cum[axis];
+                const double cut = s_cut[axis];
                 for (int q = 0; q < 4; ++q) tb[nw][q] = tb[sel][q];
                 tb[sel][axis == 0 ? 1 : 3] = cut;
                 tb[nw][axis == 0 ? 0 : 2] = cut;
