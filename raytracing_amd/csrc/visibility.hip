@@ -2014,7 +2014,7 @@ __device__ inline void mark_twins(Store *cs, int s, int first, int stride) {
 #define VIS_STRETCH 256             /* candidates held against the bitmap at a time (one per thread of a four-wave workgroup) */
 #define VIS_GRID_MIN_CANDIDATES 256 /* faces with fewer candidates are painted without the bitmap */
 #ifndef VIS_GRID_MAX_CELLS
-#define VIS_GRID_MAX_CELLS 64       /* a candidate over more cells goes the usual way */
+#define VIS_GRID_MAX_CELLS 1024     /* a candidate over more cells goes the usual way (64: the same for a whole matrix, a sixth more for a rank's share of one, whose longest tiles hold the wide polygons round the pole of the view) */
 #endif
 #define VIS_GRID_MAX_NV 8           /* canvas polygons with more vertices set no bits */
 struct GridDomain {
